@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ -- run ONLY in the build container.
+
+Imports (never copies) the reference's Python from /root/reference and HF `GPTNeoXForCausalLM` to produce
+input/output vectors that pin the oracle (oracle/) and the host-side counterparts of the reference harness:
+
+  tiny_gptneox_fp32.npz   config 1 of BASELINE.json: L=2,H=256,NH=4,I=1024,V=512, rotary 16, parallel residual.
+                          - `w###`  : the 12L+4 tensors exactly as the reference's `GptNeoXWeights.load`
+                                      (codefuse_example.py:336-419) returns them after the reference's
+                                      `split_and_convert_process` (huggingface_convert.py:22-81) wrote the .bin files
+                                      (stored as fp16: every HF parameter was made fp16-representable first).
+                          - HF fp32 greedy: prompt(s), per-step logits and tokens (16-in / 8-out, and a ragged B=2 case
+                            whose rows were run through HF one by one, un-padded).
+  tiny_gptneox_tp2.json   sha256 of every tensor the reference loader returns for tensor_para_size=2, rank 0 and 1.
+  harness_io.json         I/O of to_word_list_format / Trie.printAutoSuggestions / is_garbage /
+                          token_stream_2_str_stream_convertor / get_data_package captured from the reference.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+REF = "/root/reference/examples/pytorch/codefuse"
+sys.path.insert(0, REF)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+CFG = dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermediate_size=1024, vocab_size=512,
+           rotary_pct=0.25, use_parallel_residual=True, hidden_act="gelu_new", layer_norm_eps=1e-5,
+           max_position_embeddings=64, tie_word_embeddings=False, bos_token_id=0, eos_token_id=2, attention_bias=True)
+
+
+def build_hf():
+    from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
+    cfg = GPTNeoXConfig(**CFG)
+    torch.manual_seed(1234)
+    m = GPTNeoXForCausalLM(cfg).eval()
+    g = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layernorm.weight" in n or "layer_norm.weight" in n:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "embed" in n or "lm_head" in n:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.12 * torch.randn(p.shape, generator=g))
+            p.copy_(p.half().float())  # fp16-representable so the fixture can store fp16
+    return cfg, m
+
+
+def export_with_reference(m, cfg, saved_dir, factor):
+    import huggingface_convert as hc
+    hf_config = vars(m.config)
+    for name, param in m.named_parameters():
+        array = param.detach().cpu().numpy().astype(np.float32)
+        if name == "gpt_neox.embed_in.weight":
+            array.tofile(saved_dir + "/model.wte.bin")
+        elif name == "gpt_neox.final_layer_norm.bias":
+            array.tofile(saved_dir + "/model.final_layernorm.bias.bin")
+        elif name == "gpt_neox.final_layer_norm.weight":
+            array.tofile(saved_dir + "/model.final_layernorm.weight.bin")
+        elif name in ("embed_out.weight", "lm_head.weight"):
+            array.tofile(saved_dir + "/model.lm_head.weight.bin")
+        else:
+            hc.split_and_convert_process(saved_dir, factor, name.replace("gpt_neox.", ""), None, hf_config, array.T)
+    # post-processing of huggingface_convert.py:192-206 (use_gptj_residual)
+    for l in range(cfg.num_hidden_layers):
+        a = np.fromfile(saved_dir + f"/model.layers.{l}.attention.dense.bias.bin", dtype=np.float32)
+        b = np.fromfile(saved_dir + f"/model.layers.{l}.mlp.dense_4h_to_h.bias.bin", dtype=np.float32)
+        (a + b).astype(np.float32).tofile(saved_dir + f"/model.layers.{l}.mlp.attention.bias.sum.bin")
+
+
+def load_with_reference(saved_dir, cfg, tp, rank):
+    import codefuse_example as ce
+    nh = cfg.num_attention_heads
+    w = ce.GptNeoXWeights(nh, cfg.hidden_size // nh, cfg.num_hidden_layers, cfg.vocab_size, 1024, tp, 1, True,
+                          int8_mode=0, inference_data_type="fp32", weights_data_type=np.float32)
+    assert w.load(saved_dir, tensor_para_rank=rank, pipeline_para_rank=0)
+    return [t.numpy() for t in w.w]
+
+
+def hf_greedy(m, ids, n_new):
+    logits_steps, toks = [], []
+    cur = torch.tensor([ids], dtype=torch.long)
+    with torch.no_grad():
+        for _ in range(n_new):
+            lg = m(cur).logits[0, -1].float()
+            t = int(torch.argmax(lg))
+            logits_steps.append(lg.numpy().copy())
+            toks.append(t)
+            cur = torch.cat([cur, torch.tensor([[t]])], dim=1)
+    return np.stack(logits_steps), toks
+
+
+class FakeTok:
+    """Deterministic stand-in tokenizer (the reference helpers only call encode/decode/get_vocab)."""
+
+    def __init__(self):
+        self.vocab = {}
+        words = ["\n", "}", "for", " (", "int", " i", "=", "0", ";", "def", " ", "re", "ret", "return", "retu", "r",
+                 "x", "y", "\n}", "中", "文", "a", "b", "ab", "abc", "éé"]
+        for i, w_ in enumerate(words):
+            self.vocab[w_] = i + 3
+
+    def get_vocab(self):
+        return dict(self.vocab)
+
+    def encode(self, text):
+        out, i = [], 0
+        keys = sorted(self.vocab, key=len, reverse=True)
+        while i < len(text):
+            for k in keys:
+                if text.startswith(k, i):
+                    out.append(self.vocab[k])
+                    i += len(k)
+                    break
+            else:
+                i += 1
+        return out
+
+    def decode(self, ids):
+        inv = {v: k for k, v in self.vocab.items()}
+        return "".join(inv.get(int(i), "") for i in ids)
+
+
+def harness_io():
+    import contextlib
+    import io
+    import codefuse_example as ce
+    tok = FakeTok()
+    res = {"vocab": tok.get_vocab()}
+    cases = [[["\n}", "for ("]], [["return", "x"], ["abc"]], [[""], ["}"]]]
+    res["to_word_list_format"] = [{"in": c, "out": ce.to_word_list_format(c, tok).numpy().tolist()} for c in cases]
+    trie = ce.Trie(tok.get_vocab())
+    tr = []
+    for key in ["re", "ret", "a", "zzz", "abc", ""]:
+        r = []
+        code = trie.printAutoSuggestions(key, r)
+        tr.append({"key": key, "code": code, "ids": sorted(t_i for _, t_i in r)})
+    res["trie"] = tr
+    cps = [65, 0x4E2D, 200, 65292, 8230, 0x1F600, 127, 128, 183, 12290, 0x3400, 0x2A700, 233]
+    res["is_garbage"] = [{"cp": c, "out": bool(ce.is_garbage(c))} for c in cps]
+    streams = []
+    for toks in ([tok.vocab["for"], tok.vocab[" ("], tok.vocab["int"], tok.vocab[" i"], tok.vocab["\n"], tok.vocab["中"],
+                  tok.vocab["文"], tok.vocab["x"], tok.vocab["éé"], 2],
+                 [tok.vocab["a"], tok.vocab[" "], tok.vocab["b"], 2, tok.vocab["x"]]):
+        conv = ce.token_stream_2_str_stream_convertor(2, tok, 0)
+        chunks = []
+        for t in toks:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                conv.append_token(t)
+            chunks.append(buf.getvalue())
+        streams.append({"tokens": toks, "chunks": chunks})
+    res["stream"] = streams
+    req = {"out_seq_length": 8, "prompts": [{"prompt": "def", "top_k": 3, "stop_words": ["\n}"]},
+                                           {"prompt": "for (", "temperature": 0.5, "stop_words": ["x"]}]}
+    res["get_data_package"] = {"in": req, "seed": 77, "out": ce.get_data_package(req, 77)}
+    req2 = {"out_seq_length": 4, "beam_width": 1, "prompts": [{"prompt": "a"}]}
+    res["get_data_package2"] = {"in": req2, "seed": 5, "out": ce.get_data_package(req2, 5)}
+    return res
+
+
+def main():
+    cfg, m = build_hf()
+    rng = np.random.RandomState(42)
+    prompt = rng.randint(3, cfg.vocab_size, size=16).tolist()
+    logits, toks = hf_greedy(m, prompt, 8)
+    # ragged batch: rows of length 16 and 11, each run through HF separately (no padding semantics involved)
+    prompt_b = rng.randint(3, cfg.vocab_size, size=11).tolist()
+    logits_b, toks_b = hf_greedy(m, prompt_b, 8)
+    prompt_1 = [int(rng.randint(3, cfg.vocab_size))]
+    logits_1, toks_1 = hf_greedy(m, prompt_1, 6)
+
+    with tempfile.TemporaryDirectory() as d1:
+        export_with_reference(m, cfg, d1, 1)
+        w1 = load_with_reference(d1, cfg, 1, 0)
+        files = sorted(os.listdir(d1))
+    # fp16 storage wherever it is exact (all HF parameters); the converter's bias sums stay fp32
+    arrays = {}
+    for i, a in enumerate(w1):
+        h = a.astype(np.float16)
+        arrays[f"w{i:03d}"] = h if np.array_equal(h.astype(np.float32), a) else a.astype(np.float32)
+    np.savez_compressed(
+        os.path.join(OUT, "tiny_gptneox_fp32.npz"), **arrays,
+        cfg=np.array([cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads, cfg.intermediate_size,
+                      cfg.num_hidden_layers, cfg.vocab_size, 16, 0, 2], dtype=np.int32),
+        prompt=np.array(prompt, dtype=np.int32), hf_logits=logits.astype(np.float32), hf_tokens=np.array(toks, np.int32),
+        prompt_b=np.array(prompt_b, dtype=np.int32), hf_logits_b=logits_b.astype(np.float32),
+        hf_tokens_b=np.array(toks_b, np.int32), prompt_1=np.array(prompt_1, dtype=np.int32),
+        hf_logits_1=logits_1.astype(np.float32), hf_tokens_1=np.array(toks_1, np.int32))
+
+    tp2 = {"files_tp1": files}
+    with tempfile.TemporaryDirectory() as d2:
+        export_with_reference(m, cfg, d2, 2)
+        tp2["files_tp2"] = sorted(os.listdir(d2))
+        for r in range(2):
+            ws = load_with_reference(d2, cfg, 2, r)
+            tp2[f"rank{r}"] = [{"shape": list(a.shape), "sha256": hashlib.sha256(
+                np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()} for a in ws]
+    with open(os.path.join(OUT, "tiny_gptneox_tp2.json"), "w") as f:
+        json.dump(tp2, f, indent=1)
+    with open(os.path.join(OUT, "harness_io.json"), "w") as f:
+        json.dump(harness_io(), f, indent=1, ensure_ascii=False)
+    print("tokens", toks, toks_b, toks_1)
+
+
+if __name__ == "__main__":
+    main()
