@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of a CodeFuse-13B-shaped GPT-NeoX (weight-only int8 by default), bs=1,
+1024-token prompt + 512 generated tokens, tensor parallel over --gpus ranks (one process per GPU, RCCL).
+
+  python bench.py --gpus 1 --steps 504 --warmup 8            # N = 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one decoded token (one pass of the per-token hot path: L decoder layers + LM head + dynamic decode).
+The 1024-token prefill runs through the real context path before the timed region (KV cache resident in HBM), then W
+untimed + K timed decode steps (W + K = 512 by default -> KV length 1024..1536).  Weights are synthetic
+(random int8 + fp16 scales of CodeFuse-13B's shape, generated on the device); there is no network for checkpoints.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=504)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--dtype", default="int8", choices=["int8", "fp16"])
+    p.add_argument("--prompt-len", type=int, default=1024)
+    p.add_argument("--batch", type=int, default=1)
+    p.add_argument("--layers", type=int, default=40)
+    p.add_argument("--heads", type=int, default=40)
+    p.add_argument("--head-dim", type=int, default=128)
+    p.add_argument("--inter", type=int, default=20480)
+    p.add_argument("--vocab", type=int, default=100864)
+    p.add_argument("--rotary", type=int, default=32)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-e2e", action="store_true")
+    p.add_argument("--profile-steps", type=int, default=48)
+    return p.parse_args()
+
+
+def synth_weights(a, tp, dev):
+    """CodeFuse-13B-shaped synthetic shard in the reference's weight-list order."""
+    L, H, I, V = a.layers, a.heads * a.head_dim, a.inter, a.vocab
+    hl, il = H // tp, I // tp
+    g = torch.Generator(device=dev).manual_seed(1234)
+    h16 = dict(dtype=torch.float16, device=dev)
+
+    def rn(*shape, std=0.02, mean=0.0):
+        return (torch.randn(*shape, generator=g, device=dev) * std + mean).to(torch.float16)
+
+    groups = [[] for _ in range(12)]
+    int8_w = [[] for _ in range(4)]
+    scales = [[] for _ in range(4)]
+    shapes = [(H, 3 * hl), (hl, H), (H, il), (il, H)]
+    empty = torch.empty(0, **h16)
+    for _ in range(L):
+        groups[0].append(rn(H))
+        groups[1].append(rn(H, mean=1.0))
+        groups[3].append(rn(3 * hl))
+        groups[5].append(empty)
+        groups[7].append(rn(il))
+        groups[9].append(rn(H))
+        groups[10].append(rn(H))
+        groups[11].append(rn(H, mean=1.0))
+        for i, (K, N) in enumerate(shapes):
+            gi = (2, 4, 6, 8)[i]
+            if a.dtype == "int8":
+                # the tile layout is a permutation of the matrix: uniform random bytes ARE a uniform random int8 matrix
+                q = torch.randint(1, 256, (K, N), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+                int8_w[i].append(q.view(torch.int8))
+                scales[i].append((torch.rand(N, generator=g, device=dev) * 2e-4 + 1e-4).to(torch.float16))
+                groups[gi].append(empty)
+            else:
+                groups[gi].append(rn(K, N))
+    weights = [t for grp in groups for t in grp]
+    weights += [rn(V, H), rn(H, mean=1.0), rn(H), rn(V, H)]
+    return weights, [t for grp in int8_w for t in grp], [t for grp in scales for t in grp]
+
+
+def bytes_per_token(a, tp, t_mean):
+    L, H, I, V = a.layers, a.heads * a.head_dim, a.inter, a.vocab
+    w = 1 if a.dtype == "int8" else 2
+    return (L * (4 * H * H + 2 * H * I) * w + V * H * 2 + 2 * L * t_mean * H * 2 * a.batch) / tp
+
+
+def cpu_baseline(a):
+    """Oracle (CPU restatement, kind "port") on a bounded sample: one decode step at KV length 1024 over 2 of the L
+    layers (+ nothing else), all host cores; tokens/s extrapolated by L/2."""
+    from oracle import oracle as orc
+    from tests.helpers import quantize_layers  # noqa: F401
+    Lc = min(2, a.layers)
+    H, I, nh, dh = a.heads * a.head_dim, a.inter, a.heads, a.head_dim
+    rng = np.random.RandomState(0)
+    layers = []
+    for _ in range(Lc):
+        lay = dict(ln1_g=np.ones(H, np.float32), ln1_b=np.zeros(H, np.float32), ln2_g=np.ones(H, np.float32),
+                   ln2_b=np.zeros(H, np.float32), qkv_b=np.zeros(3 * H, np.float32), ffn1_b=np.zeros(I, np.float32),
+                   ffn2_b=np.zeros(H, np.float32))
+        for name, (K, N) in dict(qkv=(H, 3 * H), out=(H, H), ffn1=(H, I), ffn2=(I, H)).items():
+            if a.dtype == "int8":
+                lay[name + "_q"] = rng.randint(-127, 128, size=(K, N)).astype(np.int8)
+                lay[name + "_s"] = np.full(N, 2e-4, np.float32)
+            else:
+                lay[name + "_w"] = (rng.standard_normal((K, N)).astype(np.float32) * 0.02)
+        layers.append(lay)
+    glob = dict(wte=np.zeros((8, H), np.float32), final_ln_g=np.ones(H, np.float32), final_ln_b=np.zeros(H, np.float32),
+                lm_head=np.zeros((8, H), np.float32))
+    cfg = dict(head_num=nh, size_per_head=dh, inter_size=I, num_layer=Lc, vocab_size=8, rotary_dim=a.rotary, end_id=2,
+               int8_mode=1 if a.dtype == "int8" else 0, fp16=1)
+    m = orc.Model(cfg, layers, glob)
+    t = a.prompt_len
+    s_max = t + 8
+    kc = (rng.standard_normal((Lc, 1, nh, s_max, dh)).astype(np.float32) * 0.5)
+    vc = (rng.standard_normal((Lc, 1, nh, s_max, dh)).astype(np.float32) * 0.5)
+    x = rng.standard_normal((1, H)).astype(np.float32)
+    args = (np.array([t], np.int32), np.zeros(1, np.int32), np.zeros((1, s_max), np.uint8), np.zeros(1, np.uint8))
+    m.decoder_step(x, kc, vc, *args, t + 1)  # warm
+    t0 = time.time()
+    reps = 0
+    while time.time() - t0 < 10.0 and reps < 8:
+        m.decoder_step(x, kc, vc, *args, t + 1)
+        reps += 1
+    dt = (time.time() - t0) / reps
+    tok_s = 1.0 / (dt * a.layers / Lc)
+    return {"value": tok_s, "unit": "tokens/s", "cores": int(orc.lib().orc_num_threads()), "kind": "port",
+            "sample": f"{reps} decode steps at KV length {t} over {Lc} of {a.layers} layers "
+                      f"(no LM head), extrapolated x{a.layers / Lc:g}; oracle/ftcf_oracle.c"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    from fastertransformer4codefuse_amd import capi
+    from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
+    tp = world
+    H = a.heads * a.head_dim
+    weights, int8_w, scales = synth_weights(a, tp, dev)
+    end_id = 2
+    op = GptNeoXOp(group, rank, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, end_id, tp, 1,
+                   1 if a.dtype == "int8" else 0, 2048, True, weights, int8_w, scales)
+    B, S = a.batch, a.prompt_len
+    out_len = a.warmup + a.steps
+    gi = torch.Generator().manual_seed(42)
+    ids = torch.randint(3, a.vocab, (B, S), generator=gi, dtype=torch.int32).to(dev)
+    lens = torch.full((B,), S, dtype=torch.int32, device=dev)
+    total = S + out_len
+    out_ids = torch.empty((B, 1, total), dtype=torch.int32, device=dev)
+    seq = torch.empty((B, 1), dtype=torch.int32, device=dev)
+    top_k = np.array([1], np.int32)
+    minlen = np.array([out_len], np.int32)  # end_id cannot be sampled: all steps run
+
+    def make_args(olen):
+        fa = capi.ForwardArgs()
+        fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+        fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, olen, 1
+        fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+        fa.min_length, fa.n_min_length = minlen.ctypes.data, 1
+        fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+        return fa
+
+    L = capi.lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- untimed: one short request to warm every kernel / allocation ----
+    fa = make_args(out_len)
+    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))
+    capi.check(L.ftcf_gptneox_step(op._h, 2, None))
+    capi.check(L.ftcf_gptneox_finish(op._h))
+    # ---- the measured request ----
+    torch.cuda.synchronize()
+    barrier()
+    tp0 = time.perf_counter()
+    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))  # 1024-token prefill through the real context path
+    torch.cuda.synchronize()
+    prefill_wall_ms = (time.perf_counter() - tp0) * 1e3
+    done = C.c_int(0)
+    capi.check(L.ftcf_gptneox_step(op._h, a.warmup, C.byref(done)))
+    assert done.value == a.warmup
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    capi.check(L.ftcf_gptneox_step(op._h, a.steps, C.byref(done)))
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    assert done.value == a.steps, f"only {done.value} of {a.steps} steps ran"
+    capi.check(L.ftcf_gptneox_finish(op._h))
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    st = op.stats()
+
+    # ---- end-to-end latency of the whole request (prefill + 512 tokens), the reference README's metric ----
+    e2e_ms = None
+    if not a.no_e2e:
+        torch.cuda.synchronize()
+        barrier()
+        t2 = time.perf_counter()
+        capi.check(L.ftcf_gptneox_forward(op._h, C.byref(fa)))
+        torch.cuda.synchronize()
+        barrier()
+        e2e_ms = (time.perf_counter() - t2) * 1e3
+
+    # ---- roofline leg: HIP events around every weight-streaming launch of a short profiled run ----
+    roof = None
+    if a.profile_steps > 0:
+        op.set_profiling(True)
+        fa2 = make_args(out_len)
+        capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa2)))
+        capi.check(L.ftcf_gptneox_step(op._h, a.profile_steps, None))
+        capi.check(L.ftcf_gptneox_finish(op._h))
+        ps = op.stats()
+        op.set_profiling(False)
+        if ps["gemv_launches"] > 0:
+            per_launch_bytes = ps["gemv_bytes"] / ps["gemv_launches"]
+            avg_ms = ps["gemv_ms_sum"] / ps["gemv_launches"]
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": None, "kernel": "k_ln_gemv (LN + QKV + FFN1 weight stream) or k_gemv_splitk, whichever "
+                    "dominates", "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
+                    "launches": ps["gemv_launches"], "measured_over": f"{a.profile_steps} profiled decode steps"}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    tok_s = a.steps * B / elapsed
+    t_mean = S + a.warmup + a.steps / 2.0
+    bpt = bytes_per_token(a, tp, t_mean)
+    res = {
+        "metric": "decode_tokens_per_sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        # the reference's README quotes 75 tok/s (1xA100) / 98 tok/s (2xA100 TP=2) for int8, 48 / 77 fp16
+        "vs_baseline": (tok_s / {("int8", 1): 75.0, ("int8", 2): 98.0, ("fp16", 1): 48.0, ("fp16", 2): 77.0}[(a.dtype, world)]
+                        if (a.dtype, world) in (("int8", 1), ("int8", 2), ("fp16", 1), ("fp16", 2))
+                        and a.layers == 40 and a.batch == 1 else None),
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"CodeFuse-13B-shaped GPT-NeoX (L={a.layers},H={H},I={a.inter},V={a.vocab}) "
+                               f"{'weight-only int8' if a.dtype == 'int8' else 'fp16'} TP={tp}, bs={B}, "
+                               f"{S}-in/{out_len}-out greedy decode", "weights": a.dtype, "tensor_parallel": tp,
+                   "batch": B, "prompt_len": S, "output_len": out_len},
+        "prefill_ms": st["prefill_ms"], "prefill_wall_ms": prefill_wall_ms, "e2e_ms": e2e_ms,
+        "hbm_bytes_per_token_per_gpu": bpt,
+        "path_roofline_frac": bpt * tok_s / 8e12,  # whole-token HBM roofline (8 TB/s), incl. KV + fp16 LM head
+        "roofline": roof,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(a)
+        except Exception as e:  # the oracle is only a reported baseline
+            res["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

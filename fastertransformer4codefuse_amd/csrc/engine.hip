@@ -1,0 +1,1022 @@
+// Host-side engine + C ABI (include/ftcf.h) of the MI355X GPT-NeoX / CodeFuse decoder.
+//
+// Host classes mirror the reference's layer split (layers are thin: they own no scratch of their own and never
+// reMalloc per call -- one arena is planned per request shape):
+//   GptNeoX               <- models/gptneox/GptNeoX.cc:386-1052 (generation loop, LM head, dynamic decode, outputs)
+//   GptNeoXContextDecoder <- models/gptneox/GptNeoXContextDecoder.cc:223-512 (prefill)
+//   GptNeoXDecoder        <- models/gptneox/GptNeoXDecoder.cc:197-389 (one token through L layers)
+//   DecoderSelfAttentionLayer / FfnLayer / DynamicDecodeLayer are the launch helpers used by those.
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ftcf.h"
+#include "ftcf_common.h"
+#include "host_quant.h"
+#include "kernels.h"
+
+using namespace ftcf;
+
+// ---------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+template<typename F>
+static int guarded(F&& f)
+{
+    try {
+        f();
+        return FTCF_OK;
+    }
+    catch (const ftcf::Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    }
+    catch (const std::exception& e) {
+        g_last_error = e.what();
+        return FTCF_ERR_INVALID_ARG;
+    }
+}
+
+extern "C" const char* ftcf_last_error(void)
+{
+    return g_last_error.c_str();
+}
+extern "C" int ftcf_version(void)
+{
+    return FTCF_VERSION;
+}
+extern "C" int ftcf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static void require_device()
+{
+    if (ftcf_device_count() <= 0) {
+        throw Error(FTCF_ERR_NO_DEVICE,
+                    "no HIP device visible: the MI355X kernels cannot run (there is no CPU fallback in this library)");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// communicator (RCCL over xGMI) -- utils/nccl_utils.cc:56-435, nccl_inherit_utils.cc:25-68
+// ---------------------------------------------------------------------------------------------------------------
+struct ftcf_comm {
+    ncclComm_t comm = nullptr;
+    int        world = 1, rank = 0, device = 0;
+};
+
+#define FTCF_NCCL_CHECK(expr)                                                                                          \
+    do {                                                                                                               \
+        ncclResult_t _r = (expr);                                                                                      \
+        if (_r != ncclSuccess) {                                                                                       \
+            throw Error(FTCF_ERR_COMM, std::string("RCCL error ") + ncclGetErrorString(_r) + " (" #expr ")");          \
+        }                                                                                                              \
+    } while (0)
+
+extern "C" int ftcf_comm_get_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES])
+{
+    return guarded([&] {
+        static_assert(sizeof(ncclUniqueId) == FTCF_UNIQUE_ID_BYTES, "unique id size");
+        ncclUniqueId uid;
+        FTCF_NCCL_CHECK(ncclGetUniqueId(&uid));
+        memcpy(id, &uid, sizeof(uid));
+    });
+}
+
+extern "C" int ftcf_comm_init(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_size, int rank, int device,
+                              ftcf_comm_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(out != nullptr && world_size >= 1 && rank >= 0 && rank < world_size, "bad communicator args");
+        require_device();
+        FTCF_HIP_CHECK(hipSetDevice(device));
+        auto c    = std::make_unique<ftcf_comm>();
+        c->world  = world_size;
+        c->rank   = rank;
+        c->device = device;
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof(uid));
+        FTCF_NCCL_CHECK(ncclCommInitRank(&c->comm, world_size, uid, rank));
+        *out = c.release();
+    });
+}
+
+extern "C" int ftcf_comm_destroy(ftcf_comm_t c)
+{
+    return guarded([&] {
+        if (c) {
+            if (c->comm) {
+                ncclCommDestroy(c->comm);
+            }
+            delete c;
+        }
+    });
+}
+
+extern "C" int ftcf_comm_allreduce_sum(ftcf_comm_t c, void* buf, size_t count, ftcf_dtype dtype, void* stream)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(c && c->comm, "communicator not initialised");
+        FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, dtype == FTCF_FP16 ? ncclFloat16 : ncclFloat32, ncclSum,
+                                      c->comm, (hipStream_t)stream));
+    });
+}
+
+extern "C" int ftcf_comm_allgather(ftcf_comm_t c, void* buf, size_t count_per_rank, ftcf_dtype dtype, void* stream)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(c && c->comm, "communicator not initialised");
+        const size_t esz = dtype == FTCF_FP16 ? 2 : 4;
+        // in place: rank r's data lives at buf + r*count (ftNcclAllGather, nccl_utils.cc:70-82)
+        FTCF_NCCL_CHECK(ncclAllGather((const char*)buf + (size_t)c->rank * count_per_rank * esz, buf, count_per_rank,
+                                      dtype == FTCF_FP16 ? ncclFloat16 : ncclFloat32, c->comm, (hipStream_t)stream));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host quantiser entry points (libth_common counterpart)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int ftcf_symmetric_quantize_int8(const void* weight, ftcf_dtype dtype, size_t E, size_t K, size_t N,
+                                            int8_t* out_q, void* out_scale)
+{
+    return guarded([&] { host_symmetric_quantize_int8(weight, dtype == FTCF_FP16, E, K, N, out_q, out_scale); });
+}
+extern "C" int ftcf_int8_rowmajor_to_tiled(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    return guarded([&] { host_int8_rowmajor_to_tiled(q, K, N, out); });
+}
+extern "C" int ftcf_int8_tiled_to_rowmajor(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    return guarded([&] { host_int8_tiled_to_rowmajor(q, K, N, out); });
+}
+extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, void* out, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        launch_fp16_rowmajor_to_tiled((const f16*)w, K, N, (f16*)out, (hipStream_t)stream);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel-level entry points
+// ---------------------------------------------------------------------------------------------------------------
+static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m,
+                          int n, int k, bool int8, hipStream_t s)
+{
+    if (m <= 4) {
+        SplitKParams p{};
+        p.x_a = A;
+        p.W_a = W;
+        p.scale_a = scale;
+        p.bias = bias;
+        p.out = C;
+        p.N = n;
+        p.KT_a = k / (int8 ? TILE_K_I8 : TILE_K_F16);
+        p.KT_b = 0;
+        p.act = act;
+        p.tp = 1;
+        plan_splitk(p, int8, m, 4);
+        launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
+    }
+    else {
+        launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s);
+    }
+}
+
+extern "C" int ftcf_fpA_intB_gemm(const void* A, const int8_t* B, const void* scales, const void* bias, ftcf_act act,
+                                  void* C, int m, int n, int k, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        FTCF_CHECK_ARG(k % 64 == 0 && n % 16 == 0 && m >= 1, "fpA_intB GEMM needs k % 64 == 0, n % 16 == 0");
+        gemm_dispatch((const f16*)A, B, (const f16*)scales, (const f16*)bias, (int)act, (f16*)C, m, n, k, true,
+                      (hipStream_t)stream);
+    });
+}
+extern "C" int ftcf_fp16_gemm(const void* A, const void* W, const void* bias, ftcf_act act, void* C, int m, int n,
+                              int k, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        FTCF_CHECK_ARG(k % 64 == 0 && n % 16 == 0 && m >= 1, "fp16 GEMM needs k % 64 == 0, n % 16 == 0");
+        gemm_dispatch((const f16*)A, W, nullptr, (const f16*)bias, (int)act, (f16*)C, m, n, k, false,
+                      (hipStream_t)stream);
+    });
+}
+static void lm_head_dispatch(const f16* A, const f16* W, float* logits, int m, int n, int k, int ldc, hipStream_t s)
+{
+    if (m <= 4) {
+        launch_lm_head(A, W, logits, m, n, k, ldc, s);
+    }
+    else {
+        launch_gemm_nk_f32out(A, W, logits, m, n, k, ldc, s);
+    }
+}
+extern "C" int ftcf_lm_head(const void* A, const void* W, float* logits, int m, int n, int k, int ldc, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        lm_head_dispatch((const f16*)A, (const f16*)W, logits, m, n, k, ldc, (hipStream_t)stream);
+    });
+}
+extern "C" int ftcf_layernorm(const void* x, const void* gamma, const void* beta, void* out, int m, int n, float eps,
+                              ftcf_dtype dtype, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        launch_layernorm(x, gamma, beta, out, m, n, eps, dtype == FTCF_FP16, (hipStream_t)stream);
+    });
+}
+extern "C" int ftcf_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* attn, const void* in,
+                                               const void* bias, int m, int n, int tp, int inplace_variant,
+                                               ftcf_dtype dtype, void* stream)
+{
+    return guarded([&] {
+        require_device();
+        launch_add_bias_attn_ffn_residual(out, ffn, attn, in, bias, m, n, tp, inplace_variant, dtype == FTCF_FP16,
+                                          (hipStream_t)stream);
+    });
+}
+extern "C" size_t ftcf_masked_multihead_attention_workspace(int B, int nh, int dh, int s_max)
+{
+    return mmha_workspace_bytes(B, nh, dh, mmha_pick_nsplit(B, nh, s_max));
+}
+extern "C" int ftcf_masked_multihead_attention(const void* qkv, const void* qkv_bias, void* k_cache, void* v_cache,
+                                               const int* seq_len, const int* pad_count, const uint8_t* masked_tokens,
+                                               const uint8_t* finished, int B, int nh, int dh, int rot, int s_max,
+                                               int step, void* ctx, void* workspace, size_t workspace_bytes,
+                                               void* stream)
+{
+    return guarded([&] {
+        require_device();
+        MmhaParams p{};
+        p.qkv = (const f16*)qkv;
+        p.qkv_bias = (const f16*)qkv_bias;
+        p.k_cache = (f16*)k_cache;
+        p.v_cache = (f16*)v_cache;
+        p.seq_len = seq_len;
+        p.pad_count = pad_count;
+        p.masked_tokens = masked_tokens;
+        p.finished = finished;
+        p.d_step = nullptr;
+        p.step = step;
+        p.B = B;
+        p.nh = nh;
+        p.dh = dh;
+        p.rot = rot;
+        p.s_max = s_max;
+        p.ctx = (f16*)ctx;
+        p.ws = (float*)workspace;
+        p.nsplit = mmha_pick_nsplit(B, nh, s_max);
+        FTCF_CHECK_ARG(workspace_bytes >= mmha_workspace_bytes(B, nh, dh, p.nsplit), "MMHA workspace too small");
+        launch_mmha(p, (hipStream_t)stream);
+    });
+}
+extern "C" int ftcf_context_attention(const void* qkv, const void* qkv_bias, const int* input_lengths, void* k_cache,
+                                      void* v_cache, int B, int S, int nh, int dh, int rot, int s_max, void* ctx,
+                                      void* stream)
+{
+    return guarded([&] {
+        require_device();
+        launch_context_attention((const f16*)qkv, (const f16*)qkv_bias, input_lengths, (f16*)k_cache, (f16*)v_cache, B,
+                                 S, nh, dh, rot, s_max, (f16*)ctx, (hipStream_t)stream);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the engine
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DenseWeight {  // layers/DenseWeight.h:29-66
+    const void* kernel = nullptr;  // tiled (int8 or fp16)
+    const f16*  scale  = nullptr;  // weight_only_quant_scale
+    const f16*  bias   = nullptr;
+};
+struct LayerWeights {  // models/gptneox/GptNeoXDecoderLayerWeight.h
+    const f16 *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    DenseWeight qkv, attn_out, ffn1, ffn2;
+};
+
+struct DeviceBuffer {
+    void*  ptr = nullptr;
+    size_t cap = 0;
+    void   reserve(size_t bytes)
+    {
+        if (bytes > cap) {
+            if (ptr) {
+                FTCF_HIP_CHECK(hipFree(ptr));
+                ptr = nullptr;
+                cap = 0;
+            }
+            FTCF_HIP_CHECK(hipMalloc(&ptr, bytes));
+            cap = bytes;
+        }
+    }
+    ~DeviceBuffer()
+    {
+        if (ptr) {
+            (void)hipFree(ptr);
+        }
+    }
+};
+
+// carve helper over one arena
+struct Carver {
+    char*  base;
+    size_t off = 0;
+    explicit Carver(void* b): base((char*)b) {}
+    template<typename T>
+    T* take(size_t n)
+    {
+        off      = (off + 255) & ~(size_t)255;
+        T* p     = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_COUNT = 3 };
+
+}  // namespace
+
+struct ftcf_gptneox {
+    ftcf_gptneox_config       cfg{};
+    int                       H = 0, nhl = 0, hl = 0, il = 0, L = 0, V = 0, vl = 0, dh = 0;
+    bool                      int8 = false;
+    hipStream_t               stream = nullptr;
+    std::vector<LayerWeights> layers;
+    const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
+    std::vector<void*>        owned;  // tiled fp16 copies (int8_mode == 0)
+
+    DeviceBuffer arena;
+    // decode / state views (valid after plan())
+    f16 *x = nullptr, *nrm = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
+    f16 *k_cache = nullptr, *v_cache = nullptr;
+    f16 *px = nullptr, *pnrm = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
+        *pffn = nullptr;
+    float *      logits = nullptr, *gather = nullptr, *mmha_ws = nullptr;
+    void*        samp_ws = nullptr;
+    DecodeState* state = nullptr;
+    uint8_t *    finished = nullptr, *masked = nullptr;
+    int *        seq_len = nullptr, *pad_count = nullptr, *step_ids = nullptr, *d_top_k = nullptr,
+        *d_min_length = nullptr;
+    float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
+    uint64_t *draws = nullptr, *d_seed = nullptr;
+    int*      h_flags = nullptr;  // pinned
+    int       nsplit = 1;
+
+    // profiling
+    bool               profiling = false;
+    ftcf_forward_stats stats{};
+    double             kind_ms[KIND_COUNT]{}, kind_bytes[KIND_COUNT]{};
+    long               kind_n[KIND_COUNT]{};
+    std::vector<std::tuple<hipEvent_t, hipEvent_t, int, double>> pending;
+    std::vector<hipEvent_t>                                       event_pool;
+
+    ~ftcf_gptneox()
+    {
+        for (void* p : owned) {
+            (void)hipFree(p);
+        }
+        if (h_flags) {
+            (void)hipHostFree(h_flags);
+        }
+        for (auto e : event_pool) {
+            (void)hipEventDestroy(e);
+        }
+    }
+
+    hipEvent_t get_event()
+    {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        FTCF_HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+
+    template<typename F>
+    void timed(int kind, double bytes, F&& f)
+    {
+        if (!profiling) {
+            f();
+            return;
+        }
+        hipEvent_t a = get_event(), b = get_event();
+        FTCF_HIP_CHECK(hipEventRecord(a, stream));
+        f();
+        FTCF_HIP_CHECK(hipEventRecord(b, stream));
+        pending.emplace_back(a, b, kind, bytes);
+    }
+    void drain_events()
+    {
+        for (auto& t : pending) {
+            float ms = 0.f;
+            FTCF_HIP_CHECK(hipEventSynchronize(std::get<1>(t)));
+            FTCF_HIP_CHECK(hipEventElapsedTime(&ms, std::get<0>(t), std::get<1>(t)));
+            kind_ms[std::get<2>(t)] += ms;
+            kind_bytes[std::get<2>(t)] += std::get<3>(t);
+            kind_n[std::get<2>(t)] += 1;
+            event_pool.push_back(std::get<0>(t));
+            event_pool.push_back(std::get<1>(t));
+        }
+        pending.clear();
+    }
+
+    // ---- arena planning: everything a request of shape (B, S, total) needs, carved once ----
+    void plan(int B, int S, int total)
+    {
+        const int s_max = total;
+        nsplit          = mmha_pick_nsplit(B, nhl, s_max);
+        for (int pass = 0; pass < 2; pass++) {
+            Carver c(pass == 0 ? nullptr : arena.ptr);
+            const size_t cache = (size_t)L * B * nhl * s_max * dh;
+            k_cache            = c.take<f16>(cache);
+            v_cache            = c.take<f16>(cache);
+            x                  = c.take<f16>((size_t)B * H);
+            nrm                = c.take<f16>((size_t)B * H);
+            qkv                = c.take<f16>((size_t)B * 3 * hl);
+            ctx                = c.take<f16>((size_t)B * hl);
+            att                = c.take<f16>((size_t)B * H);
+            mid                = c.take<f16>((size_t)B * il);
+            ffn                = c.take<f16>((size_t)B * H);
+            logits             = c.take<float>((size_t)B * V);
+            gather             = c.take<float>((size_t)B * V);
+            mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
+            samp_ws            = c.take<char>(sampling_workspace_bytes(B, V));
+            state              = c.take<DecodeState>(1);
+            finished           = c.take<uint8_t>(B);
+            masked             = c.take<uint8_t>((size_t)B * s_max);
+            seq_len            = c.take<int>(B);
+            pad_count          = c.take<int>(B);
+            step_ids           = c.take<int>((size_t)total * B);
+            d_top_k            = c.take<int>(B);
+            d_min_length       = c.take<int>(B);
+            cum                = c.take<float>(B);
+            d_p_topk           = c.take<float>(B);
+            d_p_topp           = c.take<float>(B);
+            d_temp             = c.take<float>(B);
+            d_rep              = c.take<float>(B);
+            draws              = c.take<uint64_t>(B);
+            d_seed             = c.take<uint64_t>(B);
+            if (S > 1) {
+                const size_t M = (size_t)B * S;
+                px             = c.take<f16>(M * H);
+                pnrm           = c.take<f16>(M * H);
+                pqkv           = c.take<f16>(M * 3 * hl);
+                pctx           = c.take<f16>(M * hl);
+                patt           = c.take<f16>(M * H);
+                pmid           = c.take<f16>(M * il);
+                pffn           = c.take<f16>(M * H);
+            }
+            if (pass == 0) {
+                arena.reserve(c.off + 4096);
+            }
+        }
+    }
+
+    // ---- FfnLayer / attention projections over M rows (general path) ----
+    void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
+    {
+        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream);
+    }
+
+    void allreduce(f16* buf, size_t count)
+    {
+        if (cfg.tensor_para_size > 1) {
+            FTCF_CHECK_ARG(cfg.comm && cfg.comm->comm, "tensor_para_size > 1 needs a communicator");
+            FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, stream));
+        }
+    }
+
+    // GptNeoXContextDecoder::forward (GptNeoXContextDecoder.cc:283-507), parallel residual only
+    void context_decoder(int B, int S, const int* input_lengths, int s_max)
+    {
+        const int    M       = B * S;
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            launch_layernorm(px, w.ln1_g, w.ln1_b, pnrm, M, H, 1e-5f, true, stream);
+            gemm(pnrm, w.qkv, nullptr, 0, pqkv, M, 3 * hl, H);
+            launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B,
+                                     S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream);
+            gemm(pctx, w.attn_out, nullptr, 0, patt, M, H, hl);
+            launch_layernorm(px, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
+            gemm(pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
+            gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
+            // layer_input == layer_output for every layer with padding removal -> fp32-sum variant (:311-322,:445-461)
+            launch_add_bias_attn_ffn_residual(px, pffn, patt, px, w.ffn2.bias, M, H, cfg.tensor_para_size, 1, true,
+                                              stream);
+            allreduce(px, (size_t)M * H);
+        }
+    }
+
+    // GptNeoXDecoder::forward (GptNeoXDecoder.cc:245-384)
+    void decoder(int B, int s_max)
+    {
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        const double wbytes  = int8 ? 1.0 : 2.0;
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            // layer_input/output alias for 0 < l < L-1 in the reference (:249-250) -> which residual form it runs
+            const int inplace = (l > 0 && l < L - 1) ? 1 : 0;
+            MmhaParams mp{};
+            mp.qkv = qkv;
+            mp.qkv_bias = w.qkv.bias;
+            mp.k_cache = k_cache + l * cache_l;
+            mp.v_cache = v_cache + l * cache_l;
+            mp.seq_len = seq_len;
+            mp.pad_count = pad_count;
+            mp.masked_tokens = masked;
+            mp.finished = finished;
+            mp.d_step = &state->step;
+            mp.B = B;
+            mp.nh = nhl;
+            mp.dh = dh;
+            mp.rot = cfg.rotary_embedding_dim;
+            mp.s_max = s_max;
+            mp.ctx = ctx;
+            mp.ws = mmha_ws;
+            mp.nsplit = nsplit;
+            if (B <= 4) {
+                // fused path: [LN1 -> QKV] U [LN2 -> FFN1+bias+gelu] ; MMHA ; [out-proj U FFN2 -> residual]
+                LnGemvParams a{};
+                a.x = x;
+                a.gamma0 = w.ln1_g;
+                a.beta0 = w.ln1_b;
+                a.gamma1 = w.ln2_g;
+                a.beta1 = w.ln2_b;
+                a.W0 = w.qkv.kernel;
+                a.W1 = w.ffn1.kernel;
+                a.scale0 = w.qkv.scale;
+                a.scale1 = w.ffn1.scale;
+                a.bias1 = w.ffn1.bias;
+                a.out0 = qkv;
+                a.out1 = mid;
+                a.K = H;
+                a.NT0 = 3 * hl / 16;
+                a.NT1 = il / 16;
+                a.blocks0 = (a.NT0 + 3) / 4;
+                a.blocks1 = (a.NT1 + 3) / 4;
+                a.eps = 1e-5f;
+                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl + il), [&] { launch_ln_gemv(a, int8, B, stream); });
+                launch_mmha(mp, stream);
+                SplitKParams c{};
+                c.x_a = ctx;
+                c.x_b = mid;
+                c.W_a = w.attn_out.kernel;
+                c.W_b = w.ffn2.kernel;
+                c.scale_a = w.attn_out.scale;
+                c.scale_b = w.ffn2.scale;
+                c.bias = w.ffn2.bias;
+                c.x_in = x;
+                c.out = x;
+                c.N = H;
+                const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
+                c.KT_a = hl / tk;
+                c.KT_b = il / tk;
+                c.tp = cfg.tensor_para_size;
+                c.inplace_variant = inplace;
+                plan_splitk(c, int8, B, GEMV_SPLITK_MAX_WAVES);
+                timed(KIND_SPLITK, wbytes * H * ((double)hl + il),
+                      [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
+            }
+            else {
+                launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
+                gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
+                launch_mmha(mp, stream);
+                gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
+                launch_layernorm(x, w.ln2_g, w.ln2_b, nrm, B, H, 1e-5f, true, stream);
+                gemm(nrm, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
+                gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, cfg.tensor_para_size, inplace,
+                                                  true, stream);
+            }
+            allreduce(x, (size_t)B * H);
+        }
+    }
+
+    // ---- request session: forward() == begin() + step(all) + finish() ----
+    struct Session {
+        bool              active = false;
+        ftcf_forward_args a{};
+        SamplingParams    sp{};
+        int               B = 0, S = 0, total = 0, s_max = 0;
+        int               next_step = 0;  // host mirror of state->step
+        int               steps = 0;
+        bool              all_finished = false;
+        hipEvent_t        e0 = nullptr, e1 = nullptr;
+    } ses;
+    void begin(const ftcf_forward_args& a);
+    int  step(int max_steps);
+    void finish();
+    void forward(const ftcf_forward_args& a)
+    {
+        begin(a);
+        step(a.output_len);
+        finish();
+    }
+};
+
+// transposeAxis01 for the TP logits all-gather: [tp][B][vl] -> [B][V] (GptNeoX.cc:913-924)
+__global__ void k_transpose_gathered_logits(float* out, const float* in, int tp, int B, int vl)
+{
+    const size_t total = (size_t)tp * B * vl;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int    j = (int)(i % vl);
+        const size_t t = i / vl;
+        const int    b = (int)(t % B), r = (int)(t / B);
+        out[(size_t)b * tp * vl + (size_t)r * vl + j] = in[i];
+    }
+}
+
+template<typename T>
+static std::vector<T> broadcast_arg(const T* p, int n, int B, T dflt, const char* name)
+{
+    std::vector<T> v((size_t)B, dflt);
+    if (n > 0) {
+        FTCF_CHECK_ARG(p != nullptr, std::string(name) + " pointer is NULL");
+        FTCF_CHECK_ARG(n == 1 || n == B, std::string(name) + " must have 1 or batch_size entries");
+        for (int b = 0; b < B; b++) {
+            v[b] = p[n == 1 ? 0 : b];
+        }
+    }
+    return v;
+}
+
+void ftcf_gptneox::begin(const ftcf_forward_args& a)
+{
+    const int B = a.batch_size, S = a.max_input_len, out_len = a.output_len;
+    FTCF_CHECK_ARG(B >= 1 && S >= 1 && out_len >= 1, "batch_size, max_input_len and output_len must be >= 1");
+    FTCF_CHECK_ARG(a.input_ids && a.input_lengths && a.output_ids && a.sequence_lengths, "NULL tensor");
+    if (a.beam_width != 1) {
+        throw Error(FTCF_ERR_UNSUPPORTED, "beam_width > 1 (beam search) is not implemented yet");
+    }
+    FTCF_HIP_CHECK(hipSetDevice(cfg.device));
+    const int total = S + out_len;  // max_output_seq_len == max_seq_len == max_cache_seq_len (GptNeoX.cc:520-523)
+    const int s_max = total;
+    plan(B, S, total);
+
+    // ---- runtime args: routing of TopKSamplingLayer.cu:27-77 / TopPSamplingLayer.cu:30-110 ----
+    auto top_k = broadcast_arg<int>(a.top_k, a.n_top_k, B, 0, "top_k");
+    auto top_p = broadcast_arg<float>(a.top_p, a.n_top_p, B, 0.f, "top_p");
+    auto temp  = broadcast_arg<float>(a.temperature, a.n_temperature, B, 1.f, "temperature");
+    auto rep   = broadcast_arg<float>(a.repetition_penalty, a.n_repetition_penalty, B, 1.f, "repetition_penalty");
+    auto seed  = broadcast_arg<uint64_t>(a.random_seed, a.n_random_seed, B, 0, "random_seed");
+    auto minl  = broadcast_arg<int>(a.min_length, a.n_min_length, B, 0, "min_length");
+    std::vector<int>   k_eff(B);
+    std::vector<float> p_topk(B), p_topp(B);
+    bool               temp_all_one = true, rep_all_default = true, any_min = false;
+    for (int b = 0; b < B; b++) {
+        int   k = top_k[b];
+        float p = top_p[b];
+        FTCF_CHECK_ARG(k >= 0, "top_k must be >= 0");
+        if (k == 0 && p == 0.0f) {
+            k = 1;
+        }
+        float pk = p;
+        if (k > 0 && pk == 0.0f) {
+            pk = 1.0f;
+        }
+        k_eff[b]  = k > 1024 ? 1024 : k;
+        p_topk[b] = pk < 0.f ? 0.f : (pk > 1.f ? 1.f : pk);
+        p_topp[b] = p < 0.f ? 0.f : (p > 1.f ? 1.f : p);
+        temp_all_one &= (temp[b] == 1.0f);
+        rep_all_default &= (rep[b] == 1.0f);
+        any_min |= (minl[b] > 0);
+    }
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_top_k, k_eff.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topk, p_topk.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topp, p_topp.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_temp, temp.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_rep, rep.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_seed, seed.data(), B * 8, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_min_length, minl.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // the host vectors die at scope exit
+
+    hipEvent_t e0 = get_event(), e1 = get_event();
+    FTCF_HIP_CHECK(hipEventRecord(e0, stream));
+    launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
+    if (S > 1) {
+        launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
+        context_decoder(B, S, a.input_lengths, s_max);
+        launch_gather_last_token(x, px, a.input_lengths, B, S, H, stream);
+    }
+    else {
+        FTCF_HIP_CHECK(hipMemcpyAsync(step_ids, a.input_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    FTCF_HIP_CHECK(hipEventRecord(e1, stream));
+
+    SamplingParams sp{};
+    sp.logits = logits;
+    sp.B = B;
+    sp.V = V;
+    sp.max_input_len = S;
+    sp.total_len = total;
+    sp.end_id = cfg.end_id;
+    sp.input_lengths = a.input_lengths;
+    sp.top_k = d_top_k;
+    sp.top_p_topk = d_p_topk;
+    sp.top_p_topp = d_p_topp;
+    sp.temperature = d_temp;
+    sp.repetition_penalty = a.n_repetition_penalty > 0 ? d_rep : nullptr;
+    sp.min_length = any_min ? d_min_length : nullptr;
+    sp.random_seed = d_seed;
+    sp.draw_counter = draws;
+    sp.apply_temperature = temp_all_one ? 0 : 1;
+    sp.apply_repetition = (a.n_repetition_penalty > 0 && !rep_all_default) ? 1 : 0;
+    sp.stop_words = a.stop_words_list;
+    sp.stop_len = a.stop_words_len;
+    sp.optional_last_tokens = a.optional_last_tokens;
+    sp.optional_count = a.optional_last_tokens_count;
+    sp.return_cum_log_probs = a.return_cum_log_probs ? 1 : 0;
+    sp.output_ids = step_ids;
+    sp.finished = finished;
+    sp.seq_len = seq_len;
+    sp.cum_log_probs = cum;
+    sp.pad_count = pad_count;
+    sp.state = state;
+    sp.h_flags = h_flags;
+    sp.ws = samp_ws;
+
+    ses.active = true;
+    ses.a = a;
+    ses.sp = sp;
+    ses.B = B;
+    ses.S = S;
+    ses.total = total;
+    ses.s_max = s_max;
+    ses.next_step = S;
+    ses.steps = 0;
+    ses.all_finished = false;
+    ses.e0 = e0;
+    ses.e1 = e1;
+    stats.decode_ms = 0.f;
+}
+
+// the token loop of GptNeoX<T>::forward (GptNeoX.cc:776-1048); returns the number of iterations executed
+int ftcf_gptneox::step(int max_steps)
+{
+    FTCF_CHECK_ARG(ses.active, "no request in flight: call ftcf_gptneox_begin first");
+    FTCF_HIP_CHECK(hipSetDevice(cfg.device));
+    const ftcf_forward_args& a = ses.a;
+    const int B = ses.B, S = ses.S, total = ses.total, s_max = ses.s_max;
+    const int tp = cfg.tensor_para_size;
+    std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
+    hipEvent_t ea = get_event(), eb = get_event();
+    FTCF_HIP_CHECK(hipEventRecord(ea, stream));
+    int done = 0;
+    while (done < max_steps && ses.next_step < total && !ses.all_finished) {
+        const int step = ses.next_step;
+        if (!(S > 1 && step == S)) {
+            launch_step_embedding(x, wte, step_ids, &state->step, B, H, stream);
+            decoder(B, s_max);
+        }
+        launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, true, stream);
+        if (tp == 1) {
+            timed(KIND_LM_HEAD, 2.0 * V * H, [&] { lm_head_dispatch(nrm, lm_head, logits, B, V, H, V, stream); });
+        }
+        else {
+            // rank r computes rows [r*vl, (r+1)*vl) of the replicated lm_head (GptNeoX.cc:888-925)
+            float* mine = gather + (size_t)cfg.tensor_para_rank * B * vl;
+            timed(KIND_LM_HEAD, 2.0 * vl * H, [&] {
+                lm_head_dispatch(nrm, lm_head + (size_t)cfg.tensor_para_rank * vl * H, mine, B, vl, H, vl, stream);
+            });
+            FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
+            hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, stream, logits, gather, tp, B, vl);
+        }
+        if (a.debug_logits) {
+            FTCF_HIP_CHECK(hipMemcpyAsync(a.debug_logits + (size_t)(step - S) * B * V, logits, (size_t)B * V * 4,
+                                          hipMemcpyDeviceToDevice, stream));
+        }
+        launch_dynamic_decode(ses.sp, stream);
+        ses.steps++;
+        ses.next_step++;
+        done++;
+        // the reference synchronises once per token here as well (stop_criteria_kernels.cu:149-156)
+        FTCF_HIP_CHECK(hipStreamSynchronize(stream));
+        ses.all_finished = h_flags[0] != 0;
+        if (a.callback && step + 1 < total && cfg.tensor_para_rank == 0) {
+            // pybind_callback_utils.cc:22-103: last token of every row; a row that did not advance reports end_id
+            FTCF_HIP_CHECK(hipMemcpy(h_tokens.data(), step_ids + (size_t)step * B, (size_t)B * 4, hipMemcpyDeviceToHost));
+            FTCF_HIP_CHECK(hipMemcpy(h_seq.data(), seq_len, (size_t)B * 4, hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++) {
+                h_idx[b] = h_seq[b];
+                if (h_seq[b] != step) {
+                    h_tokens[b] = cfg.end_id;
+                }
+            }
+            a.callback(h_tokens.data(), h_idx.data(), B, 1, a.callback_user);
+        }
+    }
+    FTCF_HIP_CHECK(hipEventRecord(eb, stream));
+    FTCF_HIP_CHECK(hipEventSynchronize(eb));
+    float ms = 0.f;
+    FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
+    stats.decode_ms += ms;
+    event_pool.push_back(ea);
+    event_pool.push_back(eb);
+    return done;
+}
+
+void ftcf_gptneox::finish()
+{
+    FTCF_CHECK_ARG(ses.active, "no request in flight");
+    const ftcf_forward_args& a = ses.a;
+    // setOutputTensors (GptNeoX.cc:1090-1181)
+    launch_gather_tree(a.output_ids, a.sequence_lengths, step_ids, seq_len, a.input_lengths, ses.B, ses.S, ses.total,
+                       cfg.end_id, stream);
+    if (a.cum_log_probs) {
+        FTCF_HIP_CHECK(hipMemcpyAsync(a.cum_log_probs, cum, (size_t)ses.B * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    FTCF_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ses.e0, ses.e1));
+    stats.prefill_ms   = ms;
+    stats.decode_steps = ses.steps;
+    event_pool.push_back(ses.e0);
+    event_pool.push_back(ses.e1);
+    ses.active = false;
+    drain_events();
+}
+
+extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gptneox_weights* w, ftcf_gptneox_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(cfg && w && out, "NULL argument");
+        require_device();
+        FTCF_CHECK_ARG(cfg->pipeline_para_size == 1, "pipeline_para_size must be 1 (the CodeFuse harness forces it)");
+        if (cfg->dtype != FTCF_FP16) {
+            throw Error(FTCF_ERR_UNSUPPORTED, "the GPU engine runs fp16 weights/activations only");
+        }
+        if (!cfg->use_gptj_residual) {
+            throw Error(FTCF_ERR_UNSUPPORTED, "use_gptj_residual == 0 (sequential residual) is not implemented");
+        }
+        FTCF_CHECK_ARG(cfg->int8_mode == 0 || cfg->int8_mode == 1, "int8_mode must be 0 or 1");
+        const int tp = cfg->tensor_para_size;
+        FTCF_CHECK_ARG(tp >= 1 && cfg->head_num % tp == 0 && cfg->inter_size % tp == 0 && cfg->vocab_size % tp == 0,
+                       "head_num, inter_size and vocab_size must be divisible by tensor_para_size");
+        const int L = cfg->num_layer;
+        FTCF_CHECK_ARG(w->n_weights == 12 * L + 4, "weights must hold 12*L+4 tensors");
+        FTCF_HIP_CHECK(hipSetDevice(cfg->device));
+        auto e   = std::make_unique<ftcf_gptneox>();
+        e->cfg   = *cfg;
+        e->L     = L;
+        e->dh    = cfg->size_per_head;
+        e->H     = cfg->head_num * cfg->size_per_head;
+        e->nhl   = cfg->head_num / tp;
+        e->hl    = e->nhl * e->dh;
+        e->il    = cfg->inter_size / tp;
+        e->V     = cfg->vocab_size;
+        e->vl    = e->V / tp;
+        e->int8  = cfg->int8_mode == 1;
+        e->stream = (hipStream_t)cfg->stream;
+        FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
+        FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
+                       "hidden, local hidden and local inter sizes must be multiples of 64");
+        if (e->int8) {
+            FTCF_CHECK_ARG(w->n_int8_weights == 4 * L && w->n_scales == 4 * L, "int8 lists must hold 4*L tensors");
+        }
+        auto W = [&](int g, int l) { return w->weights[(size_t)g * L + l]; };
+        e->layers.resize(L);
+        const int H = e->H, hl = e->hl, il = e->il;
+        for (int l = 0; l < L; l++) {
+            LayerWeights& lw = e->layers[l];
+            lw.ln1_b = (const f16*)W(0, l);
+            lw.ln1_g = (const f16*)W(1, l);
+            lw.qkv.bias = (const f16*)W(3, l);
+            lw.attn_out.bias = (const f16*)W(5, l);
+            lw.ffn1.bias = (const f16*)W(7, l);
+            lw.ffn2.bias = (const f16*)W(9, l);
+            lw.ln2_b = (const f16*)W(10, l);
+            lw.ln2_g = (const f16*)W(11, l);
+            FTCF_CHECK_ARG(lw.ln1_b && lw.ln1_g && lw.ln2_b && lw.ln2_g && lw.qkv.bias && lw.ffn1.bias && lw.ffn2.bias,
+                           "missing layernorm / bias tensor");
+            if (e->int8) {
+                lw.qkv.kernel = w->int8_weights[0 * L + l];
+                lw.attn_out.kernel = w->int8_weights[1 * L + l];
+                lw.ffn1.kernel = w->int8_weights[2 * L + l];
+                lw.ffn2.kernel = w->int8_weights[3 * L + l];
+                lw.qkv.scale = (const f16*)w->scales[0 * L + l];
+                lw.attn_out.scale = (const f16*)w->scales[1 * L + l];
+                lw.ffn1.scale = (const f16*)w->scales[2 * L + l];
+                lw.ffn2.scale = (const f16*)w->scales[3 * L + l];
+                FTCF_CHECK_ARG(lw.qkv.kernel && lw.attn_out.kernel && lw.ffn1.kernel && lw.ffn2.kernel && lw.qkv.scale
+                                   && lw.attn_out.scale && lw.ffn1.scale && lw.ffn2.scale,
+                               "missing int8 kernel / scale tensor");
+            }
+            else {
+                // re-tile the reference-layout [K, N] fp16 kernels once (the binding keeps the originals alive)
+                struct {
+                    int          g;
+                    size_t       K, N;
+                    DenseWeight* d;
+                } items[4] = {{2, (size_t)H, (size_t)3 * hl, &lw.qkv},
+                              {4, (size_t)hl, (size_t)H, &lw.attn_out},
+                              {6, (size_t)H, (size_t)il, &lw.ffn1},
+                              {8, (size_t)il, (size_t)H, &lw.ffn2}};
+                for (auto& it : items) {
+                    const void* src = W(it.g, l);
+                    FTCF_CHECK_ARG(src != nullptr, "missing fp16 kernel tensor");
+                    void* dst = nullptr;
+                    FTCF_HIP_CHECK(hipMalloc(&dst, it.K * it.N * 2));
+                    e->owned.push_back(dst);
+                    launch_fp16_rowmajor_to_tiled((const f16*)src, it.K, it.N, (f16*)dst, e->stream);
+                    it.d->kernel = dst;
+                }
+            }
+        }
+        e->wte     = (const f16*)w->weights[12 * L];
+        e->final_g = (const f16*)w->weights[12 * L + 1];  // GptNeoXOp.h:172-173: slot 12L+1 = gamma
+        e->final_b = (const f16*)w->weights[12 * L + 2];
+        e->lm_head = (const f16*)w->weights[12 * L + 3];
+        FTCF_CHECK_ARG(e->wte && e->final_g && e->final_b && e->lm_head, "missing embedding / final layernorm / lm_head");
+        FTCF_HIP_CHECK(hipHostMalloc((void**)&e->h_flags, 64, hipHostMallocDefault));
+        e->h_flags[0] = e->h_flags[1] = 0;
+        FTCF_HIP_CHECK(hipStreamSynchronize(e->stream));
+        *out = e.release();
+    });
+}
+
+extern "C" int ftcf_gptneox_forward(ftcf_gptneox_t h, const ftcf_forward_args* args)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h && args, "NULL argument");
+        h->forward(*args);
+    });
+}
+
+extern "C" int ftcf_gptneox_begin(ftcf_gptneox_t h, const ftcf_forward_args* args)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h && args, "NULL argument");
+        h->begin(*args);
+    });
+}
+extern "C" int ftcf_gptneox_step(ftcf_gptneox_t h, int max_steps, int* steps_done)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h, "NULL argument");
+        const int n = h->step(max_steps);
+        if (steps_done) {
+            *steps_done = n;
+        }
+    });
+}
+extern "C" int ftcf_gptneox_finish(ftcf_gptneox_t h)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h, "NULL argument");
+        h->finish();
+    });
+}
+
+extern "C" int ftcf_gptneox_get_stats(ftcf_gptneox_t h, ftcf_forward_stats* s)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h && s, "NULL argument");
+        *s = h->stats;
+        // dominant weight-streaming kernel kind
+        int best = 0;
+        for (int k = 1; k < KIND_COUNT; k++) {
+            if (h->kind_ms[k] > h->kind_ms[best]) {
+                best = k;
+            }
+        }
+        s->gemv_ms_sum   = (float)h->kind_ms[best];
+        s->gemv_launches = h->kind_n[best];
+        s->gemv_bytes    = h->kind_bytes[best];
+    });
+}
+
+extern "C" int ftcf_gptneox_set_profiling(ftcf_gptneox_t h, int enabled)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(h, "NULL argument");
+        h->profiling = enabled != 0;
+        for (int k = 0; k < KIND_COUNT; k++) {
+            h->kind_ms[k] = h->kind_bytes[k] = 0;
+            h->kind_n[k]                     = 0;
+        }
+    });
+}
+
+extern "C" int ftcf_gptneox_destroy(ftcf_gptneox_t h)
+{
+    return guarded([&] { delete h; });
+}

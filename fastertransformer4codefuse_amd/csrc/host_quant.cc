@@ -1,0 +1,108 @@
+// Host-side weight-only quantiser (see host_quant.h).  Pure CPU code: runs inside `libth_common`'s
+// symmetric_quantize_last_axis_of_batched_matrix_int8 exactly like the reference's (WeightOnlyQuantOps.cc:140-233).
+#include "host_quant.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ftcf_common.h"
+
+namespace ftcf {
+
+// Tile layout (ftcf_common.h): byte ((nt*KT + kt)*64 + lane)*16 + j  <-  u8(q[kt*64 + (lane>>4)*16 + j][nt*16 + (lane&15)] + 128)
+// The +128 bias mirrors add_bias_and_interleave_int8s_inplace (cutlass_preprocessors.cc:350-370): the kernels
+// convert u8 -> f16 with the 0x6400 magic number and subtract 1152.
+void host_int8_rowmajor_to_tiled(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    FTCF_CHECK_ARG(K % TILE_K_I8 == 0 && N % TILE_N == 0, "int8 tiling needs K % 64 == 0 and N % 16 == 0");
+    const size_t KT = K / TILE_K_I8, NT = N / TILE_N;
+    uint8_t*     o  = reinterpret_cast<uint8_t*>(out);
+#pragma omp parallel for schedule(static)
+    for (size_t nt = 0; nt < NT; nt++) {
+        for (size_t kt = 0; kt < KT; kt++) {
+            uint8_t* tile = o + (nt * KT + kt) * TILE_BYTES;
+            for (int lane = 0; lane < 64; lane++) {
+                const size_t n  = nt * 16 + (lane & 15);
+                const size_t k0 = kt * 64 + (size_t)(lane >> 4) * 16;
+                for (int j = 0; j < 16; j++) {
+                    tile[lane * 16 + j] = (uint8_t)((int)q[(k0 + j) * N + n] + 128);
+                }
+            }
+        }
+    }
+}
+
+void host_int8_tiled_to_rowmajor(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    FTCF_CHECK_ARG(K % TILE_K_I8 == 0 && N % TILE_N == 0, "int8 tiling needs K % 64 == 0 and N % 16 == 0");
+    const size_t   KT = K / TILE_K_I8, NT = N / TILE_N;
+    const uint8_t* in = reinterpret_cast<const uint8_t*>(q);
+#pragma omp parallel for schedule(static)
+    for (size_t nt = 0; nt < NT; nt++) {
+        for (size_t kt = 0; kt < KT; kt++) {
+            const uint8_t* tile = in + (nt * KT + kt) * TILE_BYTES;
+            for (int lane = 0; lane < 64; lane++) {
+                const size_t n  = nt * 16 + (lane & 15);
+                const size_t k0 = kt * 64 + (size_t)(lane >> 4) * 16;
+                for (int j = 0; j < 16; j++) {
+                    out[(k0 + j) * N + n] = (int8_t)((int)tile[lane * 16 + j] - 128);
+                }
+            }
+        }
+    }
+}
+
+template<typename T>
+static void quantize_one(const T* w, size_t K, size_t N, int8_t* q_rowmajor, T* scale)
+{
+    std::vector<float> col_max(N, 0.f);
+    for (size_t i = 0; i < K; i++) {
+        const T* row = w + i * N;
+        for (size_t j = 0; j < N; j++) {
+            const float a = std::fabs((float)row[j]);
+            if (a > col_max[j]) {
+                col_max[j] = a;
+            }
+        }
+    }
+    for (size_t j = 0; j < N; j++) {
+        col_max[j] *= (1.f / 128.f);       // quant_range_scale = 1 / 2^(bits-1)
+        scale[j] = (T)col_max[j];          // stored in the weight dtype (:618-621)
+    }
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < K; i++) {
+        const T* row = w + i * N;
+        for (size_t j = 0; j < N; j++) {
+            const float s = std::round((float)row[j] / col_max[j]);  // divides by the UNROUNDED fp32 scale (:626-632)
+            float       c = (s < 127.f) ? s : 127.f;                 // std::min(127.f, s): NaN -> 127.f
+            if (!(c > -128.f)) {
+                c = (c != c) ? 127.f : -128.f;
+            }
+            q_rowmajor[i * N + j] = (int8_t)c;
+        }
+    }
+}
+
+void host_symmetric_quantize_int8(const void* weight, bool is_half, size_t E, size_t K, size_t N, int8_t* out_q,
+                                  void* out_scale)
+{
+    FTCF_CHECK_ARG(weight && out_q && out_scale, "NULL tensor");
+    FTCF_CHECK_ARG(E >= 1 && K >= 1 && N >= 1, "empty weight");
+    FTCF_CHECK_ARG(K % TILE_K_I8 == 0 && N % TILE_N == 0,
+                   "weight-only int8 needs K % 64 == 0 (as the reference, fpA_intB_gemm_template.h:159-163) and N % 16 == 0");
+    std::vector<int8_t> tmp(K * N);
+    for (size_t e = 0; e < E; e++) {
+        if (is_half) {
+            quantize_one<f16>(reinterpret_cast<const f16*>(weight) + e * K * N, K, N, tmp.data(),
+                              reinterpret_cast<f16*>(out_scale) + e * N);
+        }
+        else {
+            quantize_one<float>(reinterpret_cast<const float*>(weight) + e * K * N, K, N, tmp.data(),
+                                reinterpret_cast<float*>(out_scale) + e * N);
+        }
+        host_int8_rowmajor_to_tiled(tmp.data(), K, N, out_q + e * K * N);
+    }
+}
+
+}  // namespace ftcf

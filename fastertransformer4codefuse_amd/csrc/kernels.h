@@ -1,0 +1,134 @@
+// Internal launcher declarations shared by the engine and the C ABI (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "ftcf_common.h"
+
+namespace ftcf {
+
+constexpr int GEMV_SPLITK_MAX_WAVES = 10;
+constexpr int EPI_PLAIN             = 0;
+constexpr int EPI_RESIDUAL          = 1;
+
+struct LnGemvParams {
+    const f16* x;  // [M, K] layer input
+    const f16 *gamma0, *beta0, *gamma1, *beta1;
+    const void *W0, *W1;          // tiled weights of segment 0 (QKV) / 1 (FFN1)
+    const f16 *scale0, *scale1;   // int8 only
+    const f16* bias1;
+    f16 *out0, *out1;             // [M, NT0*16], [M, NT1*16]
+    int   K, NT0, NT1, blocks0, blocks1;
+    float eps;
+};
+
+struct SplitKParams {
+    const f16 *x_a, *x_b;
+    const void *W_a, *W_b;
+    const f16 *scale_a, *scale_b;
+    const f16* bias;
+    const f16* x_in;  // residual input (EPI_RESIDUAL)
+    f16*       out;
+    int        N, KT_a, KT_b;
+    int        act, tp, inplace_variant;
+    int        nwaves, slice_halves;
+    int        wave_seg[GEMV_SPLITK_MAX_WAVES], wave_t0[GEMV_SPLITK_MAX_WAVES], wave_nt[GEMV_SPLITK_MAX_WAVES];
+};
+
+void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s);
+void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves);
+void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStream_t s);
+void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s);
+
+// ---- MFMA GEMM (prefill / batched decode) : kernels_gemm.hip ----
+// C[m,n] = A[m,k] x W(tiled)  (+bias, gelu) ; int8: fused fp32 epilogue ; fp16: half epilogue
+void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
+                       int k, bool int8, hipStream_t s);
+// logits_f32[m, n] = A[m,k] x W[n,k]^T (row major fp16 weights, m > 4)
+void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s);
+
+// ---- misc : kernels_misc.hip ----
+void launch_layernorm(const void* x, const void* gamma, const void* beta, void* out, int m, int n, float eps,
+                      bool fp16, hipStream_t s);
+void launch_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* attn, const void* in, const void* bias,
+                                       int m, int n, int tp, int inplace_variant, bool fp16, hipStream_t s);
+void launch_embedding(f16* out, const f16* table, const int* ids, int n_ids, int H, hipStream_t s);
+// prompt: ids [B,S] -> out [B*S,H] and time-major output_ids[s*B+b] (gpt_kernels.cu:31-104)
+void launch_prompt_embedding(f16* out, int* output_ids, const f16* table, const int* ids, int B, int S, int H,
+                             hipStream_t s);
+// decode step: embedding of output_ids[(step-1)*B + b] where step is read from device state (decoding_kernels.cu:145-191)
+void launch_step_embedding(f16* out, const f16* table, const int* output_ids, const int* d_step, int B, int H,
+                           hipStream_t s);
+void launch_gather_last_token(f16* out, const f16* hidden, const int* input_lengths, int B, int S, int H,
+                              hipStream_t s);
+void launch_fp16_rowmajor_to_tiled(const f16* w, size_t K, size_t N, f16* out, hipStream_t s);
+
+// ---- attention : kernels_attn.hip ----
+struct MmhaParams {
+    const f16* qkv;       // [B, 3*Hl]
+    const f16* qkv_bias;  // [3*Hl]
+    f16 *      k_cache, *v_cache;  // [B, nh, s_max, dh]
+    const int* seq_len;            // tlength per row
+    const int* pad_count;
+    const uint8_t* masked_tokens;  // [B, s_max]
+    const uint8_t* finished;
+    const int*     d_step;  // device step counter (timestep = step - 1); if NULL `step` is used
+    int            step;
+    int            B, nh, dh, rot, s_max;
+    f16*           ctx;  // [B, Hl]
+    float*         ws;   // split-KV workspace
+    int            nsplit;
+};
+size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);
+int    mmha_pick_nsplit(int B, int nh, int s_max);
+void   launch_mmha(const MmhaParams& p, hipStream_t s);
+void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
+                                f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
+                                hipStream_t s);
+
+// ---- dynamic decode : kernels_sampling.hip ----
+struct DecodeState {  // device resident, one per engine
+    int step;         // current step (max_input_len .. total-1)
+    int all_finished;
+    int steps_done;
+    int pad;
+};
+struct SamplingParams {
+    float*       logits;  // [B, V] fp32 (modified in place)
+    int          B, V;
+    int          max_input_len, total_len, end_id;
+    const int*   input_lengths;
+    const int*   top_k;        // device [B] effective k (0 => row belongs to the top-p layer)
+    const float* top_p_topk;   // device [B] p used by the top-k layer
+    const float* top_p_topp;   // device [B] p used by the top-p layer
+    const float* temperature;  // device [B]
+    const float* repetition_penalty;  // device [B] or NULL
+    const int*   min_length;          // device [B] or NULL
+    const uint64_t* random_seed;      // device [B]
+    uint64_t*       draw_counter;     // device [B]
+    int             apply_temperature, apply_repetition;  // host decided (BaseSamplingLayer.cc:283-313 ALL_OF logic)
+    const int*      stop_words;       // device [B,2,stop_len] or NULL
+    int             stop_len;
+    const int*      optional_last_tokens;  // device [B,M] or NULL
+    int             optional_count;
+    int             return_cum_log_probs;
+    int*            output_ids;  // time-major [total, B]
+    uint8_t*        finished;
+    int*            seq_len;
+    float*          cum_log_probs;
+    int*            pad_count;
+    DecodeState*    state;
+    int*            h_flags;  // pinned host mirror: [0] = all_finished, [1] = step that produced it
+    void*           ws;       // workspace (see sampling_workspace_bytes)
+};
+size_t sampling_workspace_bytes(int B, int V);
+void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s);
+void   launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
+                          uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
+                          int s_max, hipStream_t s);
+void   launch_gather_tree(int* output_ids, int* sequence_lengths, const int* step_ids, const int* seq_len,
+                          const int* input_lengths, int B, int max_input_len, int total, int end_id, hipStream_t s);
+
+}  // namespace ftcf

@@ -1,0 +1,237 @@
+// MFMA GEMM over the engine's tiled weights: the prefill / batched (m > 4) counterpart of the GEMV kernels.
+//
+// Replaces CutlassFpAIntBGemmRunner<half,uint8_t>::gemm / gemm_bias_act
+// (kernels/cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm_template.h:45-197, mainloop
+// cutlass_extensions/.../gemm/threadblock/dq_mma_multistage.h) and the cuBLAS fp16 GEMMs
+// (utils/cublasMMWrapper.cc:94-386) for GptContextAttentionLayer.cc:101-141,350-393 and FfnLayer.cc:172-372.
+//
+// Shape: weights are the B operand of v_mfma_f32_16x16x32_f16 straight from global memory -- a weight tile IS one
+// wave-load and one lane's 16 bytes ARE that lane's B fragment(s) (int8: two fragments after the in-register
+// dequant, k order (lane>>4)*16 + c*8 + j; fp16: one fragment, k order (lane>>4)*8 + j).  Each wave owns 16 output
+// columns and keeps its dequantised B fragments in registers across all row groups of the block tile; activations
+// are staged through LDS and shared by the 4 waves.  Roofline: MFMA for m >= 512, HBM below.
+#include "ftcf_common.h"
+#include "kernels.h"
+
+namespace ftcf {
+
+constexpr int GEMM_KSTEP = 64;
+constexpr int GEMM_LDA   = GEMM_KSTEP + 8;  // halves per LDS row (16 B pad)
+
+template<bool INT8, int RG>
+__global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
+                                                    const f16* __restrict__ scale, const f16* __restrict__ bias,
+                                                    int act, f16* __restrict__ C, int m, int n, int k)
+{
+    constexpr int BM = RG * 16;
+    __shared__ __attribute__((aligned(16))) f16 As[BM * GEMM_LDA];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const int nt = blockIdx.x * 4 + wid;  // column group of this wave
+    const int NT = n / 16;
+    const bool active = nt < NT;
+    const int  ksteps = k / GEMM_KSTEP;
+
+    // B stream pointers
+    const int    KT    = INT8 ? k / TILE_K_I8 : k / TILE_K_F16;
+    const u32x4* wp    = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(W)
+                                                     + ((size_t)(active ? nt : 0) * KT * 64 + lane) * 16);
+    f16x2        scale2 = {(f16)1.f, (f16)1.f};
+    if constexpr (INT8) {
+        if (active) {
+            const f16 sc = scale[nt * 16 + c];
+            scale2       = f16x2{sc, sc};
+        }
+    }
+
+    // A staging: BM x 64 halves, 8 halves (16 B) per thread-chunk
+    constexpr int CHUNKS = BM * GEMM_KSTEP / 8;             // 16-byte chunks per stage
+    constexpr int CPT    = (CHUNKS + 255) / 256;            // chunks per thread
+    u32x4         areg[CPT];
+    auto load_a = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < CHUNKS) {
+                int row = m0 + ch / 8;
+                row     = row < m ? row : m - 1;
+                areg[i] = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)ks * GEMM_KSTEP + (ch % 8) * 8);
+            }
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < CHUNKS) {
+                *reinterpret_cast<u32x4*>(&As[(ch / 8) * GEMM_LDA + (ch % 8) * 8]) = areg[i];
+            }
+        }
+    };
+
+    f32x4 acc[RG];
+#pragma unroll
+    for (int r = 0; r < RG; r++) {
+        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    u32x4 breg[2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
+    auto load_b = [&](int ks) {
+        if constexpr (INT8) {
+            breg[0] = __builtin_nontemporal_load(wp + (size_t)ks * 64);
+        }
+        else {
+            breg[0] = __builtin_nontemporal_load(wp + (size_t)(2 * ks) * 64);
+            breg[1] = __builtin_nontemporal_load(wp + (size_t)(2 * ks + 1) * 64);
+        }
+    };
+
+    load_a(0);
+    if (active) {
+        load_b(0);
+    }
+    for (int ks = 0; ks < ksteps; ks++) {
+        __syncthreads();  // previous step's fragment reads are done
+        store_a();
+        f16x8 bf[2];
+        if constexpr (INT8) {
+            f16x2 d[8];
+            dequant4(breg[0].x, scale2, d[0], d[1]);
+            dequant4(breg[0].y, scale2, d[2], d[3]);
+            dequant4(breg[0].z, scale2, d[4], d[5]);
+            dequant4(breg[0].w, scale2, d[6], d[7]);
+            bf[0] = f16x8{d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
+            bf[1] = f16x8{d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
+        }
+        else {
+            bf[0] = __builtin_bit_cast(f16x8, breg[0]);
+            bf[1] = __builtin_bit_cast(f16x8, breg[1]);
+        }
+        __syncthreads();
+        if (ks + 1 < ksteps) {  // prefetch the next stage into registers while this one is consumed
+            load_a(ks + 1);
+            if (active) {
+                load_b(ks + 1);
+            }
+        }
+        if (active) {
+            // A fragment k offsets must follow the B fragment's k order (see file header)
+            const int koff0 = INT8 ? g * 16 : g * 8;
+            const int koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff0]);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff1]);
+                acc[r]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[0], acc[r], 0, 0, 0);
+                acc[r]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[1], acc[r], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) {
+        return;
+    }
+    // C/D layout of mfma 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int   col = nt * 16 + c;
+    const float bv  = bias ? (float)bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = m0 + r * 16 + g * 4 + j;
+            if (row < m) {
+                float v = acc[r][j];
+                f16   h;
+                if constexpr (INT8) {  // fused fp32 epilogue (epilogue_helpers.h:52-62)
+                    v += bv;
+                    if (act == 1) {
+                        v = gelu_f32(v);
+                    }
+                    h = (f16)v;
+                }
+                else {  // cuBLAS rounds to half; bias/gelu follow in half (activation_kernels.cu:401-426)
+                    h = (f16)v;
+                    if (act == 1) {
+                        h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
+                    }
+                    else if (bias) {
+                        h = h + bias[col];
+                    }
+                }
+                C[(size_t)row * n + col] = h;
+            }
+        }
+    }
+}
+
+void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
+                       int k, bool int8, hipStream_t s)
+{
+    if (m == 0) {
+        return;
+    }
+    FTCF_CHECK_ARG(k % GEMM_KSTEP == 0, "GEMM needs k % 64 == 0 (as the reference: fpA_intB_gemm_template.h:159-163)");
+    FTCF_CHECK_ARG(n % 16 == 0, "GEMM needs n % 16 == 0");
+    const int NT = n / 16;
+    if (m <= 32) {
+        dim3 grid((NT + 3) / 4, (m + 31) / 32);
+        if (int8) {
+            hipLaunchKernelGGL((k_gemm_tiled<true, 2>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+        }
+        else {
+            hipLaunchKernelGGL((k_gemm_tiled<false, 2>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+        }
+    }
+    else {
+        dim3 grid((NT + 3) / 4, (m + 127) / 128);
+        if (int8) {
+            hipLaunchKernelGGL((k_gemm_tiled<true, 8>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+        }
+        else {
+            hipLaunchKernelGGL((k_gemm_tiled<false, 8>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+        }
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// logits_f32[m, n] = A[m,k] x W[n,k]^T for m > 4 (batched decode LM head).  W rows are k-contiguous, which is the
+// B-operand order of the MFMA directly: lane (col = lane&15, kgroup = lane>>4) reads 16 B of row n0+col.
+__global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ A, const f16* __restrict__ W,
+                                                        float* __restrict__ C, int m, int n, int k, int ldc)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + wid) * 16;
+    const int m0 = blockIdx.y * 16;
+    if (n0 >= n) {
+        return;
+    }
+    const int  wrow = (n0 + c < n) ? n0 + c : n - 1;
+    const int  arow = (m0 + c < m) ? m0 + c : m - 1;
+    f32x4      acc  = {0.f, 0.f, 0.f, 0.f};
+    const f16* wp   = W + (size_t)wrow * k + g * 8;
+    const f16* ap   = A + (size_t)arow * k + g * 8;
+    for (int k0 = 0; k0 < k; k0 += 32) {
+        const f16x8 b = *reinterpret_cast<const f16x8*>(wp + k0);
+        const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k0);
+        acc           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = m0 + g * 4 + j;
+        if (row < m && n0 + c < n) {
+            C[(size_t)row * ldc + n0 + c] = acc[j];
+        }
+    }
+}
+
+void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s)
+{
+    FTCF_CHECK_ARG(k % 32 == 0, "k must be a multiple of 32");
+    dim3 grid((n + 63) / 64, (m + 15) / 16);
+    hipLaunchKernelGGL(k_gemm_nk_f32out, grid, dim3(256), 0, s, A, W_nk, C, m, n, k, ldc);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ftcf

@@ -1,0 +1,521 @@
+// Weight-streaming GEMV kernels for the per-token decode step (m <= 4 rows), gfx950.
+//
+// These replace, on the decode path, the reference's CutlassFpAIntBGemmRunner<half,uint8_t>::gemm / gemm_bias_act
+// (kernels/cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm_template.h:511-581) and cublasMMWrapper::Gemm
+// (utils/cublasMMWrapper.cc:94-386) call sites of DecoderSelfAttentionLayer.cc:532-577,635-678 and
+// FfnLayer.cc:203-231,330-343, fused with invokeGeneralLayerNorm (kernels/layernorm_kernels.cu:157-286) and
+// invokeAddBiasAttentionFfnResidual (kernels/add_residual_kernels.cu:116-178).
+//
+// Roofline: HBM.  Every weight byte is read exactly once per token; algorithmic bytes per launch = K*N (int8)
+// or 2*K*N (fp16) (+ 2N scales).  One wave-level load instruction fetches one 1 KiB tile (16 B per lane,
+// non-temporal), 8 tiles are kept in flight per wave while the previous 8 are consumed from registers.
+#include "ftcf_common.h"
+#include "kernels.h"
+
+namespace ftcf {
+
+constexpr int GEMV_U = 8;  // tiles per batch (x2 batches in flight)
+
+template<bool INT8>
+struct TileK {
+    static constexpr int value = INT8 ? TILE_K_I8 : TILE_K_F16;
+};
+
+// Consumes one 16-byte weight fragment against M rows of x held in LDS.
+template<bool INT8, int M>
+__device__ __forceinline__ void consume_tile(const u32x4 w, const f16* xl, const int xstride, const f16x2 scale2,
+                                             float (&acc)[M])
+{
+    if constexpr (INT8) {
+        f16x2 b[8];
+        dequant4(w.x, scale2, b[0], b[1]);
+        dequant4(w.y, scale2, b[2], b[3]);
+        dequant4(w.z, scale2, b[4], b[5]);
+        dequant4(w.w, scale2, b[6], b[7]);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
+            const f16x8 x1 = *reinterpret_cast<const f16x8*>(xl + m * xstride + 8);
+            float       a  = acc[m];
+            a              = dot2(b[0], f16x2{x0[0], x0[1]}, a);
+            a              = dot2(b[1], f16x2{x0[2], x0[3]}, a);
+            a              = dot2(b[2], f16x2{x0[4], x0[5]}, a);
+            a              = dot2(b[3], f16x2{x0[6], x0[7]}, a);
+            a              = dot2(b[4], f16x2{x1[0], x1[1]}, a);
+            a              = dot2(b[5], f16x2{x1[2], x1[3]}, a);
+            a              = dot2(b[6], f16x2{x1[4], x1[5]}, a);
+            a              = dot2(b[7], f16x2{x1[6], x1[7]}, a);
+            acc[m]         = a;
+        }
+    }
+    else {
+        const f16x8 b = __builtin_bit_cast(f16x8, w);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
+            float       a  = acc[m];
+            a              = dot2(f16x2{b[0], b[1]}, f16x2{x0[0], x0[1]}, a);
+            a              = dot2(f16x2{b[2], b[3]}, f16x2{x0[2], x0[3]}, a);
+            a              = dot2(f16x2{b[4], b[5]}, f16x2{x0[4], x0[5]}, a);
+            a              = dot2(f16x2{b[6], b[7]}, f16x2{x0[6], x0[7]}, a);
+            acc[m]         = a;
+        }
+    }
+}
+
+// Streams `ntiles` consecutive tiles of one column group.  wp: this lane's 16 B of the first tile.
+// xl: LDS pointer to this lane's k offset of the first tile (row 0); rows are xstride halves apart.
+template<bool INT8, int M>
+__device__ __forceinline__ void wave_stream(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
+                                            const f16x2 scale2, float (&acc)[M])
+{
+    constexpr int TK = TileK<INT8>::value;
+    u32x4         cur[GEMV_U], nxt[GEMV_U];
+    int           t = 0;
+    if (ntiles >= GEMV_U) {
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            cur[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+        }
+        for (; t + 2 * GEMV_U <= ntiles; t += GEMV_U) {
+#pragma unroll
+            for (int u = 0; u < GEMV_U; u++) {
+                nxt[u] = __builtin_nontemporal_load(wp + (size_t)(t + GEMV_U + u) * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < GEMV_U; u++) {
+                consume_tile<INT8, M>(cur[u], xl + (t + u) * TK, xstride, scale2, acc);
+            }
+#pragma unroll
+            for (int u = 0; u < GEMV_U; u++) {
+                cur[u] = nxt[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            consume_tile<INT8, M>(cur[u], xl + (t + u) * TK, xstride, scale2, acc);
+        }
+        t += GEMV_U;
+    }
+    for (; t < ntiles; t++) {
+        const u32x4 w = __builtin_nontemporal_load(wp + (size_t)t * 64);
+        consume_tile<INT8, M>(w, xl + t * TK, xstride, scale2, acc);
+    }
+}
+
+// After wave_stream lane (g, c) holds the partial of column c over its k sub-chunks; fold the 4 lane groups.
+template<int M>
+__device__ __forceinline__ void fold_groups(float (&acc)[M])
+{
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] += __shfl_xor(acc[m], 16, 64);
+        acc[m] += __shfl_xor(acc[m], 32, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_A: y0 = LN1(x) * W0        (QKV, no bias: the attention kernel adds it like the reference's MMHA)
+//      y1 = gelu(LN2(x) * W1 + b1)   (FFN first projection, fused epilogue of gemm_bias_act)
+// One launch, one wave per 16-column group over the full K extent; the block recomputes the LayerNorm of the
+// (tiny, L2 resident) layer input instead of paying a kernel boundary for it.
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M>
+__global__ __launch_bounds__(256) void k_ln_gemv(const LnGemvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16*   xs  = reinterpret_cast<f16*>(smem);                      // [M][K]
+    float* red = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*4 floats
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int seg  = ((int)blockIdx.x >= p.blocks0) ? 1 : 0;
+    const int grp  = (seg ? ((int)blockIdx.x - p.blocks0) : (int)blockIdx.x) * 4 + wid;  // column group in segment
+    const int NT   = seg ? p.NT1 : p.NT0;
+    const int K    = p.K;
+
+    // ---- LayerNorm prologue: fp16 half2-path numerics of layernorm_kernels.cu:157-286 ----
+    const f16* gamma = seg ? p.gamma1 : p.gamma0;
+    const f16* beta  = seg ? p.beta1 : p.beta0;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const f16* xr = p.x + (size_t)m * K;
+        float      s[2] = {0.f, 0.f};
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float f = (float)v[j];
+                s[0] += f;
+                s[1] += f * f;
+            }
+        }
+        block_sum<2>(s, red);
+        const float mean = s[0] / (float)K;
+        const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+        const f16   mh = (f16)mean, rh = (f16)rstd;
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+            const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + i);
+            const f16x8 b = *reinterpret_cast<const f16x8*>(beta + i);
+            f16x8       o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                o[j] = (((v[j] - mh) * rh) * g[j]) + b[j];
+            }
+            *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+        }
+    }
+    __syncthreads();
+    if (grp >= NT) {
+        return;
+    }
+
+    constexpr int TK = TileK<INT8>::value;
+    const int     KT = K / TK;
+    const int     c = lane & 15, g = lane >> 4;
+    const char*   wbase = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
+    const u32x4*  wp    = reinterpret_cast<const u32x4*>(wbase + ((size_t)grp * KT * 64 + lane) * 16);
+    const int     n     = grp * 16 + c;
+    f16x2         scale2 = {(f16)1.0f, (f16)1.0f};
+    if constexpr (INT8) {
+        const f16 sc = (seg ? p.scale1 : p.scale0)[n];
+        scale2       = f16x2{sc, sc};
+    }
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] = 0.f;
+    }
+    wave_stream<INT8, M>(wp, KT, xs + g * (TK / 4), K, scale2, acc);
+    fold_groups<M>(acc);
+    if (g == 0) {
+        f16*      out = seg ? p.out1 : p.out0;
+        const int N   = NT * 16;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            float v = acc[m];
+            if (seg == 1) {
+                if constexpr (INT8) {
+                    // fused epilogue in fp32 (epilogue_helpers.h:52-62): bias + gelu, one rounding
+                    v      = gelu_f32(v + (float)p.bias1[n]);
+                    out[(size_t)m * N + n] = (f16)v;
+                }
+                else {
+                    // fp16 engine: GEMM rounds to half, then invokeAddBiasGeluV2 in half (activation_kernels.cu:401-426)
+                    f16 h                  = (f16)v + p.bias1[n];
+                    out[(size_t)m * N + n] = gelu_f16(h);
+                }
+            }
+            else {
+                out[(size_t)m * N + n] = (f16)v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generic split-K GEMV: one block per 16-column group, its waves split up to two K segments
+// (segment A = x_a * W_a, segment B = x_b * W_b).  Epilogues:
+//   EPI_PLAIN    : out = half(acc_a [+ bias, gelu])                                   (single segment)
+//   EPI_RESIDUAL : attn = half(acc_a), ffn = half(acc_b), out = ffn + attn + bias + x_in/TP
+//                  (add_residual_kernels.cu:116-152; `inplace_variant` selects the fp32-sum form)
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M, int EPI>
+__global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(const SplitKParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TK   = TileK<INT8>::value;
+    const int     lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int     nw   = blockDim.x >> 6;
+    const int     grp  = blockIdx.x;
+    const int     c = lane & 15, g = lane >> 4;
+
+    const int seg   = p.wave_seg[wid];
+    const int t0    = p.wave_t0[wid];
+    const int nt    = p.wave_nt[wid];
+    const int KTseg = seg ? p.KT_b : p.KT_a;
+    const int Kseg  = KTseg * TK;
+
+    // per-wave private x slice in LDS: [M][slice_halves]
+    f16*       xs     = reinterpret_cast<f16*>(smem) + (size_t)wid * M * p.slice_halves;
+    const f16* xsrc   = seg ? p.x_b : p.x_a;
+    const int  nhalf  = nt * TK;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        for (int i = lane * 8; i < nhalf; i += 64 * 8) {
+            *reinterpret_cast<f16x8*>(xs + (size_t)m * p.slice_halves + i) =
+                *reinterpret_cast<const f16x8*>(xsrc + (size_t)m * Kseg + (size_t)t0 * TK + i);
+        }
+    }
+    // no barrier needed: the slice is read by the wave that wrote it (LDS ops of one wave are ordered)
+
+    const char*  wbase = reinterpret_cast<const char*>(seg ? p.W_b : p.W_a);
+    const u32x4* wp    = reinterpret_cast<const u32x4*>(wbase + (((size_t)grp * KTseg + t0) * 64 + lane) * 16);
+    const int    n     = grp * 16 + c;
+    f16x2        scale2 = {(f16)1.0f, (f16)1.0f};
+    if constexpr (INT8) {
+        const f16 sc = (seg ? p.scale_b : p.scale_a)[n];
+        scale2       = f16x2{sc, sc};
+    }
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] = 0.f;
+    }
+    wave_stream<INT8, M>(wp, nt, xs + g * (TK / 4), p.slice_halves, scale2, acc);
+    fold_groups<M>(acc);
+
+    // cross-wave reduction in a fixed order (deterministic)
+    float* red = reinterpret_cast<float*>(smem + (size_t)nw * M * p.slice_halves * 2);  // [nw][M][16]
+    if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            red[(wid * M + m) * 16 + c] = acc[m];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < M * 16) {
+        const int m  = threadIdx.x >> 4;
+        const int cc = threadIdx.x & 15;
+        const int nn = grp * 16 + cc;
+        float     sa = 0.f, sb = 0.f;
+        for (int w = 0; w < nw; w++) {
+            const float v = red[(w * M + m) * 16 + cc];
+            if (p.wave_seg[w]) {
+                sb += v;
+            }
+            else {
+                sa += v;
+            }
+        }
+        const size_t oidx = (size_t)m * p.N + nn;
+        if constexpr (EPI == EPI_PLAIN) {
+            if constexpr (INT8) {
+                float v = sa;
+                if (p.bias) {
+                    v += (float)p.bias[nn];
+                }
+                if (p.act == 1) {
+                    v = gelu_f32(v);
+                }
+                p.out[oidx] = (f16)v;
+            }
+            else {
+                f16 h = (f16)sa;
+                if (p.act == 1) {
+                    h = gelu_f16(p.bias ? (f16)(h + p.bias[nn]) : h);
+                }
+                else if (p.bias) {
+                    h = h + p.bias[nn];
+                }
+                p.out[oidx] = h;
+            }
+        }
+        else {
+            const f16 attn = (f16)sa, ffn = (f16)sb;
+            const f16 xin  = (f16)((float)p.x_in[oidx] / (float)p.tp);
+            const f16 b    = p.bias[nn];
+            f16       r;
+            if (p.inplace_variant) {
+                r = (f16)((float)xin + (float)ffn + (float)attn + (float)b);
+            }
+            else {
+                r = ((ffn + attn) + b) + xin;
+            }
+            p.out[oidx] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LM head: logits_f32[m, n] = x[m, :] . W[n, :]  with W the replicated fp16 [V, H] tensor, read in place
+// (models/gptneox/GptNeoX.cc:866-912).  One wave per 4 vocabulary rows, lanes along k.
+// ---------------------------------------------------------------------------------------------------------------
+template<int M>
+__global__ __launch_bounds__(256) void k_lm_head(const f16* __restrict__ x, const f16* __restrict__ W,
+                                                 float* __restrict__ logits, int n_rows, int K, int ldc)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* xs = reinterpret_cast<f16*>(smem);  // [M][K]
+    for (int i = threadIdx.x * 8; i < M * K; i += 256 * 8) {
+        *reinterpret_cast<f16x8*>(xs + i) = *reinterpret_cast<const f16x8*>(x + i);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    constexpr int R  = 4;
+    for (int r0 = (blockIdx.x * 4 + wid) * R; r0 < n_rows; r0 += nwaves * R) {
+        float acc[R][M];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                acc[r][m] = 0.f;
+            }
+        }
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            u32x4 w[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int row = (r0 + r < n_rows) ? (r0 + r) : (n_rows - 1);
+                w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)row * K + k));
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const f16x8 xv = *reinterpret_cast<const f16x8*>(xs + (size_t)m * K + k);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const f16x8 b = __builtin_bit_cast(f16x8, w[r]);
+                    float       a = acc[r][m];
+                    a             = dot2(f16x2{b[0], b[1]}, f16x2{xv[0], xv[1]}, a);
+                    a             = dot2(f16x2{b[2], b[3]}, f16x2{xv[2], xv[3]}, a);
+                    a             = dot2(f16x2{b[4], b[5]}, f16x2{xv[4], xv[5]}, a);
+                    a             = dot2(f16x2{b[6], b[7]}, f16x2{xv[6], xv[7]}, a);
+                    acc[r][m]     = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const float v = wave_sum(acc[r][m]);
+                if (lane == 0 && r0 + r < n_rows) {
+                    logits[(size_t)m * ldc + r0 + r] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M>
+static void launch_ln_gemv_m(const LnGemvParams& p, hipStream_t s)
+{
+    const size_t smem = (size_t)M * p.K * 2 + 64;
+    const int    grid = p.blocks0 + p.blocks1;
+    hipLaunchKernelGGL((k_ln_gemv<INT8, M>), dim3(grid), dim3(256), smem, s, p);
+}
+
+void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s)
+{
+    FTCF_CHECK_ARG(M >= 1 && M <= 4, "ln_gemv supports 1..4 rows");
+    FTCF_CHECK_ARG(p.K % 64 == 0 && p.K % 8 == 0, "K must be a multiple of 64");
+    if (int8) {
+        switch (M) {
+            case 1: launch_ln_gemv_m<true, 1>(p, s); break;
+            case 2: launch_ln_gemv_m<true, 2>(p, s); break;
+            case 3: launch_ln_gemv_m<true, 3>(p, s); break;
+            default: launch_ln_gemv_m<true, 4>(p, s); break;
+        }
+    }
+    else {
+        switch (M) {
+            case 1: launch_ln_gemv_m<false, 1>(p, s); break;
+            case 2: launch_ln_gemv_m<false, 2>(p, s); break;
+            case 3: launch_ln_gemv_m<false, 3>(p, s); break;
+            default: launch_ln_gemv_m<false, 4>(p, s); break;
+        }
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// Splits the tiles of up to two segments over `nw` waves proportionally (every non-empty segment gets >= 1 wave).
+void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves)
+{
+    const int TK    = int8 ? TILE_K_I8 : TILE_K_F16;
+    const int total = p.KT_a + p.KT_b;
+    int       nw    = max_waves;
+    // keep >= 8 tiles per wave when possible
+    while (nw > 1 && total / nw < GEMV_U) {
+        nw--;
+    }
+    int wa = p.KT_b == 0 ? nw : (int)((double)p.KT_a / total * nw + 0.5);
+    if (p.KT_b > 0) {
+        if (wa < 1) {
+            wa = 1;
+        }
+        if (wa > nw - 1) {
+            wa = nw - 1;
+        }
+        if (nw == 1) {  // two segments need two waves
+            nw = 2;
+            wa = 1;
+        }
+    }
+    const int wb  = nw - wa;
+    int       idx = 0, maxnt = 0;
+    for (int s = 0; s < 2; s++) {
+        const int KT = s ? p.KT_b : p.KT_a;
+        const int W  = s ? wb : wa;
+        for (int w = 0; w < W; w++) {
+            const int t0 = (int)((long)KT * w / W), t1 = (int)((long)KT * (w + 1) / W);
+            p.wave_seg[idx] = s;
+            p.wave_t0[idx]  = t0;
+            p.wave_nt[idx]  = t1 - t0;
+            maxnt           = std::max(maxnt, t1 - t0);
+            idx++;
+        }
+    }
+    p.nwaves       = idx;
+    p.slice_halves = maxnt * TK;
+    (void)M;
+}
+
+template<bool INT8, int M>
+static void launch_splitk_m(const SplitKParams& p, int epi, hipStream_t s)
+{
+    const size_t smem = (size_t)p.nwaves * M * p.slice_halves * 2 + (size_t)p.nwaves * M * 16 * 4;
+    const dim3   grid(p.N / 16), block(p.nwaves * 64);
+    if (epi == EPI_PLAIN) {
+        hipLaunchKernelGGL((k_gemv_splitk<INT8, M, EPI_PLAIN>), grid, block, smem, s, p);
+    }
+    else {
+        hipLaunchKernelGGL((k_gemv_splitk<INT8, M, EPI_RESIDUAL>), grid, block, smem, s, p);
+    }
+}
+
+void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStream_t s)
+{
+    FTCF_CHECK_ARG(M >= 1 && M <= 4, "gemv supports 1..4 rows");
+    FTCF_CHECK_ARG(p.N % 16 == 0, "N must be a multiple of 16");
+    if (int8) {
+        switch (M) {
+            case 1: launch_splitk_m<true, 1>(p, epi, s); break;
+            case 2: launch_splitk_m<true, 2>(p, epi, s); break;
+            case 3: launch_splitk_m<true, 3>(p, epi, s); break;
+            default: launch_splitk_m<true, 4>(p, epi, s); break;
+        }
+    }
+    else {
+        switch (M) {
+            case 1: launch_splitk_m<false, 1>(p, epi, s); break;
+            case 2: launch_splitk_m<false, 2>(p, epi, s); break;
+            case 3: launch_splitk_m<false, 3>(p, epi, s); break;
+            default: launch_splitk_m<false, 4>(p, epi, s); break;
+        }
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s)
+{
+    FTCF_CHECK_ARG(K % 8 == 0, "K must be a multiple of 8");
+    const size_t smem = (size_t)M * K * 2;
+    int          grid = (n_rows + 15) / 16;
+    if (grid > 2048) {
+        grid = 2048;
+    }
+    switch (M) {
+        case 1: hipLaunchKernelGGL((k_lm_head<1>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
+        case 2: hipLaunchKernelGGL((k_lm_head<2>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
+        case 3: hipLaunchKernelGGL((k_lm_head<3>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
+        case 4: hipLaunchKernelGGL((k_lm_head<4>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
+        default: throw Error(-1, "lm_head GEMV supports 1..4 rows");
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ftcf

@@ -1,0 +1,556 @@
+// Dynamic decode (beam_width == 1) for gfx950: penalties, end mask, softmax, top-k / top-p sampling, stop criteria.
+// Counterpart of DynamicDecodeLayer<float>::forward (layers/DynamicDecodeLayer.cc:192-497),
+// BaseSamplingLayer<T>::forward (layers/sampling_layers/BaseSamplingLayer.cc:255-359),
+// TopKSamplingLayer::runSampling (TopKSamplingLayer.cu:184-257), TopPSamplingLayer::runSampling and the kernels
+// kernels/sampling_penalty_kernels.cu:117-147,367-425,485-520, kernels/sampling_topk_kernels.cu:67-311,
+// kernels/sampling_topp_kernels.cu:802-1000,1296-1345, kernels/select_optional_last_tokens.cu:22-85,
+// kernels/stop_criteria_kernels.cu:24-158, kernels/decoding_kernels.cu:26-65,452-583.
+//
+// All per-request state (step counter, finished flags, sequence lengths) lives on the device so the per-token step
+// is a fixed launch sequence (hipGraph friendly); the host only reads a pinned "all finished" word.
+#include "ftcf_common.h"
+#include "kernels.h"
+
+namespace ftcf {
+
+constexpr int TOPK_BLOCKS = 8;     // blocks per row in stage 1 (the reference's BLOCKS_PER_BEAM_)
+constexpr int TOPK_MAX    = 1024;  // TopKSamplingLayer.cu: setup_topk_runtime_args<1024>
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+// identical to oracle/ftcf_oracle.c orc_uniform: (0,1].  The reference draws from curand XORWOW
+// (sampling_topk_kernels.cu:32-65,283): only the distribution is reproducible, greedy is unaffected.
+__device__ __forceinline__ float ftcf_uniform(uint64_t seed, uint64_t row, uint64_t draw)
+{
+    const uint64_t z = splitmix64(seed ^ splitmix64(row * 0x632be59bd9b4e019ULL + draw));
+    const uint32_t r = (uint32_t)(z >> 40);
+    return (float)(r + 1u) * (1.0f / 16777216.0f);
+}
+
+struct VI {
+    float v;
+    int   i;
+};
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi)
+{
+    return (v > bv) || (v == bv && i < bi);
+}
+__device__ __forceinline__ VI wave_best(VI x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(x.v, o, 64);
+        const int   oi = __shfl_xor(x.i, o, 64);
+        if (better(ov, oi, x.v, x.i)) {
+            x.v = ov;
+            x.i = oi;
+        }
+    }
+    return x;
+}
+// block arg-best; result valid in all threads.  red: 2*nw words of LDS.
+__device__ __forceinline__ VI block_best(VI x, float* redv, int* redi)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    x = wave_best(x);
+    if (lane == 0) {
+        redv[wid] = x.v;
+        redi[wid] = x.i;
+    }
+    __syncthreads();
+    VI r{redv[0], redi[0]};
+    for (int w = 1; w < nw; w++) {
+        if (better(redv[w], redi[w], r.v, r.i)) {
+            r.v = redv[w];
+            r.i = redi[w];
+        }
+    }
+    __syncthreads();
+    return r;
+}
+
+// ---- step 1: penalties, masks, softmax (one block per row) -----------------------------------------------------
+__global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[64];
+    const int        b    = blockIdx.x;
+    const int        V    = p.V;
+    float*           l    = p.logits + (size_t)b * V;
+    const int        step = p.state->step;
+    const int        tid = threadIdx.x, nt = blockDim.x;
+
+    // K15 select_optional_last_tokens: first generated step only (DynamicDecodeLayer.cc:250-267)
+    if (p.optional_last_tokens && step == p.max_input_len) {
+        uint32_t* bits = reinterpret_cast<uint32_t*>(smem);
+        const int words = (V + 31) / 32;
+        for (int i = tid; i < words; i += nt) {
+            bits[i] = 0u;
+        }
+        __syncthreads();
+        for (int j = tid; j < p.optional_count; j += nt) {
+            const int t = p.optional_last_tokens[(size_t)b * p.optional_count + j];
+            if (t >= 0 && t < V) {
+                atomicOr(&bits[t >> 5], 1u << (t & 31));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < V; i += nt) {
+            if (!((bits[i >> 5] >> (i & 31)) & 1u)) {
+                l[i] = -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+    if (p.apply_temperature) {  // sampling_penalty_kernels.cu:117-147
+        const float inv = 1.0f / (p.temperature[b] + 1e-6f);
+        for (int i = tid; i < V; i += nt) {
+            l[i] *= inv;
+        }
+        __syncthreads();
+    }
+    if (p.apply_repetition && step > 1) {  // sampling_penalty_kernels.cu:367-425
+        float*      newv = reinterpret_cast<float*>(smem);
+        int*        idx  = reinterpret_cast<int*>(newv + p.total_len);
+        const float pen  = p.repetition_penalty[b];
+        const int   in_len = p.input_lengths[b];
+        for (int t = tid; t < step; t += nt) {
+            if (t >= in_len && t < p.max_input_len) {
+                idx[t] = -1;
+                continue;
+            }
+            const int   id = p.output_ids[(size_t)t * p.B + b];
+            const float lg = l[id];
+            idx[t]         = id;
+            newv[t]        = lg < 0.0f ? lg * pen : lg / pen;
+        }
+        __syncthreads();
+        for (int t = tid; t < step; t += nt) {
+            if (idx[t] >= 0) {
+                l[idx[t]] = newv[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (p.min_length && tid == 0) {  // sampling_penalty_kernels.cu:485-520
+        if (p.seq_len[b] + 1 - p.max_input_len < p.min_length[b]) {
+            l[p.end_id] = -FLT_MAX;
+        }
+    }
+    __syncthreads();
+    const bool fin      = p.finished[b];
+    const bool is_topp  = p.top_k[b] == 0;
+    const bool need_sm  = is_topp || p.return_cum_log_probs;
+    if (fin) {  // addBiasEndMask (sampling_topk_kernels.cu:67-110)
+        for (int i = tid; i < V; i += nt) {
+            l[i] = (i == p.end_id) ? FLT_MAX : -FLT_MAX;
+        }
+        __syncthreads();
+    }
+    if (need_sm) {  // addBiasSoftMax (sampling_topp_kernels.cu:1296-1345)
+        float mx = -FLT_MAX;
+        for (int i = tid; i < V; i += nt) {
+            mx = fmaxf(mx, l[i]);
+        }
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = mx;
+        }
+        __syncthreads();
+        mx = red[0];
+        for (int w = 1; w < (nt >> 6); w++) {
+            mx = fmaxf(mx, red[w]);
+        }
+        __syncthreads();
+        float sum = 0.f;
+        for (int i = tid; i < V; i += nt) {
+            const float e = __expf(l[i] - mx);
+            l[i]          = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        if ((tid & 63) == 0) {
+            red[tid >> 6] = sum;
+        }
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < (nt >> 6); w++) {
+            tot += red[w];
+        }
+        const float den = tot + 1e-6f;
+        for (int i = tid; i < V; i += nt) {
+            l[i] = l[i] / den;
+        }
+    }
+}
+
+// ---- step 2: stage-1 top-k: every block extracts the k best of its contiguous vocabulary slice ------------------
+__global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, float* cand_v, int* cand_i, int slice)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redv[4];
+    __shared__ int   redi[4];
+    float*           sv = reinterpret_cast<float*>(smem);  // [slice]
+    const int        b = blockIdx.y, blk = blockIdx.x;
+    int              k = p.top_k[b];
+    if (k == 0) {
+        k = 1;  // top-p rows only need the arg max for the shortcut test
+    }
+    if (p.finished[b]) {
+        return;
+    }
+    const int    V  = p.V;
+    const int    i0 = blk * slice;
+    const int    n  = max(0, min(slice, V - i0));
+    const float* l  = p.logits + (size_t)b * V + i0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        sv[i] = l[i];
+    }
+    __syncthreads();
+    float* ov = cand_v + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
+    int*   oi = cand_i + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
+    uint32_t* taken = reinterpret_cast<uint32_t*>(sv + slice);  // [ceil(slice/32)]
+    for (int i = threadIdx.x; i < (slice + 31) / 32; i += 256) {
+        taken[i] = 0u;
+    }
+    __syncthreads();
+    for (int it = 0; it < k; it++) {
+        VI best{-INFINITY, 0x7fffffff};
+        for (int i = threadIdx.x; i < n; i += 256) {
+            if ((taken[i >> 5] >> (i & 31)) & 1u) {
+                continue;
+            }
+            const float v = sv[i];
+            if (best.i == 0x7fffffff || better(v, i, best.v, best.i)) {
+                best.v = v;
+                best.i = i;
+            }
+        }
+        const VI r = block_best(best, redv, redi);
+        if (threadIdx.x == 0) {
+            const bool valid = r.i != 0x7fffffff;
+            ov[it] = valid ? r.v : -INFINITY;
+            oi[it] = valid ? (i0 + r.i) : -1;
+            if (valid) {
+                taken[r.i >> 5] |= 1u << (r.i & 31);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- step 3: merge + sample (one block per row) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* cand_v, int* cand_i)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float redv[4];
+    __shared__ int   redi[4];
+    __shared__ float s_rnd;
+    const int        b = blockIdx.x;
+    const int        V = p.V;
+    const int        step = p.state->step;
+    int*             out_id = p.output_ids + (size_t)step * p.B + b;
+    if (p.finished[b]) {
+        if (threadIdx.x == 0) {
+            *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242 ; top-p: arg max of the end mask
+        }
+        return;
+    }
+    const int k = p.top_k[b];
+    float*    l = p.logits + (size_t)b * V;
+    if (k > 0) {
+        // ---- top-k layer (sampling_topk_kernels.cu:210-311) ----
+        float* sv   = reinterpret_cast<float*>(smem);       // [k] sorted values
+        int*   si   = reinterpret_cast<int*>(sv + TOPK_MAX);  // [k] ids
+        float* cv   = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        int*   ci   = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        for (int it = 0; it < k; it++) {
+            VI best{-INFINITY, 0x7fffffff};
+            for (int c = threadIdx.x; c < TOPK_BLOCKS * k; c += 256) {
+                const int   blk = c / k, j = c % k;
+                const int   id  = ci[blk * TOPK_MAX + j];
+                const float v   = cv[blk * TOPK_MAX + j];
+                if (id >= 0 && better(v, id, best.v, best.i)) {
+                    best.v = v;
+                    best.i = id;
+                }
+            }
+            const VI r = block_best(best, redv, redi);
+            if (threadIdx.x == 0) {
+                sv[it] = r.v;
+                si[it] = r.i;
+            }
+            // remove the winner from the candidate lists
+            for (int c = threadIdx.x; c < TOPK_BLOCKS * k; c += 256) {
+                const int blk = c / k, j = c % k;
+                if (ci[blk * TOPK_MAX + j] == r.i) {
+                    ci[blk * TOPK_MAX + j] = -1;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float smax = sv[0];
+            float       ssum = 0.f;
+            for (int i = 0; i < k; i++) {
+                float u = sv[i];
+                if (!p.return_cum_log_probs) {
+                    u = __expf(u - smax);  // :271-275
+                }
+                sv[i] = u;
+                ssum += u;
+            }
+            const float u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
+            p.draw_counter[b] += 1;
+            float rnd  = u01 * p.top_p_topk[b] * ssum;  // :283
+            int   pick = k - 1;
+            for (int i = 0; i < k; i++) {
+                rnd -= sv[i];
+                if (rnd <= 0.0f || i == k - 1) {
+                    pick = i;
+                    break;
+                }
+            }
+            int id = si[pick];
+            if (id == 0x7fffffff || id < 0) {
+                id = 0;
+            }
+            *out_id = id;
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                p.cum_log_probs[b] += logf(sv[pick]);
+            }
+            p.seq_len[b] += 1;  // :305-308
+            p.finished[b] = (id == p.end_id);
+        }
+    }
+    else {
+        // ---- top-p layer (sampling_topp_kernels.cu:802-1000): probabilities are in `l` ----
+        // stage 1 (k forced to 1) left the arg max of every slice in the candidate lists
+        float* cv = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        int*   ci = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        VI     best{-INFINITY, 0x7fffffff};
+        if (threadIdx.x < TOPK_BLOCKS && ci[threadIdx.x * TOPK_MAX] >= 0) {
+            best.v = cv[threadIdx.x * TOPK_MAX];
+            best.i = ci[threadIdx.x * TOPK_MAX];
+        }
+        const VI    top = block_best(best, redv, redi);
+        const float thr = p.top_p_topp[b];
+        float       u01 = 0.f;
+        if (threadIdx.x == 0) {
+            u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
+            p.draw_counter[b] += 1;
+            s_rnd = u01 * thr;
+        }
+        __syncthreads();
+        int   id = top.i;
+        float pr = top.v;
+        if (!(top.v >= thr)) {
+            // exact sorted walk: repeatedly extract the (value desc, index asc) maximum and accumulate in fp32 until
+            // rand * p <= cumulative -- identical to the sequential scan over the sorted array.
+            float cum = 0.f;
+            for (int it = 0; it < V; it++) {
+                VI bb{-INFINITY, 0x7fffffff};
+                for (int i = threadIdx.x; i < V; i += 256) {
+                    const float v = l[i];
+                    if (better(v, i, bb.v, bb.i)) {
+                        bb.v = v;
+                        bb.i = i;
+                    }
+                }
+                const VI r = block_best(bb, redv, redi);
+                cum += r.v;
+                id = r.i;
+                pr = r.v;
+                if (s_rnd <= cum || it == V - 1) {
+                    break;
+                }
+                if (threadIdx.x == 0) {
+                    l[r.i] = -INFINITY;
+                }
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) {
+            *out_id = id;
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                p.cum_log_probs[b] += logf(pr);
+            }
+            p.seq_len[b] += 1;
+            p.finished[b] = (id == p.end_id);
+        }
+    }
+}
+
+// ---- step 4: stop words, length criterion, bookkeeping (single block) -----------------------------------------
+__global__ void k_decode_finish(const SamplingParams p)
+{
+    __shared__ int s_all;
+    const int      step = p.state->step;
+    if (threadIdx.x == 0) {
+        s_all = 1;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < p.B; b += blockDim.x) {
+        if (p.stop_words) {  // stop_criteria_kernels.cu:24-83
+            const int* words = p.stop_words + (size_t)b * 2 * p.stop_len;
+            const int* offs  = words + p.stop_len;
+            for (int id = 0; id < p.stop_len; id++) {
+                if (offs[id] < 0) {
+                    continue;
+                }
+                const int item_end = offs[id], item_start = id > 0 ? offs[id - 1] : 0;
+                const int item_size = item_end - item_start;
+                bool      stop      = false;
+                if (step + 1 >= item_size) {
+                    stop = true;
+                    for (int t = item_size - 1; t >= 0; t--) {
+                        const int prev = p.output_ids[(size_t)(step - (item_size - 1) + t) * p.B + b];
+                        if (prev != words[item_start + t]) {
+                            stop = false;
+                            break;
+                        }
+                    }
+                }
+                if (stop) {
+                    p.finished[b] = 1;
+                }
+            }
+        }
+        if (step >= p.total_len) {  // length_criterion (stop_criteria_kernels.cu:106-158), limit = total_len
+            p.finished[b] = 1;
+        }
+        if (!p.finished[b]) {
+            atomicAnd(&s_all, 0);
+        }
+        if (step == p.max_input_len) {  // invokeUpdatePaddingCount (gpt_kernels.cu:981-1033)
+            p.pad_count[b] += p.max_input_len - p.input_lengths[b];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.state->all_finished = s_all;
+        p.state->steps_done += 1;
+        p.h_flags[1] = step;
+        __threadfence_system();
+        p.h_flags[0] = s_all;
+        p.state->step = step + 1;
+    }
+}
+
+size_t sampling_workspace_bytes(int B, int V)
+{
+    (void)V;
+    return (size_t)B * TOPK_BLOCKS * TOPK_MAX * (sizeof(float) + sizeof(int));
+}
+
+void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
+{
+    float* cand_v = reinterpret_cast<float*>(p.ws);
+    int*   cand_i = reinterpret_cast<int*>(cand_v + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX);
+    size_t prep_smem = 0;
+    if (p.optional_last_tokens) {
+        prep_smem = std::max(prep_smem, (size_t)((p.V + 31) / 32) * 4);
+    }
+    if (p.apply_repetition) {
+        prep_smem = std::max(prep_smem, (size_t)p.total_len * 8);
+    }
+    FTCF_CHECK_ARG(prep_smem <= 60 * 1024, "sequence too long for the repetition-penalty staging buffer");
+    hipLaunchKernelGGL(k_decode_prep, dim3(p.B), dim3(1024), prep_smem, s, p);
+    const int slice = (p.V + TOPK_BLOCKS - 1) / TOPK_BLOCKS;
+    FTCF_CHECK_ARG((size_t)slice * 4 <= 60 * 1024, "vocabulary slice does not fit in LDS");
+    hipLaunchKernelGGL(k_topk_stage1, dim3(TOPK_BLOCKS, p.B), dim3(256), (size_t)slice * 4 + ((slice + 31) / 32) * 4, s, p, cand_v, cand_i, slice);
+    hipLaunchKernelGGL(k_sample, dim3(p.B), dim3(256), (size_t)TOPK_MAX * 8, s, p, cand_v, cand_i);
+    hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// invokeDecodingInitialize (decoding_kernels.cu:26-65) + invokeMaskPaddingTokens (gpt_kernels.cu:1035-1082)
+__global__ void k_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count,
+                              uint8_t* masked_tokens, uint64_t* draw_counter, const int* input_lengths, DecodeState* st,
+                              int B, int max_input_len, int s_max)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        finished[b]      = 0;
+        seq_len[b]       = max_input_len - 1;
+        cum_log_probs[b] = 0.f;
+        pad_count[b]     = 0;
+        draw_counter[b]  = 0;
+        if (b == 0) {
+            st->step         = max_input_len;
+            st->all_finished = 0;
+            st->steps_done   = 0;
+        }
+    }
+    const int len = input_lengths[b];
+    for (int s = threadIdx.x; s < s_max; s += blockDim.x) {
+        masked_tokens[(size_t)b * s_max + s] = (s >= len && s < max_input_len) ? 1 : 0;
+    }
+}
+
+void launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
+                        uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
+                        int s_max, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decode_init, dim3(B), dim3(256), 0, s, finished, seq_len, cum_log_probs, pad_count,
+                       masked_tokens, draw_counter, input_lengths, st, B, max_input_len, s_max);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// gatherTree with beam_width 1 and no prompts (decoding_kernels.cu:452-583) + the [time,batch] -> [batch,time] transpose
+__global__ void k_gather_tree(int* output_ids, int* sequence_lengths, const int* step_ids, const int* seq_len,
+                              const int* input_lengths, int B, int max_input_len, int total, int end_id)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) {
+        return;
+    }
+    const int tmp_len = seq_len[b] + 1;  // max_sequence_length_final_step = 1
+    sequence_lengths[b] = tmp_len;
+    const int max_len = tmp_len;
+    const int msl     = max_len < total ? max_len : total;
+    int*      beams   = output_ids + (size_t)b * total;
+    for (int t = 0; t < total; t++) {
+        beams[t] = 0;
+    }
+    if (msl <= 0) {
+        return;
+    }
+    const int in_len  = input_lengths[b];
+    const int pad_off = max_input_len - in_len;
+    beams[msl - 1 - pad_off] = step_ids[(size_t)(msl - 1) * B + b];
+    for (int level = msl - 2; level >= 0; level--) {
+        if (level >= in_len && level < max_input_len) {
+            continue;
+        }
+        const int tgt = level >= max_input_len ? level - pad_off : level;
+        beams[tgt]    = step_ids[(size_t)level * B + b];
+    }
+    for (int index = max_len - pad_off; index < total; index++) {
+        beams[index] = end_id;
+    }
+    bool fin = false;
+    for (int t = max_input_len; t < msl; t++) {
+        if (fin) {
+            beams[t] = end_id;
+        }
+        else if (beams[t] == end_id) {
+            fin = true;
+        }
+    }
+}
+
+void launch_gather_tree(int* output_ids, int* sequence_lengths, const int* step_ids, const int* seq_len,
+                        const int* input_lengths, int B, int max_input_len, int total, int end_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gather_tree, dim3(B), dim3(64), 0, s, output_ids, sequence_lengths, step_ids, seq_len,
+                       input_lengths, B, max_input_len, total, end_id);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ftcf

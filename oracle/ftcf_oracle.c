@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 /* ------------------------------------------------------------------------------------------------ */
 /* binary16 emulation                                                                                */
@@ -81,6 +82,11 @@ float orc_half_bits_to_float(uint16_t h)
     float f;
     memcpy(&f, &x, 4);
     return f;
+}
+
+int orc_num_threads(void)
+{
+    return omp_get_max_threads();
 }
 
 float orc_round_half(float x)
@@ -189,47 +195,56 @@ void orc_add_bias_gelu(float* x, const float* bias, int m, int n, int fp16)
 void orc_gemm(const float* A, int m, int k, int n, const float* W, const int8_t* q, const float* scale,
               const float* bias, int act, float* C, int fp16, int out_fp32)
 {
+    /* parallel over column blocks (so that m == 1 decode GEMVs also use every core); per element the k loop runs in
+     * order with a double accumulator */
+    const int NB = 128;
 #pragma omp parallel
     {
-        double* acc  = (double*)malloc(sizeof(double) * (size_t)n);
-        float*  brow = (float*)malloc(sizeof(float) * (size_t)n);
+        double* acc  = (double*)malloc(sizeof(double) * (size_t)NB * (size_t)(m > 0 ? m : 1));
+        float*  brow = (float*)malloc(sizeof(float) * (size_t)NB);
 #pragma omp for schedule(static)
-        for (int i = 0; i < m; i++) {
-            for (int j = 0; j < n; j++) {
-                acc[j] = 0.0;
+        for (int j0 = 0; j0 < n; j0 += NB) {
+            const int nb = (n - j0 < NB) ? (n - j0) : NB;
+            for (int i = 0; i < m * NB; i++) {
+                acc[i] = 0.0;
             }
             for (int kk = 0; kk < k; kk++) {
-                const double a = (double)A[(size_t)i * k + kk];
                 if (q) {
-                    const int8_t* qr = q + (size_t)kk * n;
-                    for (int j = 0; j < n; j++) {
-                        brow[j] = orc_round_half((float)qr[j] * scale[j]);
-                    }
-                    for (int j = 0; j < n; j++) {
-                        acc[j] += a * (double)brow[j];
+                    const int8_t* qr = q + (size_t)kk * n + j0;
+                    for (int j = 0; j < nb; j++) {
+                        brow[j] = orc_round_half((float)qr[j] * scale[j0 + j]);
                     }
                 }
                 else {
-                    const float* wr = W + (size_t)kk * n;
-                    for (int j = 0; j < n; j++) {
-                        acc[j] += a * (double)wr[j];
+                    const float* wr = W + (size_t)kk * n + j0;
+                    for (int j = 0; j < nb; j++) {
+                        brow[j] = wr[j];
+                    }
+                }
+                for (int i = 0; i < m; i++) {
+                    const double a = (double)A[(size_t)i * k + kk];
+                    double*      ar = acc + (size_t)i * NB;
+                    for (int j = 0; j < nb; j++) {
+                        ar[j] += a * (double)brow[j];
                     }
                 }
             }
-            for (int j = 0; j < n; j++) {
-                float v = (float)acc[j];
-                if (q) { /* fused epilogue in fp32 */
-                    if (bias) {
-                        v += bias[j];
+            for (int i = 0; i < m; i++) {
+                for (int j = 0; j < nb; j++) {
+                    float v = (float)acc[(size_t)i * NB + j];
+                    if (q) { /* fused epilogue in fp32 */
+                        if (bias) {
+                            v += bias[j0 + j];
+                        }
+                        if (act == 1) {
+                            v = gelu_f32(v);
+                        }
                     }
-                    if (act == 1) {
-                        v = gelu_f32(v);
+                    if (!out_fp32) {
+                        v = RT(v);
                     }
+                    C[(size_t)i * n + j0 + j] = v;
                 }
-                if (!out_fp32) {
-                    v = RT(v);
-                }
-                C[(size_t)i * n + j] = v;
             }
         }
         free(acc);

@@ -74,6 +74,7 @@ typedef struct {
 } orc_sampling;
 
 /* ---- scalar helpers ---- */
+int      orc_num_threads(void);
 float    orc_round_half(float x);
 uint16_t orc_float_to_half_bits(float x);
 float    orc_half_bits_to_float(uint16_t h);

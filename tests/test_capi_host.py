@@ -1,0 +1,80 @@
+"""CPU (-m "not gpu"): the C-ABI library loads, exports every symbol include/ftcf.h declares, fails loudly without a
+GPU, and its host-side quantiser (libth_common counterpart) matches the oracle bit for bit."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fastertransformer4codefuse_amd import capi
+from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp, symmetric_quantize_last_axis_of_batched_matrix_int8
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ftcf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ftcf_[a-z0-9_A-Z]+)\s*\(", hdr)) - {"ftcf_token_callback"})
+    assert declared, "no declarations parsed"
+    lib = capi.lib()
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTED) == declared
+    assert lib.ftcf_version() == 100
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_ops_fail_loudly_without_a_gpu():
+    assert capi.device_count() == 0
+    with pytest.raises(capi.FtcfError):
+        capi.require_gpu()
+    rc = capi.lib().ftcf_layernorm(None, None, None, None, 1, 8, C.c_float(1e-5), 1, None)
+    assert rc == -5 and b"no HIP device" in capi.lib().ftcf_last_error()
+    with pytest.raises(capi.FtcfError):
+        GptNeoXOp(None, 0, 4, 64, 1024, 2, 512, 16, 0, 2, 1, 1, 0, 1024, True, [torch.zeros(1)], [], [])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_host_quantizer_matches_oracle_bit_exact(dtype):
+    torch.manual_seed(0)
+    K, N = 256, 96
+    w = (torch.randn(K, N) * 0.02).to(dtype).contiguous()
+    w[:, 5] = 0  # all-zero column: NaN path of the reference
+    q, s = symmetric_quantize_last_axis_of_batched_matrix_int8(w)
+    assert q.shape == w.shape and q.dtype == torch.int8 and s.dtype == dtype and s.shape == (N,)
+    q_rm = torch.empty((K, N), dtype=torch.int8)
+    capi.check(capi.lib().ftcf_int8_tiled_to_rowmajor(capi.vp(q), C.c_size_t(K), C.c_size_t(N), capi.vp(q_rm)))
+    oq, os_ = orc.symmetric_quantize_int8(w.float().numpy(), weight_is_half=(dtype == torch.float16))
+    np.testing.assert_array_equal(q_rm.numpy(), oq)
+    np.testing.assert_array_equal(s.float().numpy(), os_)
+    # round trip of the tile layout
+    q2 = torch.empty_like(q)
+    capi.check(capi.lib().ftcf_int8_rowmajor_to_tiled(capi.vp(q_rm), C.c_size_t(K), C.c_size_t(N), capi.vp(q2)))
+    assert torch.equal(q, q2)
+
+
+def test_tile_layout_known_answer():
+    """DESIGN.md layout: byte ((nt*KT+kt)*64 + lane)*16 + j = u8(q[kt*64 + (lane>>4)*16 + j][nt*16 + (lane&15)] + 128)."""
+    K, N = 128, 32
+    q = (np.arange(K * N, dtype=np.int64).reshape(K, N) % 251 - 125).astype(np.int8)
+    t = np.empty_like(q)
+    capi.check(capi.lib().ftcf_int8_rowmajor_to_tiled(capi.vp(q), C.c_size_t(K), C.c_size_t(N), capi.vp(t)))
+    flat = t.reshape(-1).view(np.uint8)
+    for (nt, kt, lane, j) in [(0, 0, 0, 0), (1, 1, 37, 9), (0, 1, 63, 15), (1, 0, 16, 3)]:
+        k = kt * 64 + (lane >> 4) * 16 + j
+        n = nt * 16 + (lane & 15)
+        assert flat[((nt * 2 + kt) * 64 + lane) * 16 + j] == (int(q[k, n]) + 128)
+
+
+def test_batched_3d_quantize_and_argument_checks():
+    w = (torch.randn(2, 64, 16) * 0.1).half()
+    q, s = symmetric_quantize_last_axis_of_batched_matrix_int8(w)
+    assert q.shape == (2, 64, 16) and s.shape == (2, 16)
+    with pytest.raises(RuntimeError):
+        symmetric_quantize_last_axis_of_batched_matrix_int8(torch.zeros(4))
+    with pytest.raises(capi.FtcfError):
+        symmetric_quantize_last_axis_of_batched_matrix_int8(torch.zeros(60, 16))  # K % 64 != 0

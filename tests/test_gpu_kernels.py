@@ -1,0 +1,230 @@
+"""-m gpu: kernel-level parity of the HIP path (through the C ABI) against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+capi = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    global capi
+    from fastertransformer4codefuse_amd import capi as _c
+    capi = _c
+    capi.require_gpu()
+    yield
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def quant(w_np):
+    from fastertransformer4codefuse_amd.gptneox_op import symmetric_quantize_last_axis_of_batched_matrix_int8 as qf
+    q, s = qf(torch.from_numpy(w_np).half().contiguous())
+    return q, s
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 8, 33, 177])
+@pytest.mark.parametrize("n,k", [(1024, 4096), (2048, 8192)])
+def test_fpA_intB_gemm_matches_reference_formula(m, n, k):
+    # th_gemm_dequantize.py:65-115: weights N(0, 0.002), rtol 1e-3 / atol 2e-3 vs matmul(act, q.to(fp16) * scale)
+    torch.manual_seed(734876213)
+    w = (torch.randn(k, n) * 0.002).half().float().numpy()
+    q, s = quant(w)
+    q_rm, s_o = orc.symmetric_quantize_int8(w, True)
+    act = torch.randn(m, k).half()
+    ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, fp16=True)
+    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    A = act.cuda()
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(q.cuda()), capi.vp(s.cuda()), None, 0, capi.vp(out),
+                                             m, n, k, sp()))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("m", [4, 128])
+def test_identity_activation_dequant_is_bit_exact(m):
+    # th_gemm_dequantize.py:22-40
+    torch.manual_seed(0)
+    k, n = 128, 256
+    w = (torch.randn(k, n) * 0.05).half()
+    q, s = quant(w.float().numpy())
+    q_rm, s_o = orc.symmetric_quantize_int8(w.float().numpy(), True)
+    ref = (torch.from_numpy(q_rm).half() * torch.from_numpy(s_o).half())
+    A = torch.eye(k, dtype=torch.float16)[:m].contiguous().cuda()
+    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(q.cuda()), capi.vp(s.cuda()), None, 0, capi.vp(out),
+                                             m, n, k, sp()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref[:m])
+
+
+@pytest.mark.parametrize("m", [1, 4, 16, 130])
+def test_fpA_intB_gemm_bias_gelu_epilogue(m):
+    torch.manual_seed(1)
+    n, k = 1024, 512
+    w = (torch.randn(k, n) * 0.05).half().float().numpy()
+    q, s = quant(w)
+    q_rm, s_o = orc.symmetric_quantize_int8(w, True)
+    act = torch.randn(m, k).half()
+    bias = torch.randn(n).half()
+    ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, bias=bias.float().numpy(), act=1, fp16=True)
+    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(act.cuda()), capi.vp(q.cuda()), capi.vp(s.cuda()),
+                                             capi.vp(bias.cuda()), 1, capi.vp(out), m, n, k, sp()))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("m", [1, 3, 7, 200])
+def test_fp16_gemm(m):
+    torch.manual_seed(2)
+    n, k = 512, 1024
+    w = (torch.randn(k, n) * 0.03).half()
+    act = torch.randn(m, k).half()
+    bias = torch.randn(n).half()
+    wt = torch.empty((k, n), dtype=torch.float16, device="cuda")
+    capi.check(capi.lib().ftcf_fp16_rowmajor_to_tiled(capi.vp(w.cuda()), C.c_size_t(k), C.c_size_t(n), capi.vp(wt), sp()))
+    for act_kind, b in ((0, None), (1, bias)):
+        ref = orc.gemm(act.float().numpy(), W=w.float().numpy(), bias=None if b is None else b.float().numpy(),
+                       act=act_kind, fp16=True)
+        out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        capi.check(capi.lib().ftcf_fp16_gemm(capi.vp(act.cuda()), capi.vp(wt), capi.vp(None if b is None else b.cuda()),
+                                             act_kind, capi.vp(out), m, n, k, sp()))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("m", [1, 4, 9])
+def test_lm_head(m):
+    torch.manual_seed(3)
+    V, H = 2000, 512
+    W = (torch.randn(V, H) * 0.1).half()
+    x = torch.randn(m, H).half()
+    ref = orc.lm_head(x.float().numpy(), W.float().numpy())
+    out = torch.empty((m, V), dtype=torch.float32, device="cuda")
+    capi.check(capi.lib().ftcf_lm_head(capi.vp(x.cuda()), capi.vp(W.cuda()), capi.vp(out), m, V, H, V, sp()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+
+
+def test_layernorm_and_residual_match_oracle_rounding_points():
+    rng = np.random.RandomState(5)
+    m, n = 7, 5120
+    x = orc.round_half(rng.randn(m, n).astype(np.float32))
+    g = orc.round_half(1 + 0.1 * rng.randn(n).astype(np.float32))
+    b = orc.round_half(0.1 * rng.randn(n).astype(np.float32))
+    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    X, G, Bt = (torch.from_numpy(a).half().cuda() for a in (x, g, b))
+    capi.check(capi.lib().ftcf_layernorm(capi.vp(X), capi.vp(G), capi.vp(Bt), capi.vp(out), m, n, C.c_float(1e-5), 1, sp()))
+    torch.cuda.synchronize()
+    ref = orc.layernorm(x, g, b, fp16=True)
+    got = out.cpu().float().numpy()
+    # identical rounding points; fp32 reduction order may flip half(mean)/half(rstd) by one ulp on rare rows
+    assert np.mean(got != ref) < 0.02
+    np.testing.assert_allclose(got, ref, rtol=4e-3, atol=4e-3)
+    ffn, att = orc.round_half(x * 0.5), orc.round_half(x * 0.25)
+    for inplace in (0, 1):
+        for tp in (1, 2):
+            ref = orc.add_bias_attn_ffn_residual(ffn, att, x, b, tp=tp, inplace_variant=bool(inplace), fp16=True)
+            o2 = torch.empty((m, n), dtype=torch.float16, device="cuda")
+            capi.check(capi.lib().ftcf_add_bias_attn_ffn_residual(
+                capi.vp(o2), capi.vp(torch.from_numpy(ffn).half().cuda()), capi.vp(torch.from_numpy(att).half().cuda()),
+                capi.vp(X), capi.vp(Bt), m, n, tp, inplace, 1, sp()))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(o2.cpu().float().numpy(), ref)  # elementwise: bit exact
+
+
+@pytest.mark.parametrize("dh,nh,rot", [(128, 5, 32), (64, 4, 16)])
+@pytest.mark.parametrize("tl", [0, 1, 31, 100, 700])
+def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl):
+    rng = np.random.RandomState(tl + dh)
+    B, s_max = 3, 1024
+    hl = nh * dh
+    kc = orc.round_half(rng.randn(B, nh, s_max, dh).astype(np.float32))
+    vc = orc.round_half(rng.randn(B, nh, s_max, dh).astype(np.float32))
+    qkv = orc.round_half(rng.randn(B, 3 * hl).astype(np.float32))
+    bias = orc.round_half(0.1 * rng.randn(3 * hl).astype(np.float32))
+    seq_len = np.array([tl, max(tl - 1, 0), tl], dtype=np.int32)
+    pad = np.array([0, 2, 0], dtype=np.int32)
+    masked = np.zeros((B, s_max), dtype=np.uint8)
+    if tl > 8:
+        masked[1, 3:5] = 1
+    finished = np.array([0, 0, 1], dtype=np.uint8)
+    step = tl + 1
+    kc_o, vc_o = kc.copy(), vc.copy()
+    ref = orc.mmha_step(qkv, bias, kc_o, vc_o, seq_len, pad, masked, finished, nh, dh, rot, step, fp16=True)
+    t = lambda a, dt=torch.float16: torch.from_numpy(a).to(dt).cuda()
+    Kc, Vc = t(kc), t(vc)
+    ctx = torch.zeros((B, hl), dtype=torch.float16, device="cuda")
+    wsb = capi.lib().ftcf_masked_multihead_attention_workspace(B, nh, dh, s_max)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    capi.check(capi.lib().ftcf_masked_multihead_attention(
+        capi.vp(t(qkv)), capi.vp(t(bias)), capi.vp(Kc), capi.vp(Vc), capi.vp(t(seq_len, torch.int32)),
+        capi.vp(t(pad, torch.int32)), capi.vp(t(masked, torch.uint8)), capi.vp(t(finished, torch.uint8)), B, nh, dh, rot,
+        s_max, step, capi.vp(ctx), capi.vp(ws), C.c_size_t(wsb), sp()))
+    torch.cuda.synchronize()
+    got = ctx.cpu().float().numpy()
+    np.testing.assert_allclose(got[:2], ref[:2], rtol=1e-2, atol=2e-3)
+    # the new key / value rows were appended to the cache exactly (bias + rotary, half rounding points)
+    for b in range(2):
+        np.testing.assert_allclose(Kc.cpu().float().numpy()[b, :, seq_len[b]], kc_o[b, :, seq_len[b]], rtol=2e-3, atol=2e-3)
+        np.testing.assert_array_equal(Vc.cpu().float().numpy()[b, :, seq_len[b]], vc_o[b, :, seq_len[b]])
+    assert np.all(got[2] == 0)  # finished row untouched
+
+
+@pytest.mark.parametrize("dh,nh,rot", [(128, 3, 32), (64, 4, 16)])
+def test_context_attention_matches_oracle(dh, nh, rot):
+    rng = np.random.RandomState(11)
+    B, S, s_max = 2, 70, 96
+    hl = nh * dh
+    lens = np.array([70, 37], dtype=np.int32)
+    qkv = orc.round_half(rng.randn(B * S, 3 * hl).astype(np.float32))
+    bias = orc.round_half(0.1 * rng.randn(3 * hl).astype(np.float32))
+    kc_o = np.zeros((B, nh, s_max, dh), dtype=np.float32)
+    vc_o = np.zeros_like(kc_o)
+    ref = orc.context_attention(qkv, bias, lens, kc_o, vc_o, B, S, nh, dh, rot, fp16=True)
+    t = lambda a, dt=torch.float16: torch.from_numpy(a).to(dt).cuda()
+    Kc = torch.zeros((B, nh, s_max, dh), dtype=torch.float16, device="cuda")
+    Vc = torch.zeros_like(Kc)
+    ctx = torch.zeros((B * S, hl), dtype=torch.float16, device="cuda")
+    capi.check(capi.lib().ftcf_context_attention(capi.vp(t(qkv)), capi.vp(t(bias)), capi.vp(t(lens, torch.int32)),
+                                                 capi.vp(Kc), capi.vp(Vc), B, S, nh, dh, rot, s_max, capi.vp(ctx), sp()))
+    torch.cuda.synchronize()
+    got = ctx.cpu().float().numpy().reshape(B, S, hl)
+    refr = ref.reshape(B, S, hl)
+    for b in range(B):
+        np.testing.assert_allclose(got[b, :lens[b]], refr[b, :lens[b]], rtol=1e-2, atol=2e-3)
+    np.testing.assert_allclose(Kc.cpu().float().numpy()[:, :, :S], kc_o[:, :, :S], rtol=2e-3, atol=2e-3)
+    np.testing.assert_array_equal(Vc.cpu().float().numpy()[:, :, :S], vc_o[:, :, :S])
+
+
+def test_gemv_and_mfma_paths_agree_at_codefuse_13b_shapes():
+    """Full BASELINE sizes (H=5120, I=20480): the m<=4 VALU GEMV and the m>4 MFMA GEMM read the same tiled image;
+    they must agree with each other and with an fp32 torch reference of the dequantised weights on the device."""
+    torch.manual_seed(7)
+    for (k, n) in ((5120, 15360), (20480, 5120)):
+        w = (torch.randn(k, n, device="cuda") * 0.02).half()
+        q, s = quant(w.cpu().float().numpy())
+        Q, S = q.cuda(), s.cuda()
+        x = torch.randn(1, k, device="cuda").half()
+        o1 = torch.empty((1, n), dtype=torch.float16, device="cuda")
+        capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(x), capi.vp(Q), capi.vp(S), None, 0, capi.vp(o1), 1, n, k, sp()))
+        x8 = x.repeat(8, 1).contiguous()
+        o8 = torch.empty((8, n), dtype=torch.float16, device="cuda")
+        capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(x8), capi.vp(Q), capi.vp(S), None, 0, capi.vp(o8), 8, n, k, sp()))
+        torch.cuda.synchronize()
+        q_rm = torch.empty((k, n), dtype=torch.int8)
+        capi.check(capi.lib().ftcf_int8_tiled_to_rowmajor(capi.vp(q), C.c_size_t(k), C.c_size_t(n), capi.vp(q_rm)))
+        deq = (q_rm.cuda().half() * S).float()
+        ref = (x.float() @ deq)
+        torch.testing.assert_close(o1.float(), ref, rtol=2e-3, atol=3e-3)
+        torch.testing.assert_close(o8[3:4].float(), ref, rtol=2e-3, atol=3e-3)
+        assert torch.equal(o8[0], o8[7])
