@@ -25,6 +25,20 @@ def sp():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_KEEP = []
+
+
+def D(t):
+    """device copy that stays alive (a temporary `.cuda()` would be freed -- and its block reused -- as soon as the
+    ctypes pointer has been taken)"""
+    d = t.cuda() if isinstance(t, torch.Tensor) else torch.from_numpy(t).cuda()
+    _KEEP.append(d)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return d
+
+
 def quant(w_np):
     from fastertransformer4codefuse_amd.gptneox_op import symmetric_quantize_last_axis_of_batched_matrix_int8 as qf
     q, s = qf(torch.from_numpy(w_np).half().contiguous())
@@ -43,7 +57,7 @@ def test_fpA_intB_gemm_matches_reference_formula(m, n, k):
     ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, fp16=True)
     out = torch.empty((m, n), dtype=torch.float16, device="cuda")
     A = act.cuda()
-    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(q.cuda()), capi.vp(s.cuda()), None, 0, capi.vp(out),
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(D(q)), capi.vp(D(s)), None, 0, capi.vp(out),
                                              m, n, k, sp()))
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3)
@@ -60,7 +74,7 @@ def test_identity_activation_dequant_is_bit_exact(m):
     ref = (torch.from_numpy(q_rm).half() * torch.from_numpy(s_o).half())
     A = torch.eye(k, dtype=torch.float16)[:m].contiguous().cuda()
     out = torch.empty((m, n), dtype=torch.float16, device="cuda")
-    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(q.cuda()), capi.vp(s.cuda()), None, 0, capi.vp(out),
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(D(q)), capi.vp(D(s)), None, 0, capi.vp(out),
                                              m, n, k, sp()))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref[:m])
@@ -77,8 +91,8 @@ def test_fpA_intB_gemm_bias_gelu_epilogue(m):
     bias = torch.randn(n).half()
     ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, bias=bias.float().numpy(), act=1, fp16=True)
     out = torch.empty((m, n), dtype=torch.float16, device="cuda")
-    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(act.cuda()), capi.vp(q.cuda()), capi.vp(s.cuda()),
-                                             capi.vp(bias.cuda()), 1, capi.vp(out), m, n, k, sp()))
+    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(D(act)), capi.vp(D(q)), capi.vp(D(s)),
+                                             capi.vp(D(bias)), 1, capi.vp(out), m, n, k, sp()))
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3)
 
@@ -91,12 +105,12 @@ def test_fp16_gemm(m):
     act = torch.randn(m, k).half()
     bias = torch.randn(n).half()
     wt = torch.empty((k, n), dtype=torch.float16, device="cuda")
-    capi.check(capi.lib().ftcf_fp16_rowmajor_to_tiled(capi.vp(w.cuda()), C.c_size_t(k), C.c_size_t(n), capi.vp(wt), sp()))
+    capi.check(capi.lib().ftcf_fp16_rowmajor_to_tiled(capi.vp(D(w)), C.c_size_t(k), C.c_size_t(n), capi.vp(wt), sp()))
     for act_kind, b in ((0, None), (1, bias)):
         ref = orc.gemm(act.float().numpy(), W=w.float().numpy(), bias=None if b is None else b.float().numpy(),
                        act=act_kind, fp16=True)
         out = torch.empty((m, n), dtype=torch.float16, device="cuda")
-        capi.check(capi.lib().ftcf_fp16_gemm(capi.vp(act.cuda()), capi.vp(wt), capi.vp(None if b is None else b.cuda()),
+        capi.check(capi.lib().ftcf_fp16_gemm(capi.vp(D(act)), capi.vp(wt), capi.vp(None if b is None else D(b)),
                                              act_kind, capi.vp(out), m, n, k, sp()))
         torch.cuda.synchronize()
         torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=2e-3, atol=2e-3)
@@ -110,7 +124,7 @@ def test_lm_head(m):
     x = torch.randn(m, H).half()
     ref = orc.lm_head(x.float().numpy(), W.float().numpy())
     out = torch.empty((m, V), dtype=torch.float32, device="cuda")
-    capi.check(capi.lib().ftcf_lm_head(capi.vp(x.cuda()), capi.vp(W.cuda()), capi.vp(out), m, V, H, V, sp()))
+    capi.check(capi.lib().ftcf_lm_head(capi.vp(D(x)), capi.vp(D(W)), capi.vp(out), m, V, H, V, sp()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
 
@@ -136,7 +150,7 @@ def test_layernorm_and_residual_match_oracle_rounding_points():
             ref = orc.add_bias_attn_ffn_residual(ffn, att, x, b, tp=tp, inplace_variant=bool(inplace), fp16=True)
             o2 = torch.empty((m, n), dtype=torch.float16, device="cuda")
             capi.check(capi.lib().ftcf_add_bias_attn_ffn_residual(
-                capi.vp(o2), capi.vp(torch.from_numpy(ffn).half().cuda()), capi.vp(torch.from_numpy(att).half().cuda()),
+                capi.vp(o2), capi.vp(D(torch.from_numpy(ffn).half())), capi.vp(D(torch.from_numpy(att).half())),
                 capi.vp(X), capi.vp(Bt), m, n, tp, inplace, 1, sp()))
             torch.cuda.synchronize()
             np.testing.assert_array_equal(o2.cpu().float().numpy(), ref)  # elementwise: bit exact
@@ -161,7 +175,7 @@ def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl):
     step = tl + 1
     kc_o, vc_o = kc.copy(), vc.copy()
     ref = orc.mmha_step(qkv, bias, kc_o, vc_o, seq_len, pad, masked, finished, nh, dh, rot, step, fp16=True)
-    t = lambda a, dt=torch.float16: torch.from_numpy(a).to(dt).cuda()
+    t = lambda a, dt=torch.float16: D(torch.from_numpy(a).to(dt))
     Kc, Vc = t(kc), t(vc)
     ctx = torch.zeros((B, hl), dtype=torch.float16, device="cuda")
     wsb = capi.lib().ftcf_masked_multihead_attention_workspace(B, nh, dh, s_max)
@@ -191,7 +205,7 @@ def test_context_attention_matches_oracle(dh, nh, rot):
     kc_o = np.zeros((B, nh, s_max, dh), dtype=np.float32)
     vc_o = np.zeros_like(kc_o)
     ref = orc.context_attention(qkv, bias, lens, kc_o, vc_o, B, S, nh, dh, rot, fp16=True)
-    t = lambda a, dt=torch.float16: torch.from_numpy(a).to(dt).cuda()
+    t = lambda a, dt=torch.float16: D(torch.from_numpy(a).to(dt))
     Kc = torch.zeros((B, nh, s_max, dh), dtype=torch.float16, device="cuda")
     Vc = torch.zeros_like(Kc)
     ctx = torch.zeros((B * S, hl), dtype=torch.float16, device="cuda")
