@@ -280,6 +280,8 @@ extern "C" int ftcf_masked_multihead_attention(const void* qkv, const void* qkv_
         p.ws = (float*)workspace;
         p.nsplit = mmha_pick_nsplit(B, nh, s_max);
         FTCF_CHECK_ARG(workspace_bytes >= mmha_workspace_bytes(B, nh, dh, p.nsplit), "MMHA workspace too small");
+        p.counters = mmha_counters(p.ws, B, nh, dh, p.nsplit);
+        FTCF_HIP_CHECK(hipMemsetAsync(p.counters, 0, (size_t)B * nh * sizeof(int), (hipStream_t)stream));
         launch_mmha(p, (hipStream_t)stream);
     });
 }
@@ -553,6 +555,7 @@ struct ftcf_gptneox {
             mp.ctx = ctx;
             mp.ws = mmha_ws;
             mp.nsplit = nsplit;
+            mp.counters = mmha_counters(mmha_ws, B, nhl, dh, nsplit);
             if (B <= 4) {
                 // fused path: [LN1 -> QKV] U [LN2 -> FFN1+bias+gelu] ; MMHA ; [out-proj U FFN2 -> residual]
                 LnGemvParams a{};
@@ -711,6 +714,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
 
     hipEvent_t e0 = get_event(), e1 = get_event();
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
+    FTCF_HIP_CHECK(hipMemsetAsync(mmha_counters(mmha_ws, B, nhl, dh, nsplit), 0, (size_t)B * nhl * sizeof(int), stream));
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
     if (S > 1) {
         launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
@@ -787,16 +791,27 @@ int ftcf_gptneox::step(int max_steps)
             launch_step_embedding(x, wte, step_ids, &state->step, B, H, stream);
             decoder(B, s_max);
         }
-        launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, true, stream);
+        // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
+        const bool fuse_ln = B <= 4;
+        if (!fuse_ln) {
+            launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, true, stream);
+        }
+        auto lm = [&](const f16* Wrows, float* out, int rows, int ld) {
+            if (fuse_ln) {
+                launch_lm_head(x, Wrows, out, B, rows, H, ld, stream, final_g, final_b, 1e-5f);
+            }
+            else {
+                lm_head_dispatch(nrm, Wrows, out, B, rows, H, ld, stream);
+            }
+        };
         if (tp == 1) {
-            timed(KIND_LM_HEAD, 2.0 * V * H, [&] { lm_head_dispatch(nrm, lm_head, logits, B, V, H, V, stream); });
+            timed(KIND_LM_HEAD, 2.0 * V * H, [&] { lm(lm_head, logits, V, V); });
         }
         else {
             // rank r computes rows [r*vl, (r+1)*vl) of the replicated lm_head (GptNeoX.cc:888-925)
             float* mine = gather + (size_t)cfg.tensor_para_rank * B * vl;
-            timed(KIND_LM_HEAD, 2.0 * vl * H, [&] {
-                lm_head_dispatch(nrm, lm_head + (size_t)cfg.tensor_para_rank * vl * H, mine, B, vl, H, vl, stream);
-            });
+            timed(KIND_LM_HEAD, 2.0 * vl * H,
+                  [&] { lm(lm_head + (size_t)cfg.tensor_para_rank * vl * H, mine, vl, vl); });
             FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
             hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, stream, logits, gather, tp, B, vl);
         }

@@ -40,7 +40,9 @@ struct SplitKParams {
 void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s);
 void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves);
 void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStream_t s);
-void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s);
+// optional fused LayerNorm of x (gamma != NULL)
+void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s,
+                    const f16* gamma = nullptr, const f16* beta = nullptr, float eps = 1e-5f);
 
 // ---- MFMA GEMM (prefill / batched decode) : kernels_gemm.hip ----
 // C[m,n] = A[m,k] x W(tiled)  (+bias, gelu) ; int8: fused fp32 epilogue ; fp16: half epilogue
@@ -78,10 +80,12 @@ struct MmhaParams {
     int            step;
     int            B, nh, dh, rot, s_max;
     f16*           ctx;  // [B, Hl]
-    float*         ws;   // split-KV workspace
+    float*         ws;   // split-KV workspace: [B][nh][nsplit][dh+2] partials
+    int*           counters;  // [B][nh] arrival tickets (zero between launches)
     int            nsplit;
 };
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);
+int*   mmha_counters(float* ws, int B, int nh, int dh, int nsplit);
 int    mmha_pick_nsplit(int B, int nh, int s_max);
 void   launch_mmha(const MmhaParams& p, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,

@@ -39,17 +39,11 @@ __device__ __forceinline__ void rotary_pair(f16& a, f16& b, int j, int rot, int 
 }
 
 template<int DH>
-__global__ __launch_bounds__(256) void k_mmha_split(const MmhaParams p)
+__device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, float* wsout, int h, int b, int sp)
 {
     constexpr int LPK = DH / 8;    // lanes per key/value row (16 B each)
     constexpr int KPI = 64 / LPK;  // rows per wave-load
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float*    wsout = p.ws + (((size_t)b * p.nh + h) * p.nsplit + sp) * (DH + 2);
-    if (p.finished && p.finished[b]) {
-        return;  // :1176 (ctx of a finished row is never consumed)
-    }
     const int tl    = p.seq_len[b];  // tlength: number of cached keys; the new token goes to index tl
     const int chunk = (((p.s_max + p.nsplit - 1) / p.nsplit) + 15) & ~15;
     const int t_beg = sp * chunk;
@@ -241,36 +235,95 @@ __global__ __launch_bounds__(256) void k_mmha_split(const MmhaParams p)
     }
 }
 
+// One launch: every split workgroup publishes its (max, sum, out[DH]) partial, takes a ticket, and the LAST arriver
+// of each (row, head) merges the partials in split order (deterministic) -- the in-launch hand-off recipe of
+// cdna_hip_programming.md G16: plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release (+ asm vmcnt(0))
+// -> relaxed agent ticket ; consumer: one-lane agent acquire -> barrier -> plain loads.  Placement independent.
 template<int DH>
-__global__ void k_mmha_combine(const MmhaParams p)
+__global__ __launch_bounds__(256) void k_mmha_split(const MmhaParams p)
 {
-    const int h = blockIdx.x, b = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_last;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
     if (p.finished && p.finished[b]) {
+        return;  // :1176 (ctx of a finished row is never consumed); uniform for all splits of the row
+    }
+    float* wsout = p.ws + (((size_t)b * p.nh + h) * p.nsplit + sp) * (DH + 2);
+    mmha_partial<DH>(p, smem, wsout, h, b, sp);
+    if (p.nsplit == 1) {
+        __syncthreads();
+        if (threadIdx.x < DH) {
+            const float inv = 1.f / (wsout[DH + 1] + 1.e-6f);  // :1632
+            p.ctx[(size_t)b * p.nh * DH + h * DH + threadIdx.x] = (f16)(wsout[threadIdx.x] * inv);
+        }
         return;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* counter = p.counters + (size_t)b * p.nh + h;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last      = (t == p.nsplit - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) {
+        return;
+    }
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
     const float* ws = p.ws + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
-    float        m  = -INFINITY;
-    for (int s = 0; s < p.nsplit; s++) {
-        m = fmaxf(m, ws[s * (DH + 2) + DH]);
-    }
-    const int d = threadIdx.x;
-    float     L = 0.f, o = 0.f;
-    for (int s = 0; s < p.nsplit; s++) {
-        const float ms = ws[s * (DH + 2) + DH];
-        if (ms == -INFINITY) {
-            continue;
+    float*       sw = reinterpret_cast<float*>(smem);  // [nsplit] weights, then [1] denominator
+    if (threadIdx.x < 64) {
+        float ms = -INFINITY, ls = 0.f;
+        // nsplit <= 64 (mmha_pick_nsplit caps at 32)
+        if ((int)threadIdx.x < p.nsplit) {
+            ms = ws[threadIdx.x * (DH + 2) + DH];
+            ls = ws[threadIdx.x * (DH + 2) + DH + 1];
         }
-        const float w = __expf(ms - m);
-        L += w * ws[s * (DH + 2) + DH + 1];
-        o += w * ws[s * (DH + 2) + d];
+        const float m = wave_max(ms);
+        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+        if ((int)threadIdx.x < p.nsplit) {
+            sw[threadIdx.x] = w;
+        }
+        // fixed-order sum over splits
+        float L = 0.f;
+        for (int s2 = 0; s2 < p.nsplit; s2++) {
+            L += __shfl(w * ls, s2, 64);
+        }
+        if (threadIdx.x == 0) {
+            sw[p.nsplit] = L;
+        }
     }
-    const float inv = 1.f / (L + 1.e-6f);  // :1632
-    p.ctx[(size_t)b * p.nh * DH + h * DH + d] = (f16)(o * inv);
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        const int d = threadIdx.x;
+        float     o = 0.f;
+#pragma unroll 4
+        for (int s2 = 0; s2 < p.nsplit; s2++) {
+            o += sw[s2] * ws[s2 * (DH + 2) + d];
+        }
+        const float inv = 1.f / (sw[p.nsplit] + 1.e-6f);  // :1632
+        p.ctx[(size_t)b * p.nh * DH + h * DH + d] = (f16)(o * inv);
+    }
 }
 
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit)
 {
-    return (size_t)B * nh * nsplit * (dh + 2) * sizeof(float);
+    // partials + one arrival counter per (row, head); the counters must be zero before the first launch and are
+    // re-zeroed by the last arriver
+    return (((size_t)B * nh * nsplit * (dh + 2) * sizeof(float) + 255) & ~(size_t)255) + (size_t)B * nh * sizeof(int);
+}
+
+int* mmha_counters(float* ws, int B, int nh, int dh, int nsplit)
+{
+    size_t off = (size_t)B * nh * nsplit * (dh + 2) * sizeof(float);
+    off        = (off + 255) & ~(size_t)255;
+    return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + off);
 }
 
 int mmha_pick_nsplit(int B, int nh, int s_max)
@@ -288,13 +341,12 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
     const int    chunk = (((p.s_max + p.nsplit - 1) / p.nsplit) + 15) & ~15;
     const size_t smem  = (size_t)3 * p.dh * 2 + (8 + 4 * p.dh) * 4 + (size_t)chunk * 4;
     dim3         grid(p.nh, p.B, p.nsplit);
+    FTCF_CHECK_ARG(p.nsplit <= 64 && (p.nsplit == 1 || p.counters != nullptr), "bad split-KV configuration");
     if (p.dh == 128) {
         hipLaunchKernelGGL(k_mmha_split<128>, grid, dim3(256), smem, s, p);
-        hipLaunchKernelGGL(k_mmha_combine<128>, dim3(p.nh, p.B), dim3(128), 0, s, p);
     }
     else {
         hipLaunchKernelGGL(k_mmha_split<64>, grid, dim3(256), smem, s, p);
-        hipLaunchKernelGGL(k_mmha_combine<64>, dim3(p.nh, p.B), dim3(64), 0, s, p);
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }

@@ -65,42 +65,73 @@ __device__ __forceinline__ void consume_tile(const u32x4 w, const f16* xl, const
 
 // Streams `ntiles` consecutive tiles of one column group.  wp: this lane's 16 B of the first tile.
 // xl: LDS pointer to this lane's k offset of the first tile (row 0); rows are xstride halves apart.
+// Two register batches (A/B) of GEMV_U tiles ping-pong WITHOUT register copies, so that the batch being consumed only
+// waits for its own loads (counted vmcnt) while the other batch stays in flight.
+template<bool INT8, int M>
+struct WaveStream {
+    u32x4 A[GEMV_U], B[GEMV_U];
+
+    __device__ __forceinline__ void load(u32x4 (&r)[GEMV_U], const u32x4* __restrict__ wp, int batch)
+    {
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            r[u] = __builtin_nontemporal_load(wp + (size_t)(batch * GEMV_U + u) * 64);
+        }
+    }
+    __device__ __forceinline__ void consume(const u32x4 (&r)[GEMV_U], int batch, const f16* xl, const int xstride,
+                                            const f16x2 scale2, float (&acc)[M])
+    {
+        constexpr int TK = TileK<INT8>::value;
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            consume_tile<INT8, M>(r[u], xl + (batch * GEMV_U + u) * TK, xstride, scale2, acc);
+        }
+    }
+    // issue the first batch early (before a prologue that does not depend on the weights)
+    __device__ __forceinline__ void prime(const u32x4* __restrict__ wp, int ntiles)
+    {
+        if (ntiles >= GEMV_U) {
+            load(A, wp, 0);
+        }
+    }
+    __device__ __forceinline__ void run(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
+                                        const f16x2 scale2, float (&acc)[M])
+    {
+        constexpr int TK = TileK<INT8>::value;
+        const int     nb = ntiles / GEMV_U;
+        int           b  = 0;
+        while (b + 2 <= nb) {
+            // sched_barrier: hipcc's scheduler otherwise sinks each load batch below the preceding consume (to save
+            // registers), which serialises load and compute -- the pipeline must keep one batch in flight
+            load(B, wp, b + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(A, b, xl, xstride, scale2, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // unconditional (clamped) reload keeps the loop body branch free; the last one is a harmless re-read
+            load(A, wp, (b + 2 < nb) ? b + 2 : nb - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B, b + 1, xl, xstride, scale2, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            b += 2;
+        }
+        if (b < nb) {
+            consume(A, b, xl, xstride, scale2, acc);
+            b++;
+        }
+        for (int t = nb * GEMV_U; t < ntiles; t++) {
+            const u32x4 w = __builtin_nontemporal_load(wp + (size_t)t * 64);
+            consume_tile<INT8, M>(w, xl + t * TK, xstride, scale2, acc);
+        }
+    }
+};
+
 template<bool INT8, int M>
 __device__ __forceinline__ void wave_stream(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
                                             const f16x2 scale2, float (&acc)[M])
 {
-    constexpr int TK = TileK<INT8>::value;
-    u32x4         cur[GEMV_U], nxt[GEMV_U];
-    int           t = 0;
-    if (ntiles >= GEMV_U) {
-#pragma unroll
-        for (int u = 0; u < GEMV_U; u++) {
-            cur[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
-        }
-        for (; t + 2 * GEMV_U <= ntiles; t += GEMV_U) {
-#pragma unroll
-            for (int u = 0; u < GEMV_U; u++) {
-                nxt[u] = __builtin_nontemporal_load(wp + (size_t)(t + GEMV_U + u) * 64);
-            }
-#pragma unroll
-            for (int u = 0; u < GEMV_U; u++) {
-                consume_tile<INT8, M>(cur[u], xl + (t + u) * TK, xstride, scale2, acc);
-            }
-#pragma unroll
-            for (int u = 0; u < GEMV_U; u++) {
-                cur[u] = nxt[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < GEMV_U; u++) {
-            consume_tile<INT8, M>(cur[u], xl + (t + u) * TK, xstride, scale2, acc);
-        }
-        t += GEMV_U;
-    }
-    for (; t < ntiles; t++) {
-        const u32x4 w = __builtin_nontemporal_load(wp + (size_t)t * 64);
-        consume_tile<INT8, M>(w, xl + t * TK, xstride, scale2, acc);
-    }
+    WaveStream<INT8, M> ws;
+    ws.prime(wp, ntiles);
+    ws.run(wp, ntiles, xl, xstride, scale2, acc);
 }
 
 // After wave_stream lane (g, c) holds the partial of column c over its k sub-chunks; fold the 4 lane groups.
@@ -132,51 +163,107 @@ __global__ __launch_bounds__(256) void k_ln_gemv(const LnGemvParams p)
     const int grp  = (seg ? ((int)blockIdx.x - p.blocks0) : (int)blockIdx.x) * 4 + wid;  // column group in segment
     const int NT   = seg ? p.NT1 : p.NT0;
     const int K    = p.K;
-
-    // ---- LayerNorm prologue: fp16 half2-path numerics of layernorm_kernels.cu:157-286 ----
-    const f16* gamma = seg ? p.gamma1 : p.gamma0;
-    const f16* beta  = seg ? p.beta1 : p.beta0;
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        const f16* xr = p.x + (size_t)m * K;
-        float      s[2] = {0.f, 0.f};
-        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float f = (float)v[j];
-                s[0] += f;
-                s[1] += f * f;
-            }
-        }
-        block_sum<2>(s, red);
-        const float mean = s[0] / (float)K;
-        const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
-        const f16   mh = (f16)mean, rh = (f16)rstd;
-        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
-            const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + i);
-            const f16x8 b = *reinterpret_cast<const f16x8*>(beta + i);
-            f16x8       o;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                o[j] = (((v[j] - mh) * rh) * g[j]) + b[j];
-            }
-            *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
-        }
-    }
-    __syncthreads();
-    if (grp >= NT) {
-        return;
-    }
-
     constexpr int TK = TileK<INT8>::value;
     const int     KT = K / TK;
     const int     c = lane & 15, g = lane >> 4;
-    const char*   wbase = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
-    const u32x4*  wp    = reinterpret_cast<const u32x4*>(wbase + ((size_t)grp * KT * 64 + lane) * 16);
-    const int     n     = grp * 16 + c;
-    f16x2         scale2 = {(f16)1.0f, (f16)1.0f};
+    const bool    active = grp < NT;
+    const char*   wbase  = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
+    const u32x4*  wp     = reinterpret_cast<const u32x4*>(wbase + ((size_t)(active ? grp : 0) * KT * 64 + lane) * 16);
+
+    const f16* gamma = seg ? p.gamma1 : p.gamma0;
+    const f16* beta  = seg ? p.beta1 : p.beta0;
+    WaveStream<INT8, M> ws;
+    constexpr int XV = 4;  // register-resident LayerNorm for K <= 8192 (single-row decode: the bs=1 hot path)
+    if (M == 1 && K <= 2048 * XV) {
+        // ---- all global loads first: x, gamma, beta (L2 hits), THEN the first weight batch; the LayerNorm math
+        //      below runs while the weights are in flight (counted vmcnt: the x loads are the oldest) ----
+        f16x8 xv[M][XV], gv[XV], bv[XV];
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int  i  = threadIdx.x * 8 + j * 2048;
+            const bool ok = i < K;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                xv[m][j] = ok ? *reinterpret_cast<const f16x8*>(p.x + (size_t)m * K + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            gv[j] = ok ? *reinterpret_cast<const f16x8*>(gamma + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            bv[j] = ok ? *reinterpret_cast<const f16x8*>(beta + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (active) {
+            ws.prime(wp, KT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LayerNorm: fp16 half2-path numerics of layernorm_kernels.cu:157-286 ----
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            float s[2] = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float f = (float)xv[m][j][e];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                const int i = threadIdx.x * 8 + j * 2048;
+                if (i < K) {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        o[e] = (((xv[m][j][e] - mh) * rh) * gv[j][e]) + bv[j][e];
+                    }
+                    *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+                }
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16* xr = p.x + (size_t)m * K;
+            float      s[2] = {0.f, 0.f};
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float f = (float)v[j];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v  = *reinterpret_cast<const f16x8*>(xr + i);
+                const f16x8 gg = *reinterpret_cast<const f16x8*>(gamma + i);
+                const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + i);
+                f16x8       o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
+                }
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+            }
+        }
+        if (active) {
+            ws.prime(wp, KT);
+        }
+    }
+    __syncthreads();
+    if (!active) {
+        return;
+    }
+    const int n      = grp * 16 + c;
+    f16x2     scale2 = {(f16)1.0f, (f16)1.0f};
     if constexpr (INT8) {
         const f16 sc = (seg ? p.scale1 : p.scale0)[n];
         scale2       = f16x2{sc, sc};
@@ -186,7 +273,7 @@ __global__ __launch_bounds__(256) void k_ln_gemv(const LnGemvParams p)
     for (int m = 0; m < M; m++) {
         acc[m] = 0.f;
     }
-    wave_stream<INT8, M>(wp, KT, xs + g * (TK / 4), K, scale2, acc);
+    ws.run(wp, KT, xs + g * (TK / 4), K, scale2, acc);
     fold_groups<M>(acc);
     if (g == 0) {
         f16*      out = seg ? p.out1 : p.out0;
@@ -240,17 +327,47 @@ __global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(cons
     f16*       xs     = reinterpret_cast<f16*>(smem) + (size_t)wid * M * p.slice_halves;
     const f16* xsrc   = seg ? p.x_b : p.x_a;
     const int  nhalf  = nt * TK;
+    const char*  wbase = reinterpret_cast<const char*>(seg ? p.W_b : p.W_a);
+    const u32x4* wp    = reinterpret_cast<const u32x4*>(wbase + (((size_t)grp * KTseg + t0) * 64 + lane) * 16);
+    WaveStream<INT8, M> ws;
+    constexpr int SV = (M == 1) ? 8 : ((M == 2) ? 4 : 2);  // slice vectors per lane held in registers
+    if (nhalf <= 512 * SV) {
+        // x slice loads first (L2 hits), then the first weight batch: the LDS staging overlaps the HBM latency
+        f16x8 xv[M][SV];
 #pragma unroll
-    for (int m = 0; m < M; m++) {
-        for (int i = lane * 8; i < nhalf; i += 64 * 8) {
-            *reinterpret_cast<f16x8*>(xs + (size_t)m * p.slice_halves + i) =
-                *reinterpret_cast<const f16x8*>(xsrc + (size_t)m * Kseg + (size_t)t0 * TK + i);
+        for (int j = 0; j < SV; j++) {
+            const int i = lane * 8 + j * 512;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                xv[m][j] = (i < nhalf) ? *reinterpret_cast<const f16x8*>(xsrc + (size_t)m * Kseg + (size_t)t0 * TK + i) :
+                                         f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
+        ws.prime(wp, nt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < SV; j++) {
+            const int i = lane * 8 + j * 512;
+            if (i < nhalf) {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    *reinterpret_cast<f16x8*>(xs + (size_t)m * p.slice_halves + i) = xv[m][j];
+                }
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            for (int i = lane * 8; i < nhalf; i += 64 * 8) {
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * p.slice_halves + i) =
+                    *reinterpret_cast<const f16x8*>(xsrc + (size_t)m * Kseg + (size_t)t0 * TK + i);
+            }
+        }
+        ws.prime(wp, nt);
     }
     // no barrier needed: the slice is read by the wave that wrote it (LDS ops of one wave are ordered)
 
-    const char*  wbase = reinterpret_cast<const char*>(seg ? p.W_b : p.W_a);
-    const u32x4* wp    = reinterpret_cast<const u32x4*>(wbase + (((size_t)grp * KTseg + t0) * 64 + lane) * 16);
     const int    n     = grp * 16 + c;
     f16x2        scale2 = {(f16)1.0f, (f16)1.0f};
     if constexpr (INT8) {
@@ -262,7 +379,7 @@ __global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(cons
     for (int m = 0; m < M; m++) {
         acc[m] = 0.f;
     }
-    wave_stream<INT8, M>(wp, nt, xs + g * (TK / 4), p.slice_halves, scale2, acc);
+    ws.run(wp, nt, xs + g * (TK / 4), p.slice_halves, scale2, acc);
     fold_groups<M>(acc);
 
     // cross-wave reduction in a fixed order (deterministic)
@@ -333,12 +450,49 @@ __global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(cons
 // ---------------------------------------------------------------------------------------------------------------
 template<int M>
 __global__ __launch_bounds__(256) void k_lm_head(const f16* __restrict__ x, const f16* __restrict__ W,
-                                                 float* __restrict__ logits, int n_rows, int K, int ldc)
+                                                 float* __restrict__ logits, int n_rows, int K, int ldc,
+                                                 const f16* __restrict__ gamma, const f16* __restrict__ beta, float eps)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* xs = reinterpret_cast<f16*>(smem);  // [M][K]
-    for (int i = threadIdx.x * 8; i < M * K; i += 256 * 8) {
-        *reinterpret_cast<f16x8*>(xs + i) = *reinterpret_cast<const f16x8*>(x + i);
+    f16*   xs  = reinterpret_cast<f16*>(smem);  // [M][K]
+    float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2);
+    if (gamma) {
+        // fused final LayerNorm (GptNeoX.cc:854-863 invokeGeneralLayerNorm, half2-path numerics): every block
+        // normalises the tiny [M,K] hidden state itself instead of paying a kernel boundary for it
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16* xr   = x + (size_t)m * K;
+            float      s[2] = {0.f, 0.f};
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float f = (float)v[j];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v  = *reinterpret_cast<const f16x8*>(xr + i);
+                const f16x8 gg = *reinterpret_cast<const f16x8*>(gamma + i);
+                const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + i);
+                f16x8       o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
+                }
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+            }
+        }
+    }
+    else {
+        for (int i = threadIdx.x * 8; i < M * K; i += 256 * 8) {
+            *reinterpret_cast<f16x8*>(xs + i) = *reinterpret_cast<const f16x8*>(x + i);
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -500,21 +654,25 @@ void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStr
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
-void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s)
+void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s,
+                    const f16* gamma, const f16* beta, float eps)
 {
     FTCF_CHECK_ARG(K % 8 == 0, "K must be a multiple of 8");
-    const size_t smem = (size_t)M * K * 2;
+    const size_t smem = (size_t)M * K * 2 + 64;
     int          grid = (n_rows + 15) / 16;
     if (grid > 2048) {
         grid = 2048;
     }
+#define FTCF_LM(MM)                                                                                                    \
+    hipLaunchKernelGGL((k_lm_head<MM>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc, gamma, beta, eps)
     switch (M) {
-        case 1: hipLaunchKernelGGL((k_lm_head<1>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
-        case 2: hipLaunchKernelGGL((k_lm_head<2>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
-        case 3: hipLaunchKernelGGL((k_lm_head<3>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
-        case 4: hipLaunchKernelGGL((k_lm_head<4>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc); break;
+        case 1: FTCF_LM(1); break;
+        case 2: FTCF_LM(2); break;
+        case 3: FTCF_LM(3); break;
+        case 4: FTCF_LM(4); break;
         default: throw Error(-1, "lm_head GEMV supports 1..4 rows");
     }
+#undef FTCF_LM
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
