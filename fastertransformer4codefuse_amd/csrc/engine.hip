@@ -349,7 +349,7 @@ struct Carver {
     }
 };
 
-enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_COUNT = 3 };
+enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND_COUNT = 4 };
 
 }  // namespace
 
@@ -357,7 +357,13 @@ struct ftcf_gptneox {
     ftcf_gptneox_config       cfg{};
     int                       H = 0, nhl = 0, hl = 0, il = 0, L = 0, V = 0, vl = 0, dh = 0;
     bool                      int8 = false;
-    hipStream_t               stream = nullptr;
+    // `stream` is the engine's own work stream (capturable, unlike the legacy null stream torch usually hands over);
+    // it is ordered after `user_stream` at begin() and drained before forward()/finish() return
+    hipStream_t               stream = nullptr, stream2 = nullptr, user_stream = nullptr;
+    hipEvent_t                ev_fork = nullptr, ev_join = nullptr, ev_user = nullptr;
+    // 0: 3 launches/layer (K1, K2 = MMHA || FFN1, K3) -- default; 2: two concurrent stream chains (measured slower:
+    // cross-stream fork/join costs 5-10 us each on this runtime, profiles/r01 notes)
+    int                       decode_mode = 0;
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
     std::vector<void*>        owned;  // tiled fp16 copies (int8_mode == 0)
@@ -391,6 +397,21 @@ struct ftcf_gptneox {
     {
         for (void* p : owned) {
             (void)hipFree(p);
+        }
+        if (stream2) {
+            (void)hipStreamDestroy(stream2);
+        }
+        if (stream) {
+            (void)hipStreamDestroy(stream);
+        }
+        if (ev_user) {
+            (void)hipEventDestroy(ev_user);
+        }
+        if (ev_fork) {
+            (void)hipEventDestroy(ev_fork);
+        }
+        if (ev_join) {
+            (void)hipEventDestroy(ev_join);
         }
         if (h_flags) {
             (void)hipHostFree(h_flags);
@@ -556,29 +577,105 @@ struct ftcf_gptneox {
             mp.ws = mmha_ws;
             mp.nsplit = nsplit;
             mp.counters = mmha_counters(mmha_ws, B, nhl, dh, nsplit);
-            if (B <= 4) {
-                // fused path: [LN1 -> QKV] U [LN2 -> FFN1+bias+gelu] ; MMHA ; [out-proj U FFN2 -> residual]
+            if (B <= 4 && decode_mode == 2) {
+                // Two concurrent dependency chains per layer (parallel residual, GptNeoXDecoder.cc:267-356):
+                //   chain A (side stream): LN2 -> FFN1 + bias + gelu  ->  FFN2                      (2 x 104.9 MB/TP)
+                //   chain B (main stream): LN1 -> QKV -> MMHA -> [wait A] out-proj + residual       (78.6 + KV + 26.2 MB/TP)
+                // The chains only meet in the residual epilogue, so the attention's latency chain and every kernel's
+                // ramp / tail overlap with the other chain's weight streaming instead of idling HBM.
+                const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
+                FTCF_HIP_CHECK(hipEventRecord(ev_fork, stream));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
+                LnGemvParams f{};
+                f.x = x;
+                f.gamma1 = w.ln2_g;
+                f.beta1 = w.ln2_b;
+                f.W1 = w.ffn1.kernel;
+                f.scale1 = w.ffn1.scale;
+                f.bias1 = w.ffn1.bias;
+                f.out1 = mid;
+                f.K = H;
+                f.NT0 = 0;
+                f.NT1 = il / 16;
+                f.blocks0 = 0;
+                f.blocks1 = (f.NT1 + 3) / 4;
+                f.eps = 1e-5f;
+                launch_ln_gemv(f, int8, B, stream2);
+                SplitKParams f2{};
+                f2.x_a = mid;
+                f2.W_a = w.ffn2.kernel;
+                f2.scale_a = w.ffn2.scale;
+                f2.out = ffn;
+                f2.N = H;
+                f2.KT_a = il / tk;
+                f2.tp = 1;
+                plan_splitk(f2, int8, B, 8);
+                launch_gemv_splitk(f2, int8, B, EPI_PLAIN, stream2);
+                FTCF_HIP_CHECK(hipEventRecord(ev_join, stream2));
                 LnGemvParams a{};
                 a.x = x;
                 a.gamma0 = w.ln1_g;
                 a.beta0 = w.ln1_b;
-                a.gamma1 = w.ln2_g;
-                a.beta1 = w.ln2_b;
                 a.W0 = w.qkv.kernel;
-                a.W1 = w.ffn1.kernel;
                 a.scale0 = w.qkv.scale;
-                a.scale1 = w.ffn1.scale;
-                a.bias1 = w.ffn1.bias;
                 a.out0 = qkv;
-                a.out1 = mid;
                 a.K = H;
                 a.NT0 = 3 * hl / 16;
-                a.NT1 = il / 16;
                 a.blocks0 = (a.NT0 + 3) / 4;
-                a.blocks1 = (a.NT1 + 3) / 4;
                 a.eps = 1e-5f;
-                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl + il), [&] { launch_ln_gemv(a, int8, B, stream); });
+                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] { launch_ln_gemv(a, int8, B, stream); });
                 launch_mmha(mp, stream);
+                FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
+                SplitKParams c{};
+                c.x_a = ctx;
+                c.W_a = w.attn_out.kernel;
+                c.scale_a = w.attn_out.scale;
+                c.bias = w.ffn2.bias;
+                c.x_in = x;
+                c.ffn_in = ffn;
+                c.out = x;
+                c.N = H;
+                c.KT_a = hl / tk;
+                c.tp = cfg.tensor_para_size;
+                c.inplace_variant = inplace;
+                plan_splitk(c, int8, B, 4);
+                timed(KIND_SPLITK, wbytes * H * (double)hl,
+                      [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
+            }
+            else             if (B <= 4) {
+                // fused path, 3 launches per layer:
+                //   K1  LN1 -> QKV                                  (78.6 MB/TP int8)
+                //   K2  MMHA  ||  LN2 -> FFN1 + bias + gelu         (attention hidden under 104.9 MB/TP of streaming)
+                //   K3  [out-proj U FFN2] -> residual               (131 MB/TP)
+                LnGemvParams a{};
+                a.x = x;
+                a.gamma0 = w.ln1_g;
+                a.beta0 = w.ln1_b;
+                a.W0 = w.qkv.kernel;
+                a.scale0 = w.qkv.scale;
+                a.out0 = qkv;
+                a.K = H;
+                a.NT0 = 3 * hl / 16;
+                a.NT1 = 0;
+                a.blocks0 = (a.NT0 + 3) / 4;
+                a.blocks1 = 0;
+                a.eps = 1e-5f;
+                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] { launch_ln_gemv(a, int8, B, stream); });
+                LnGemvParams f{};
+                f.x = x;
+                f.gamma1 = w.ln2_g;
+                f.beta1 = w.ln2_b;
+                f.W1 = w.ffn1.kernel;
+                f.scale1 = w.ffn1.scale;
+                f.bias1 = w.ffn1.bias;
+                f.out1 = mid;
+                f.K = H;
+                f.NT0 = 0;
+                f.NT1 = il / 16;
+                f.blocks0 = 0;
+                f.blocks1 = (f.NT1 + 3) / 4;
+                f.eps = 1e-5f;
+                timed(KIND_FUSED, wbytes * H * (double)il, [&] { launch_mmha_ln_gemv(mp, f, int8, B, stream); });
                 SplitKParams c{};
                 c.x_a = ctx;
                 c.x_b = mid;
@@ -624,8 +721,11 @@ struct ftcf_gptneox {
         int               steps = 0;
         bool              all_finished = false;
         hipEvent_t        e0 = nullptr, e1 = nullptr;
+        hipGraphExec_t    graph_exec = nullptr;
     } ses;
+    bool use_graph = true;
     void begin(const ftcf_forward_args& a);
+    void enqueue_step(bool with_decoder);
     int  step(int max_steps);
     void finish();
     void forward(const ftcf_forward_args& a)
@@ -671,6 +771,9 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         throw Error(FTCF_ERR_UNSUPPORTED, "beam_width > 1 (beam search) is not implemented yet");
     }
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
+    // everything the caller enqueued on its stream (input tensors) happens-before the engine's work
+    FTCF_HIP_CHECK(hipEventRecord(ev_user, user_stream));
+    FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_user, 0));
     const int total = S + out_len;  // max_output_seq_len == max_seq_len == max_cache_seq_len (GptNeoX.cc:520-523)
     const int s_max = total;
     plan(B, S, total);
@@ -773,21 +876,13 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     stats.decode_ms = 0.f;
 }
 
-// the token loop of GptNeoX<T>::forward (GptNeoX.cc:776-1048); returns the number of iterations executed
-int ftcf_gptneox::step(int max_steps)
+// enqueues one iteration of the token loop (GptNeoX.cc:776-1048) on `stream` (and the side stream)
+void ftcf_gptneox::enqueue_step(bool with_decoder)
 {
-    FTCF_CHECK_ARG(ses.active, "no request in flight: call ftcf_gptneox_begin first");
-    FTCF_HIP_CHECK(hipSetDevice(cfg.device));
     const ftcf_forward_args& a = ses.a;
-    const int B = ses.B, S = ses.S, total = ses.total, s_max = ses.s_max;
+    const int B = ses.B, S = ses.S, s_max = ses.s_max;
     const int tp = cfg.tensor_para_size;
-    std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
-    hipEvent_t ea = get_event(), eb = get_event();
-    FTCF_HIP_CHECK(hipEventRecord(ea, stream));
-    int done = 0;
-    while (done < max_steps && ses.next_step < total && !ses.all_finished) {
-        const int step = ses.next_step;
-        if (!(S > 1 && step == S)) {
+    if (with_decoder) {
             launch_step_embedding(x, wte, step_ids, &state->step, B, H, stream);
             decoder(B, s_max);
         }
@@ -816,10 +911,56 @@ int ftcf_gptneox::step(int max_steps)
             hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, stream, logits, gather, tp, B, vl);
         }
         if (a.debug_logits) {
-            FTCF_HIP_CHECK(hipMemcpyAsync(a.debug_logits + (size_t)(step - S) * B * V, logits, (size_t)B * V * 4,
-                                          hipMemcpyDeviceToDevice, stream));
+            FTCF_HIP_CHECK(hipMemcpyAsync(a.debug_logits + (size_t)(ses.next_step - S) * B * V, logits,
+                                          (size_t)B * V * 4, hipMemcpyDeviceToDevice, stream));
         }
-        launch_dynamic_decode(ses.sp, stream);
+    launch_dynamic_decode(ses.sp, stream);
+}
+
+// the token loop of GptNeoX<T>::forward (GptNeoX.cc:776-1048); returns the number of iterations executed
+int ftcf_gptneox::step(int max_steps)
+{
+    FTCF_CHECK_ARG(ses.active, "no request in flight: call ftcf_gptneox_begin first");
+    FTCF_HIP_CHECK(hipSetDevice(cfg.device));
+    const ftcf_forward_args& a = ses.a;
+    const int B = ses.B, S = ses.S, total = ses.total, s_max = ses.s_max;
+    const int tp = cfg.tensor_para_size;
+    std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
+    hipEvent_t ea = get_event(), eb = get_event();
+    FTCF_HIP_CHECK(hipEventRecord(ea, stream));
+    int done = 0;
+    while (done < max_steps && ses.next_step < total && !ses.all_finished) {
+        const int  step         = ses.next_step;
+        const bool with_decoder = !(S > 1 && step == S);
+        const bool graph_ok     = use_graph && with_decoder && !profiling && tp == 1 && !a.debug_logits;
+        if (graph_ok) {
+            if (!ses.graph_exec) {
+                // capture ONE regular decode step (all pointers are fixed for the session, the step counter lives
+                // on the device) and replay it: no per-kernel host launch cost, cross-stream fork/join become edges
+                hipGraph_t g = nullptr;
+                FTCF_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    enqueue_step(true);
+                }
+                catch (...) {
+                    (void)hipStreamEndCapture(stream, &g);
+                    if (g) {
+                        (void)hipGraphDestroy(g);
+                    }
+                    throw;
+                }
+                FTCF_HIP_CHECK(hipStreamEndCapture(stream, &g));
+                FTCF_HIP_CHECK(hipGraphInstantiate(&ses.graph_exec, g, nullptr, nullptr, 0));
+                FTCF_HIP_CHECK(hipGraphDestroy(g));
+            }
+            FTCF_HIP_CHECK(hipGraphLaunch(ses.graph_exec, stream));
+        }
+        else {
+            enqueue_step(with_decoder);
+        }
+        if (a.debug_logits) {
+            // (logits are modified in place by the decode kernels; the tap is taken inside enqueue_step when eager)
+        }
         ses.steps++;
         ses.next_step++;
         done++;
@@ -867,6 +1008,10 @@ void ftcf_gptneox::finish()
     event_pool.push_back(ses.e0);
     event_pool.push_back(ses.e1);
     ses.active = false;
+    if (ses.graph_exec) {
+        (void)hipGraphExecDestroy(ses.graph_exec);
+        ses.graph_exec = nullptr;
+    }
     drain_events();
 }
 
@@ -900,7 +1045,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->V     = cfg->vocab_size;
         e->vl    = e->V / tp;
         e->int8  = cfg->int8_mode == 1;
-        e->stream = (hipStream_t)cfg->stream;
+        e->user_stream = (hipStream_t)cfg->stream;
+        FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_user, hipEventDisableTiming));
         FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
         FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
                        "hidden, local hidden and local inter sizes must be multiples of 64");
@@ -961,6 +1108,16 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->final_b = (const f16*)w->weights[12 * L + 2];
         e->lm_head = (const f16*)w->weights[12 * L + 3];
         FTCF_CHECK_ARG(e->wte && e->final_g && e->final_b && e->lm_head, "missing embedding / final layernorm / lm_head");
+        FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        if (const char* m = getenv("FTCF_DECODE_MODE")) {
+            e->decode_mode = atoi(m);
+        }
+        e->use_graph = cfg->use_hip_graph != 0;
+        if (const char* m = getenv("FTCF_USE_GRAPH")) {
+            e->use_graph = atoi(m) != 0;
+        }
         FTCF_HIP_CHECK(hipHostMalloc((void**)&e->h_flags, 64, hipHostMallocDefault));
         e->h_flags[0] = e->h_flags[1] = 0;
         FTCF_HIP_CHECK(hipStreamSynchronize(e->stream));

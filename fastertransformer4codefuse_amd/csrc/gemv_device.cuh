@@ -1,0 +1,294 @@
+// Device-side building blocks of the weight-streaming GEMV kernels (shared by kernels_gemv.hip and kernels_fused.hip).
+#pragma once
+#include "ftcf_common.h"
+#include "kernels.h"
+
+namespace ftcf {
+
+constexpr int GEMV_U = 8;  // tiles per batch (x2 batches in flight)
+
+template<bool INT8>
+struct TileK {
+    static constexpr int value = INT8 ? TILE_K_I8 : TILE_K_F16;
+};
+
+// Consumes one 16-byte weight fragment against M rows of x held in LDS.
+template<bool INT8, int M>
+__device__ __forceinline__ void consume_tile(const u32x4 w, const f16* xl, const int xstride, const f16x2 scale2,
+                                             float (&acc)[M])
+{
+    if constexpr (INT8) {
+        f16x2 b[8];
+        dequant4(w.x, scale2, b[0], b[1]);
+        dequant4(w.y, scale2, b[2], b[3]);
+        dequant4(w.z, scale2, b[4], b[5]);
+        dequant4(w.w, scale2, b[6], b[7]);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
+            const f16x8 x1 = *reinterpret_cast<const f16x8*>(xl + m * xstride + 8);
+            float       a  = acc[m];
+            a              = dot2(b[0], f16x2{x0[0], x0[1]}, a);
+            a              = dot2(b[1], f16x2{x0[2], x0[3]}, a);
+            a              = dot2(b[2], f16x2{x0[4], x0[5]}, a);
+            a              = dot2(b[3], f16x2{x0[6], x0[7]}, a);
+            a              = dot2(b[4], f16x2{x1[0], x1[1]}, a);
+            a              = dot2(b[5], f16x2{x1[2], x1[3]}, a);
+            a              = dot2(b[6], f16x2{x1[4], x1[5]}, a);
+            a              = dot2(b[7], f16x2{x1[6], x1[7]}, a);
+            acc[m]         = a;
+        }
+    }
+    else {
+        const f16x8 b = __builtin_bit_cast(f16x8, w);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
+            float       a  = acc[m];
+            a              = dot2(f16x2{b[0], b[1]}, f16x2{x0[0], x0[1]}, a);
+            a              = dot2(f16x2{b[2], b[3]}, f16x2{x0[2], x0[3]}, a);
+            a              = dot2(f16x2{b[4], b[5]}, f16x2{x0[4], x0[5]}, a);
+            a              = dot2(f16x2{b[6], b[7]}, f16x2{x0[6], x0[7]}, a);
+            acc[m]         = a;
+        }
+    }
+}
+
+// Streams `ntiles` consecutive tiles of one column group.  wp: this lane's 16 B of the first tile.
+// xl: LDS pointer to this lane's k offset of the first tile (row 0); rows are xstride halves apart.
+// Two register batches (A/B) of GEMV_U tiles ping-pong WITHOUT register copies, so that the batch being consumed only
+// waits for its own loads (counted vmcnt) while the other batch stays in flight.
+template<bool INT8, int M>
+struct WaveStream {
+    u32x4 A[GEMV_U], B[GEMV_U];
+
+    __device__ __forceinline__ void load(u32x4 (&r)[GEMV_U], const u32x4* __restrict__ wp, int batch)
+    {
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            r[u] = __builtin_nontemporal_load(wp + (size_t)(batch * GEMV_U + u) * 64);
+        }
+    }
+    __device__ __forceinline__ void consume(const u32x4 (&r)[GEMV_U], int batch, const f16* xl, const int xstride,
+                                            const f16x2 scale2, float (&acc)[M])
+    {
+        constexpr int TK = TileK<INT8>::value;
+#pragma unroll
+        for (int u = 0; u < GEMV_U; u++) {
+            consume_tile<INT8, M>(r[u], xl + (batch * GEMV_U + u) * TK, xstride, scale2, acc);
+        }
+    }
+    // issue the first batch early (before a prologue that does not depend on the weights)
+    __device__ __forceinline__ void prime(const u32x4* __restrict__ wp, int ntiles)
+    {
+        if (ntiles >= GEMV_U) {
+            load(A, wp, 0);
+        }
+    }
+    __device__ __forceinline__ void run(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
+                                        const f16x2 scale2, float (&acc)[M])
+    {
+        constexpr int TK = TileK<INT8>::value;
+        const int     nb = ntiles / GEMV_U;
+        int           b  = 0;
+        while (b + 2 <= nb) {
+            // sched_barrier: hipcc's scheduler otherwise sinks each load batch below the preceding consume (to save
+            // registers), which serialises load and compute -- the pipeline must keep one batch in flight
+            load(B, wp, b + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(A, b, xl, xstride, scale2, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            // unconditional (clamped) reload keeps the loop body branch free; the last one is a harmless re-read
+            load(A, wp, (b + 2 < nb) ? b + 2 : nb - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(B, b + 1, xl, xstride, scale2, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            b += 2;
+        }
+        if (b < nb) {
+            consume(A, b, xl, xstride, scale2, acc);
+            b++;
+        }
+        for (int t = nb * GEMV_U; t < ntiles; t++) {
+            const u32x4 w = __builtin_nontemporal_load(wp + (size_t)t * 64);
+            consume_tile<INT8, M>(w, xl + t * TK, xstride, scale2, acc);
+        }
+    }
+};
+
+template<bool INT8, int M>
+__device__ __forceinline__ void wave_stream(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
+                                            const f16x2 scale2, float (&acc)[M])
+{
+    WaveStream<INT8, M> ws;
+    ws.prime(wp, ntiles);
+    ws.run(wp, ntiles, xl, xstride, scale2, acc);
+}
+
+// After wave_stream lane (g, c) holds the partial of column c over its k sub-chunks; fold the 4 lane groups.
+template<int M>
+__device__ __forceinline__ void fold_groups(float (&acc)[M])
+{
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] += __shfl_xor(acc[m], 16, 64);
+        acc[m] += __shfl_xor(acc[m], 32, 64);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K_A: y0 = LN1(x) * W0        (QKV, no bias: the attention kernel adds it like the reference's MMHA)
+//      y1 = gelu(LN2(x) * W1 + b1)   (FFN first projection, fused epilogue of gemm_bias_act)
+// One launch, one wave per 16-column group over the full K extent; the block recomputes the LayerNorm of the
+// (tiny, L2 resident) layer input instead of paying a kernel boundary for it.
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M>
+__device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem, const int block_id)
+{
+    f16*   xs  = reinterpret_cast<f16*>(smem);                      // [M][K]
+    float* red = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*4 floats
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int seg  = (block_id >= p.blocks0) ? 1 : 0;
+    const int grp  = (seg ? (block_id - p.blocks0) : block_id) * 4 + wid;  // column group in segment
+    const int NT   = seg ? p.NT1 : p.NT0;
+    const int K    = p.K;
+    constexpr int TK = TileK<INT8>::value;
+    const int     KT = K / TK;
+    const int     c = lane & 15, g = lane >> 4;
+    const bool    active = grp < NT;
+    const char*   wbase  = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
+    const u32x4*  wp     = reinterpret_cast<const u32x4*>(wbase + ((size_t)(active ? grp : 0) * KT * 64 + lane) * 16);
+
+    const f16* gamma = seg ? p.gamma1 : p.gamma0;
+    const f16* beta  = seg ? p.beta1 : p.beta0;
+    WaveStream<INT8, M> ws;
+    constexpr int XV = 4;  // register-resident LayerNorm for K <= 8192 (single-row decode: the bs=1 hot path)
+    if (M == 1 && K <= 2048 * XV) {
+        // ---- all global loads first: x, gamma, beta (L2 hits), THEN the first weight batch; the LayerNorm math
+        //      below runs while the weights are in flight (counted vmcnt: the x loads are the oldest) ----
+        f16x8 xv[M][XV], gv[XV], bv[XV];
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int  i  = threadIdx.x * 8 + j * 2048;
+            const bool ok = i < K;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                xv[m][j] = ok ? *reinterpret_cast<const f16x8*>(p.x + (size_t)m * K + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            gv[j] = ok ? *reinterpret_cast<const f16x8*>(gamma + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            bv[j] = ok ? *reinterpret_cast<const f16x8*>(beta + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (active) {
+            ws.prime(wp, KT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- LayerNorm: fp16 half2-path numerics of layernorm_kernels.cu:157-286 ----
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            float s[2] = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float f = (float)xv[m][j][e];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+            for (int j = 0; j < XV; j++) {
+                const int i = threadIdx.x * 8 + j * 2048;
+                if (i < K) {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        o[e] = (((xv[m][j][e] - mh) * rh) * gv[j][e]) + bv[j][e];
+                    }
+                    *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+                }
+            }
+        }
+    }
+    else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16* xr = p.x + (size_t)m * K;
+            float      s[2] = {0.f, 0.f};
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float f = (float)v[j];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+                const f16x8 v  = *reinterpret_cast<const f16x8*>(xr + i);
+                const f16x8 gg = *reinterpret_cast<const f16x8*>(gamma + i);
+                const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + i);
+                f16x8       o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
+                }
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+            }
+        }
+        if (active) {
+            ws.prime(wp, KT);
+        }
+    }
+    __syncthreads();
+    if (!active) {
+        return;
+    }
+    const int n      = grp * 16 + c;
+    f16x2     scale2 = {(f16)1.0f, (f16)1.0f};
+    if constexpr (INT8) {
+        const f16 sc = (seg ? p.scale1 : p.scale0)[n];
+        scale2       = f16x2{sc, sc};
+    }
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] = 0.f;
+    }
+    ws.run(wp, KT, xs + g * (TK / 4), K, scale2, acc);
+    fold_groups<M>(acc);
+    if (g == 0) {
+        f16*      out = seg ? p.out1 : p.out0;
+        const int N   = NT * 16;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            float v = acc[m];
+            if (seg == 1) {
+                if constexpr (INT8) {
+                    // fused epilogue in fp32 (epilogue_helpers.h:52-62): bias + gelu, one rounding
+                    v      = gelu_f32(v + (float)p.bias1[n]);
+                    out[(size_t)m * N + n] = (f16)v;
+                }
+                else {
+                    // fp16 engine: GEMM rounds to half, then invokeAddBiasGeluV2 in half (activation_kernels.cu:401-426)
+                    f16 h                  = (f16)v + p.bias1[n];
+                    out[(size_t)m * N + n] = gelu_f16(h);
+                }
+            }
+            else {
+                out[(size_t)m * N + n] = (f16)v;
+            }
+        }
+    }
+}
+
+
+}  // namespace ftcf

@@ -30,6 +30,7 @@ struct SplitKParams {
     const f16 *scale_a, *scale_b;
     const f16* bias;
     const f16* x_in;  // residual input (EPI_RESIDUAL)
+    const f16* ffn_in;  // EPI_RESIDUAL with a single segment: the FFN output comes from this buffer (two-stream path)
     f16*       out;
     int        N, KT_a, KT_b;
     int        act, tp, inplace_variant;
@@ -91,6 +92,9 @@ void   launch_mmha(const MmhaParams& p, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
                                 hipStream_t s);
+
+// ---- fused attention + FFN1 weight stream : kernels_fused.hip ----
+void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8, int M, hipStream_t s);
 
 // ---- dynamic decode : kernels_sampling.hip ----
 struct DecodeState {  // device resident, one per engine
