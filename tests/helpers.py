@@ -79,3 +79,33 @@ def random_model(cfg, seed=0, std=0.05, fp16=True, tp=1, rank=0):
     w = [a for g in groups for a in g]
     w += [r(V, H, s=0.3), r(H, s=0.05, mean=1.0), r(H, s=0.05), r(V, H, s=0.3)]
     return w
+
+
+def shard_weights(cfg, w, tp, rank):
+    """Tensor-parallel shard of a reference-order weight list, as the reference's converter + loader produce it
+    (huggingface_convert.py:35-81: QKV/FFN1 columns, out-proj/FFN2 rows, row-split GEMM biases divided by TP)."""
+    L = cfg["num_layer"]
+    nh, dh = cfg["head_num"], cfg["size_per_head"]
+    H, I = nh * dh, cfg["inter_size"]
+    hl, il = H // tp, I // tp
+    out = []
+    for g in range(12):
+        for l in range(L):
+            a = w[g * L + l]
+            if g == 2:
+                a = a.reshape(H, 3, H)[:, :, rank * hl:(rank + 1) * hl].reshape(H, 3 * hl)
+            elif g == 3:
+                a = a.reshape(3, H)[:, rank * hl:(rank + 1) * hl].reshape(3 * hl)
+            elif g == 4:
+                a = a.reshape(H, H)[rank * hl:(rank + 1) * hl, :]
+            elif g == 6:
+                a = a.reshape(H, I)[:, rank * il:(rank + 1) * il]
+            elif g == 7:
+                a = a.reshape(I)[rank * il:(rank + 1) * il]
+            elif g == 8:
+                a = a.reshape(I, H)[rank * il:(rank + 1) * il, :]
+            elif g == 9:
+                a = a / tp
+            out.append(np.ascontiguousarray(a, dtype=np.float32))
+    out += [w[12 * L], w[12 * L + 1], w[12 * L + 2], w[12 * L + 3]]
+    return out
