@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libftcf.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("FTCF_LIB_NAME", "libftcf.so"))  # env: kernel-variant experiments
 
 UNIQUE_ID_BYTES = 128
 FP32, FP16 = 0, 1

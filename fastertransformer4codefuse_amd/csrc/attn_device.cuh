@@ -15,109 +15,153 @@ __device__ __forceinline__ float group_sum(float v, int lanes_per_key)
 
 // rotary coefficient exactly as the reference computes it (decoder_masked_multihead_attention_utils.h:1325-1329):
 // inv_freq = t / 10000^(2j/rot) ; {cos, sin}(inv_freq) in fp32
-__device__ __forceinline__ void rotary_pair(f16& a, f16& b, int j, int rot, int pos)
+__device__ __forceinline__ void rotary_coef(int j, int rot, int pos, float& cs, float& sn)
 {
     const float inv_freq = (float)pos / powf(10000.0f, (float)(2 * j) / (float)rot);
-    const float cs = cosf(inv_freq), sn = sinf(inv_freq);
+    cs = cosf(inv_freq);
+    sn = sinf(inv_freq);
+}
+__device__ __forceinline__ void rotary_apply(f16& a, f16& b, const float cs, const float sn)
+{
     const float fa = (float)a, fb = (float)b;
     a = (f16)(cs * fa - sn * fb);
     b = (f16)(cs * fb + sn * fa);
 }
-
-// write-through (sc1) store / L1-bypassing load at agent scope: the partials are handed to another workgroup inside
-// the launch, so they must not linger in this CU's L1 / this XCD's L2 write-back state (MI355X_MICROARCH.md,
-// "Workgroup dispatch, XCD placement & inter-workgroup visibility": `sc1` stores + `sc1` loads on both sides).
-__device__ __forceinline__ void st_agent(float* p, float v)
+__device__ __forceinline__ void rotary_pair(f16& a, f16& b, int j, int rot, int pos)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float cs, sn;
+    rotary_coef(j, rot, pos, cs, sn);
+    rotary_apply(a, b, cs, sn);
 }
 
+// In-launch hand-off of the split-KV partials uses 8-byte {tag, value} GRANULES written with ONE relaxed agent-scope
+// (sc1, write-through) store each and polled with relaxed agent-scope loads: the data is its own flag, so there is no
+// drain / ticket / fence round trip on the latency chain (cdna_hip_programming.md G16 recipe R2, MI355X_MICROARCH.md
+// row "handoff-1to1").  tag = f(step, layer) + 1 is unique per launch; the slab is zeroed when a request begins.
+typedef unsigned long long u64;
+__device__ __forceinline__ void st_granule(u64* g, unsigned tag, float v)
+{
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_granule(const u64* g)
+{
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int MMHA_MAX_SPLIT = 16;
+constexpr int MMHA_SPIN_LIMIT = 1 << 22;  // bounded: a protocol bug must not hang the GPU
+
+// Split `sp` of (row b, head h): computes the un-normalised partial (max, sum, out[DH]) over its key range and
+// publishes it as granules.  Latency chain: ONE round trip for {finished, seq_len, step, q, bias, K rows, V rows}
+// (the K/V rows of the whole fixed chunk are requested before tlength is known and masked afterwards), then math.
 template<int DH>
-__device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, float* wsout, int h, int b, int sp)
+__device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u64* gout, const unsigned tag, int h,
+                                             int b, int sp)
 {
     constexpr int LPK = DH / 8;    // lanes per key/value row (16 B each)
     constexpr int KPI = 64 / LPK;  // rows per wave-load
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int tl    = p.seq_len[b];  // tlength: number of cached keys; the new token goes to index tl
+    const int sub = lane % LPK, grp = lane / LPK;
     const int chunk = (((p.s_max + p.nsplit - 1) / p.nsplit) + 15) & ~15;
     const int t_beg = sp * chunk;
-    int       t_end = t_beg + chunk;  // exclusive, over positions 0..tl (tl = current token)
-    if (t_end > tl + 1) {
-        t_end = tl + 1;
-    }
-    if (t_beg > tl) {  // empty split
-        if (threadIdx.x == 0) {
-            st_agent(&wsout[DH], -INFINITY);
-            st_agent(&wsout[DH + 1], 0.f);
-        }
-        if (threadIdx.x < DH) {
-            st_agent(&wsout[threadIdx.x], 0.f);
-        }
-        return;
-    }
-    const bool owns_cur = (tl >= t_beg && tl < t_end);
-    const int  sub = lane % LPK, grp = lane / LPK;
-    const int  t_cached_end = owns_cur ? tl : t_end;  // cached keys of this split: [t_beg, t_cached_end)
     const f16* kc = p.k_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
     const f16* vc = p.v_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
-    // Latency chain: when the split's keys fit in registers (<= 4 waves x KPI x UK rows) the K AND V rows are requested
-    // up front, before the q/bias/rotary prologue -- one HBM round trip instead of two dependent ones.
     constexpr int UK   = 8;
-    const bool    fast = (chunk <= 4 * KPI * UK) && (t_cached_end > t_beg);
+    const bool    fast = (chunk <= 4 * KPI * UK);
     u32x4         kreg[UK], vreg[UK];
     if (fast) {
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * 4 * KPI + wid * KPI + grp;
-            t       = t < t_cached_end ? t : t_cached_end - 1;
+            t       = t < p.s_max ? t : p.s_max - 1;  // always inside the cache; rows >= tlength are masked below
             kreg[u] = *reinterpret_cast<const u32x4*>(kc + (size_t)t * DH + sub * 8);
         }
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * 4 * KPI + wid * KPI + grp;
-            t       = t < t_cached_end ? t : t_cached_end - 1;
+            t       = t < p.s_max ? t : p.s_max - 1;
             vreg[u] = *reinterpret_cast<const u32x4*>(vc + (size_t)t * DH + sub * 8);
         }
     }
+    const int  hl = p.nh * DH;
+    f16        q_in = (f16)0.f, k_in = (f16)0.f, v_in = (f16)0.f;
+    if (threadIdx.x < DH) {
+        const int    d    = threadIdx.x;
+        const size_t base = (size_t)b * 3 * hl + h * DH + d;
+        q_in = p.qkv[base] + (p.qkv_bias ? p.qkv_bias[h * DH + d] : (f16)0.f);
+        k_in = p.qkv[base + hl] + (p.qkv_bias ? p.qkv_bias[hl + h * DH + d] : (f16)0.f);
+        v_in = p.qkv[base + 2 * hl] + (p.qkv_bias ? p.qkv_bias[2 * hl + h * DH + d] : (f16)0.f);
+    }
+    float rot_cs = 1.f, rot_sn = 0.f;
+    if (p.rot_table && threadIdx.x < p.rot / 2) {
+        rot_cs = p.rot_table[((size_t)b * (p.rot / 2) + threadIdx.x) * 2];
+        rot_sn = p.rot_table[((size_t)b * (p.rot / 2) + threadIdx.x) * 2 + 1];
+    }
+    // padding mask of the rows this lane scores, fetched with the same round trip (not inside the qk loop)
+    unsigned mask_bits = 0u;
+    if (fast && p.masked_tokens && sub == 0) {
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+            int t = t_beg + u * 4 * KPI + wid * KPI + grp;
+            t     = t < p.s_max ? t : p.s_max - 1;
+            mask_bits |= (p.masked_tokens[(size_t)b * p.s_max + t] ? 1u : 0u) << u;
+        }
+    }
+    const bool fin  = p.finished && p.finished[b];
+    const int  tl   = p.seq_len[b];  // tlength: number of cached keys; the new token goes to index tl
+    const int  step = p.d_step ? *p.d_step : p.step;
+    const int  pos  = (step - 1) - (p.pad_count ? p.pad_count[b] : 0);  // :1303,:1343-1344
+    __builtin_amdgcn_sched_barrier(0);
+    if (fin) {
+        return false;  // :1176 (ctx of a finished row is never consumed); uniform for all splits of the row
+    }
+    int t_end = t_beg + chunk;  // exclusive, over positions 0..tl (tl = current token)
+    if (t_end > tl + 1) {
+        t_end = tl + 1;
+    }
+    if (t_beg > tl) {  // empty split
+        if (threadIdx.x < DH) {
+            st_granule(&gout[threadIdx.x], tag, 0.f);
+        }
+        if (threadIdx.x == 0) {
+            st_granule(&gout[DH], tag, -INFINITY);
+            st_granule(&gout[DH + 1], tag, 0.f);
+        }
+        return true;
+    }
+    const bool owns_cur     = (tl >= t_beg && tl < t_end);
+    const int  t_cached_end = owns_cur ? tl : t_end;  // cached keys of this split: [t_beg, t_cached_end)
 
     f16*   s_q    = reinterpret_cast<f16*>(smem);       // [DH]
     f16*   s_k    = s_q + DH;                            // [DH] new key
     f16*   s_v    = s_k + DH;                            // [DH] new value
     float* s_red  = reinterpret_cast<float*>(s_v + DH);  // [8 + 4*DH]
     float* s_p    = s_red + 8 + 4 * DH;                  // [chunk]
-
-    const int hl   = p.nh * DH;
-    const int step = p.d_step ? *p.d_step : p.step;
-    const int pos  = (step - 1) - (p.pad_count ? p.pad_count[b] : 0);  // :1303,:1343-1344
-    // ---- q (+bias, rotary); new k/v for the split that owns the current position ----
     if (threadIdx.x < DH) {
-        const int    d    = threadIdx.x;
-        const size_t base = (size_t)b * 3 * hl + h * DH + d;
-        const f16    bq   = p.qkv_bias ? p.qkv_bias[h * DH + d] : (f16)0.f;
-        s_q[d]            = p.qkv[base] + bq;
-        if (owns_cur) {
-            const f16 bk = p.qkv_bias ? p.qkv_bias[hl + h * DH + d] : (f16)0.f;
-            const f16 bv = p.qkv_bias ? p.qkv_bias[2 * hl + h * DH + d] : (f16)0.f;
-            s_k[d]       = p.qkv[base + hl] + bk;
-            s_v[d]       = p.qkv[base + 2 * hl] + bv;
-        }
+        s_q[threadIdx.x] = q_in;
+        s_k[threadIdx.x] = k_in;
+        s_v[threadIdx.x] = v_in;
     }
     __syncthreads();
     if (p.rot > 0 && threadIdx.x < p.rot / 2) {
         const int j = threadIdx.x;
-        f16       a = s_q[j], c = s_q[j + p.rot / 2];
-        rotary_pair(a, c, j, p.rot, pos);
+        float     cs, sn;
+        if (p.rot_table) {  // {cos, sin} of this step's position, computed once per token (k_rotary_table)
+            cs = rot_cs;
+            sn = rot_sn;
+        }
+        else {
+            rotary_coef(j, p.rot, pos, cs, sn);
+        }
+        f16 a = s_q[j], c = s_q[j + p.rot / 2];
+        rotary_apply(a, c, cs, sn);
         s_q[j]             = a;
         s_q[j + p.rot / 2] = c;
         if (owns_cur) {
-            f16 ka = s_k[j], kc = s_k[j + p.rot / 2];
-            rotary_pair(ka, kc, j, p.rot, pos);
+            f16 ka = s_k[j], kc2 = s_k[j + p.rot / 2];
+            rotary_apply(ka, kc2, cs, sn);
             s_k[j]             = ka;
-            s_k[j + p.rot / 2] = kc;
+            s_k[j + p.rot / 2] = kc2;
         }
     }
     __syncthreads();
@@ -133,7 +177,7 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
     // ---- phase 1: qk for the cached keys (fp32 accumulate, MMHA_USE_FP32_ACUM_FOR_FMA) ----
     float lmax = -INFINITY;
     constexpr int U = 4;
-    auto qk_one = [&](const u32x4 raw, const int t) {
+    auto qk_one = [&](const u32x4 raw, const int t, const int u_fast) {
         const f16x8 kv = __builtin_bit_cast(f16x8, raw);
         float       a  = 0.f;
         a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
@@ -142,7 +186,7 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
         a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
         a              = group_sum(a, LPK) * inv_sqrt_dh;
         if (t < t_cached_end && sub == 0) {
-            const bool m = mask && mask[t];
+            const bool m = (u_fast >= 0) ? ((mask_bits >> u_fast) & 1u) != 0u : (mask && mask[t]);
             s_p[t - t_beg] = m ? -INFINITY : a;  // masked keys get probability 0 (:1570,:1610-1622)
             if (!m) {
                 lmax = fmaxf(lmax, a);
@@ -152,7 +196,7 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
     if (fast) {
 #pragma unroll
         for (int u = 0; u < UK; u++) {
-            qk_one(kreg[u], t_beg + u * 4 * KPI + wid * KPI + grp);
+            qk_one(kreg[u], t_beg + u * 4 * KPI + wid * KPI + grp, u);
         }
     }
     else {
@@ -166,7 +210,7 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                qk_one(kr[u], t0 + u * 4 * KPI + grp);
+                qk_one(kr[u], t0 + u * 4 * KPI + grp, -1);
             }
         }
     }
@@ -211,11 +255,13 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
         acc[j] = 0.f;
     }
     auto pv_one = [&](const u32x4 raw, const int t) {
-        const float pt = (t < t_cached_end) ? s_p[t - t_beg] : 0.f;
-        const f16x8 vv = __builtin_bit_cast(f16x8, raw);
+        if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything (NaN bits)
+            const float pt = s_p[t - t_beg];
+            const f16x8 vv = __builtin_bit_cast(f16x8, raw);
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+            for (int j = 0; j < 8; j++) {
+                acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+            }
         }
     };
     if (fast) {
@@ -264,57 +310,70 @@ __device__ __forceinline__ void mmha_partial(const MmhaParams& p, char* smem, fl
     __syncthreads();
     if (threadIdx.x < DH) {
         const int d = threadIdx.x;
-        st_agent(&wsout[d], (s_o[d] + s_o[DH + d]) + (s_o[2 * DH + d] + s_o[3 * DH + d]));
+        st_granule(&gout[d], tag, (s_o[d] + s_o[DH + d]) + (s_o[2 * DH + d] + s_o[3 * DH + d]));
     }
     if (threadIdx.x == 0) {
-        st_agent(&wsout[DH], m_loc);
-        st_agent(&wsout[DH + 1], (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+        st_granule(&gout[DH], tag, m_loc);
+        st_granule(&gout[DH + 1], tag, (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
     }
+    return true;
 }
 
-// One launch: every split workgroup publishes its (max, sum, out[DH]) partial, takes a ticket, and the LAST arriver
-// of each (row, head) merges the partials in split order (deterministic) -- the in-launch hand-off recipe of
-// cdna_hip_programming.md G16: plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release (+ asm vmcnt(0))
-// -> relaxed agent ticket ; consumer: one-lane agent acquire -> barrier -> plain loads.  Placement independent.
+// One launch: every split workgroup publishes its partial as granules; the split-0 workgroup of each (row, head) then
+// polls the nsplit partials (all loads of one pass in flight together), merges them in split order (deterministic)
+// and writes ctx.  Only split 0 ever waits, producers never do: no deadlock under any dispatch order as long as the
+// producers get scheduled, and every spin is bounded.
 template<int DH>
 __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int& s_last, const int h, const int b, const int sp)
 {
-    if (p.finished && p.finished[b]) {
-        return;  // :1176 (ctx of a finished row is never consumed); uniform for all splits of the row
-    }
-    float* wsout = p.ws + (((size_t)b * p.nh + h) * p.nsplit + sp) * (DH + 2);
-    mmha_partial<DH>(p, smem, wsout, h, b, sp);
-    if (p.nsplit == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x < DH) {
-            const float inv = 1.f / (ld_agent(&wsout[DH + 1]) + 1.e-6f);  // :1632
-            p.ctx[(size_t)b * p.nh * DH + h * DH + threadIdx.x] = (f16)(ld_agent(&wsout[threadIdx.x]) * inv);
-        }
+    (void)s_last;
+    const int      step = p.d_step ? *p.d_step : p.step;
+    const unsigned tag  = (unsigned)(step * 256 + p.layer) + 1u;  // num_layer <= 256 (checked at create)
+    u64*           gall = p.gran + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
+    const bool     live = mmha_partial<DH>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
+    if (!live || sp != 0) {
         return;
     }
-    // publish: sc1 payload (st_agent) -> every wave drains its stores -> barrier -> ONE relaxed agent ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- merger (split 0) ----
     __syncthreads();
-    int* counter = p.counters + (size_t)b * p.nh + h;
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last      = (t == p.nsplit - 1) ? 1 : 0;
-        if (s_last) {
-            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    float* sval = reinterpret_cast<float*>(smem);  // [nsplit][DH+2], then [nsplit] weights + [1] denominator
+    const int ne = DH + 2;
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+        u64 gv[MMHA_MAX_SPLIT];
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int s2 = 0; s2 < MMHA_MAX_SPLIT; s2++) {
+                if (s2 < p.nsplit) {
+                    gv[s2] = ld_granule(&gall[(size_t)s2 * ne + i]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < MMHA_MAX_SPLIT; s2++) {
+                if (s2 < p.nsplit) {
+                    ok &= ((unsigned)(gv[s2] >> 32) == tag);
+                }
+            }
+            if (ok || ++spins > MMHA_SPIN_LIMIT) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < MMHA_MAX_SPLIT; s2++) {
+            if (s2 < p.nsplit) {
+                sval[s2 * ne + i] = __uint_as_float((unsigned)gv[s2]);
+            }
         }
     }
     __syncthreads();
-    if (!s_last) {
-        return;
-    }
-    const float* ws = p.ws + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
-    float*       sw = reinterpret_cast<float*>(smem);  // [nsplit] weights, then [1] denominator
+    float* sw = sval + p.nsplit * ne;
     if (threadIdx.x < 64) {
         float ms = -INFINITY, ls = 0.f;
-        if ((int)threadIdx.x < p.nsplit) {  // nsplit <= 64
-            ms = ld_agent(&ws[threadIdx.x * (DH + 2) + DH]);
-            ls = ld_agent(&ws[threadIdx.x * (DH + 2) + DH + 1]);
+        if ((int)threadIdx.x < p.nsplit) {
+            ms = sval[threadIdx.x * ne + DH];
+            ls = sval[threadIdx.x * ne + DH + 1];
         }
         const float m = wave_max(ms);
         const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
@@ -333,14 +392,12 @@ __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int&
     if (threadIdx.x < DH) {
         const int d = threadIdx.x;
         float     o = 0.f;
-#pragma unroll 4
         for (int s2 = 0; s2 < p.nsplit; s2++) {
-            o += sw[s2] * ld_agent(&ws[s2 * (DH + 2) + d]);
+            o += sw[s2] * sval[s2 * ne + d];
         }
         const float inv = 1.f / (sw[p.nsplit] + 1.e-6f);  // :1632
         p.ctx[(size_t)b * p.nh * DH + h * DH + d] = (f16)(o * inv);
     }
 }
-
 
 }  // namespace ftcf

@@ -186,7 +186,8 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
         p.KT_b = 0;
         p.act = act;
         p.tp = 1;
-        plan_splitk(p, int8, m, 4);
+        static const int dbg_waves = getenv("FTCF_SPLITK_WAVES") ? atoi(getenv("FTCF_SPLITK_WAVES")) : 4;
+        plan_splitk(p, int8, m, dbg_waves);
         launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
     }
     else {
@@ -277,11 +278,12 @@ extern "C" int ftcf_masked_multihead_attention(const void* qkv, const void* qkv_
         p.rot = rot;
         p.s_max = s_max;
         p.ctx = (f16*)ctx;
-        p.ws = (float*)workspace;
+        p.gran = (unsigned long long*)workspace;
+        p.layer = 0;
         p.nsplit = mmha_pick_nsplit(B, nh, s_max);
         FTCF_CHECK_ARG(workspace_bytes >= mmha_workspace_bytes(B, nh, dh, p.nsplit), "MMHA workspace too small");
-        p.counters = mmha_counters(p.ws, B, nh, dh, p.nsplit);
-        FTCF_HIP_CHECK(hipMemsetAsync(p.counters, 0, (size_t)B * nh * sizeof(int), (hipStream_t)stream));
+        // the granule tags must not match anything left from an earlier call
+        FTCF_HIP_CHECK(hipMemsetAsync(p.gran, 0, mmha_workspace_bytes(B, nh, dh, p.nsplit), (hipStream_t)stream));
         launch_mmha(p, (hipStream_t)stream);
     });
 }
@@ -364,6 +366,7 @@ struct ftcf_gptneox {
     // 0: 3 launches/layer (K1, K2 = MMHA || FFN1, K3) -- default; 2: two concurrent stream chains (measured slower:
     // cross-stream fork/join costs 5-10 us each on this runtime, profiles/r01 notes)
     int                       decode_mode = 0;
+    int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
     std::vector<void*>        owned;  // tiled fp16 copies (int8_mode == 0)
@@ -374,7 +377,7 @@ struct ftcf_gptneox {
     f16 *k_cache = nullptr, *v_cache = nullptr;
     f16 *px = nullptr, *pnrm = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
         *pffn = nullptr;
-    float *      logits = nullptr, *gather = nullptr, *mmha_ws = nullptr;
+    float *      logits = nullptr, *gather = nullptr, *mmha_ws = nullptr, *rot_table = nullptr;
     void*        samp_ws = nullptr;
     DecodeState* state = nullptr;
     uint8_t *    finished = nullptr, *masked = nullptr;
@@ -482,6 +485,7 @@ struct ftcf_gptneox {
             gather             = c.take<float>((size_t)B * V);
             mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
             samp_ws            = c.take<char>(sampling_workspace_bytes(B, V));
+            rot_table          = c.take<float>((size_t)B * 256);
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -568,15 +572,16 @@ struct ftcf_gptneox {
             mp.masked_tokens = masked;
             mp.finished = finished;
             mp.d_step = &state->step;
+            mp.rot_table = rot_table;
             mp.B = B;
             mp.nh = nhl;
             mp.dh = dh;
             mp.rot = cfg.rotary_embedding_dim;
             mp.s_max = s_max;
             mp.ctx = ctx;
-            mp.ws = mmha_ws;
+            mp.gran = (unsigned long long*)mmha_ws;
+            mp.layer = l;
             mp.nsplit = nsplit;
-            mp.counters = mmha_counters(mmha_ws, B, nhl, dh, nsplit);
             if (B <= 4 && decode_mode == 2) {
                 // Two concurrent dependency chains per layer (parallel residual, GptNeoXDecoder.cc:267-356):
                 //   chain A (side stream): LN2 -> FFN1 + bias + gelu  ->  FFN2                      (2 x 104.9 MB/TP)
@@ -660,7 +665,14 @@ struct ftcf_gptneox {
                 a.blocks0 = (a.NT0 + 3) / 4;
                 a.blocks1 = 0;
                 a.eps = 1e-5f;
-                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] { launch_ln_gemv(a, int8, B, stream); });
+                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] {
+                    if (k1_wpg > 0) {
+                        launch_ln_gemv_group(a, int8, B, k1_wpg, stream);
+                    }
+                    else {
+                        launch_ln_gemv(a, int8, B, stream);
+                    }
+                });
                 LnGemvParams f{};
                 f.x = x;
                 f.gamma1 = w.ln2_g;
@@ -817,7 +829,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
 
     hipEvent_t e0 = get_event(), e1 = get_event();
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
-    FTCF_HIP_CHECK(hipMemsetAsync(mmha_counters(mmha_ws, B, nhl, dh, nsplit), 0, (size_t)B * nhl * sizeof(int), stream));
+    FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
     if (S > 1) {
         launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
@@ -884,6 +896,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
     const int tp = cfg.tensor_para_size;
     if (with_decoder) {
             launch_step_embedding(x, wte, step_ids, &state->step, B, H, stream);
+            launch_rotary_table(rot_table, &state->step, pad_count, B, cfg.rotary_embedding_dim, stream);
             decoder(B, s_max);
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
@@ -1033,6 +1046,7 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
                        "head_num, inter_size and vocab_size must be divisible by tensor_para_size");
         const int L = cfg->num_layer;
         FTCF_CHECK_ARG(w->n_weights == 12 * L + 4, "weights must hold 12*L+4 tensors");
+        FTCF_CHECK_ARG(L >= 1 && L <= 256, "num_layer must be in 1..256");
         FTCF_HIP_CHECK(hipSetDevice(cfg->device));
         auto e   = std::make_unique<ftcf_gptneox>();
         e->cfg   = *cfg;
@@ -1113,6 +1127,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         if (const char* m = getenv("FTCF_DECODE_MODE")) {
             e->decode_mode = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_K1_WPG")) {
+            e->k1_wpg = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_USE_GRAPH")) {

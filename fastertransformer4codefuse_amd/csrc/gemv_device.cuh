@@ -5,7 +5,10 @@
 
 namespace ftcf {
 
-constexpr int GEMV_U = 8;  // tiles per batch (x2 batches in flight)
+#ifndef FTCF_GEMV_U
+#define FTCF_GEMV_U 8
+#endif
+constexpr int GEMV_U = FTCF_GEMV_U;  // tiles per batch (x2 batches in flight)
 
 template<bool INT8>
 struct TileK {
@@ -290,5 +293,152 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Balanced variant of K_A: ONE 16-column group per workgroup, its waves split K (LDS reduce in wave order).
+// Workgroup counts: QKV 960, FFN1 1280 at CodeFuse-13B -> 3.75 / 5 per CU instead of the 0.94 / 1.25 of the
+// 4-groups-per-workgroup form, whose CUs with one extra workgroup set the kernel time (measured +30 %).
+// Segment 0 blocks are [0, NT0), segment 1 blocks [NT0, NT0 + NT1).
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M>
+__device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char* smem, const int block_id)
+{
+    const int nw   = blockDim.x >> 6;
+    f16*      xs   = reinterpret_cast<f16*>(smem);                          // [M][K]
+    float*    red  = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*nw floats (LN), then [nw][M][16]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int seg  = (block_id >= p.NT0) ? 1 : 0;
+    const int grp  = seg ? block_id - p.NT0 : block_id;
+    const int K    = p.K;
+    constexpr int TK = TileK<INT8>::value;
+    const int     KT = K / TK;
+    const int     c = lane & 15, g = lane >> 4;
+    const int     t0 = (int)((long)KT * wid / nw), t1 = (int)((long)KT * (wid + 1) / nw);
+    const int     nt = t1 - t0;
+    const char*   wbase = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
+    const u32x4*  wp    = reinterpret_cast<const u32x4*>(wbase + (((size_t)grp * KT + t0) * 64 + lane) * 16);
+    WaveStream<INT8, M> ws;
+    const f16* gamma = seg ? p.gamma1 : p.gamma0;
+    const f16* beta  = seg ? p.beta1 : p.beta0;
+    const int  nthr  = blockDim.x;
+    constexpr int XV = 5;  // register-resident LayerNorm: K <= 40 * nthr (5120 at 128 threads); larger K takes the loop path
+    if (M == 1 && K <= nthr * 8 * XV) {
+        // x, gamma, beta (L2 hits) are requested first, then the first weight batch; the LayerNorm math runs while
+        // the weights are in flight (counted vmcnt: the x loads are the oldest)
+        f16x8 xv[XV], gv[XV], bv[XV];
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int  i  = (threadIdx.x + j * nthr) * 8;
+            const bool ok = i < K;
+            xv[j] = ok ? *reinterpret_cast<const f16x8*>(p.x + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            gv[j] = ok ? *reinterpret_cast<const f16x8*>(gamma + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            bv[j] = ok ? *reinterpret_cast<const f16x8*>(beta + i) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        ws.prime(wp, nt);
+        __builtin_amdgcn_sched_barrier(0);
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float f = (float)xv[j][e];
+                s[0] += f;
+                s[1] += f * f;
+            }
+        }
+        block_sum<2>(s, red);
+        const float mean = s[0] / (float)K;
+        const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+        const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+        for (int j = 0; j < XV; j++) {
+            const int i = (threadIdx.x + j * nthr) * 8;
+            if (i < K) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    o[e] = (((xv[j][e] - mh) * rh) * gv[j][e]) + bv[j][e];
+                }
+                *reinterpret_cast<f16x8*>(xs + i) = o;
+            }
+        }
+    }
+    else {
+        ws.prime(wp, nt);  // weights first: the LayerNorm below runs under their HBM latency
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const f16* xr   = p.x + (size_t)m * K;
+            float      s[2] = {0.f, 0.f};
+            for (int i = threadIdx.x * 8; i < K; i += nthr * 8) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float f = (float)v[j];
+                    s[0] += f;
+                    s[1] += f * f;
+                }
+            }
+            block_sum<2>(s, red);
+            const float mean = s[0] / (float)K;
+            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + p.eps);
+            const f16   mh = (f16)mean, rh = (f16)rstd;
+            for (int i = threadIdx.x * 8; i < K; i += nthr * 8) {
+                const f16x8 v  = *reinterpret_cast<const f16x8*>(xr + i);
+                const f16x8 gg = *reinterpret_cast<const f16x8*>(gamma + i);
+                const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + i);
+                f16x8       o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
+                }
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+            }
+        }
+    }
+    __syncthreads();
+    const int n      = grp * 16 + c;
+    f16x2     scale2 = {(f16)1.0f, (f16)1.0f};
+    if constexpr (INT8) {
+        const f16 sc = (seg ? p.scale1 : p.scale0)[n];
+        scale2       = f16x2{sc, sc};
+    }
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        acc[m] = 0.f;
+    }
+    ws.run(wp, nt, xs + (size_t)t0 * TK + g * (TK / 4), K, scale2, acc);
+    fold_groups<M>(acc);
+    float* part = red + 2 * nw;  // [nw][M][16]
+    if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            part[(wid * M + m) * 16 + c] = acc[m];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < M * 16) {
+        const int m = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        const int nn = grp * 16 + cc;
+        float     v  = 0.f;
+        for (int w = 0; w < nw; w++) {
+            v += part[(w * M + m) * 16 + cc];
+        }
+        f16*      out = seg ? p.out1 : p.out0;
+        const int N   = (seg ? p.NT1 : p.NT0) * 16;
+        if (seg == 1) {
+            if constexpr (INT8) {
+                out[(size_t)m * N + nn] = (f16)gelu_f32(v + (float)p.bias1[nn]);  // epilogue_helpers.h:52-62
+            }
+            else {
+                out[(size_t)m * N + nn] = gelu_f16((f16)v + p.bias1[nn]);  // activation_kernels.cu:401-426
+            }
+        }
+        else {
+            out[(size_t)m * N + nn] = (f16)v;
+        }
+    }
+}
 
 }  // namespace ftcf

@@ -9,7 +9,7 @@
 
 namespace ftcf {
 
-constexpr int GEMV_SPLITK_MAX_WAVES = 10;
+constexpr int GEMV_SPLITK_MAX_WAVES = 16;
 constexpr int EPI_PLAIN             = 0;
 constexpr int EPI_RESIDUAL          = 1;
 
@@ -39,6 +39,8 @@ struct SplitKParams {
 };
 
 void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s);
+// one 16-column group per workgroup of `wpg` waves (balanced form, grid = NT0 + NT1)
+void launch_ln_gemv_group(const LnGemvParams& p, bool int8, int M, int wpg, hipStream_t s);
 void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves);
 void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStream_t s);
 // optional fused LayerNorm of x (gamma != NULL)
@@ -78,17 +80,20 @@ struct MmhaParams {
     const uint8_t* masked_tokens;  // [B, s_max]
     const uint8_t* finished;
     const int*     d_step;  // device step counter (timestep = step - 1); if NULL `step` is used
+    const float*   rot_table;  // optional [B][rot/2][2] {cos, sin} of this step's rotary position
     int            step;
     int            B, nh, dh, rot, s_max;
     f16*           ctx;  // [B, Hl]
-    float*         ws;   // split-KV workspace: [B][nh][nsplit][dh+2] partials
-    int*           counters;  // [B][nh] arrival tickets (zero between launches)
+    unsigned long long* gran;  // split-KV hand-off slab: [B][nh][nsplit][dh+2] {tag,value} granules (zero at request start)
+    int            layer;      // tag salt: unique per launch within a token
     int            nsplit;
 };
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);
-int*   mmha_counters(float* ws, int B, int nh, int dh, int nsplit);
 int    mmha_pick_nsplit(int B, int nh, int s_max);
+size_t mmha_smem_bytes(int dh, int s_max, int nsplit);
 void   launch_mmha(const MmhaParams& p, hipStream_t s);
+// {cos, sin}(pos * 10000^(-2j/rot)), pos = step - 1 - pad_count[b], once per token (decoder_masked_multihead_attention_utils.h:1325-1329)
+void   launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
                                 hipStream_t s);

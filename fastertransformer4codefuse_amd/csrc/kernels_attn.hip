@@ -28,34 +28,53 @@ __global__ __launch_bounds__(256) void k_mmha_split(const MmhaParams p)
 
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit)
 {
-    // partials + one arrival counter per (row, head); the counters must be zero before the first launch and are
-    // re-zeroed by the last arriver
-    return (((size_t)B * nh * nsplit * (dh + 2) * sizeof(float) + 255) & ~(size_t)255) + (size_t)B * nh * sizeof(int);
+    return (size_t)B * nh * nsplit * (dh + 2) * sizeof(unsigned long long);
 }
 
-int* mmha_counters(float* ws, int B, int nh, int dh, int nsplit)
+size_t mmha_smem_bytes(int dh, int s_max, int nsplit)
 {
-    size_t off = (size_t)B * nh * nsplit * (dh + 2) * sizeof(float);
-    off        = (off + 255) & ~(size_t)255;
-    return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + off);
+    const int    chunk   = (((s_max + nsplit - 1) / nsplit) + 15) & ~15;
+    const size_t partial = (size_t)3 * dh * 2 + (8 + 4 * dh) * 4 + (size_t)chunk * 4;
+    const size_t merge   = ((size_t)nsplit * (dh + 2) + nsplit + 1) * 4;
+    return std::max(partial, merge);
 }
 
 int mmha_pick_nsplit(int B, int nh, int s_max)
 {
-    int want = (768 + B * nh - 1) / (B * nh);  // aim for >= ~768 workgroups
+    int want = (640 + B * nh - 1) / (B * nh);  // aim for >= ~640 workgroups
     int maxs = (s_max + 63) / 64;              // at least 64 keys per split
-    int n    = std::max(1, std::min(std::min(want, maxs), 32));
+    int n    = std::max(1, std::min(std::min(want, maxs), 16));  // <= MMHA_MAX_SPLIT: one polling pass per merge
     return n;
+}
+
+__global__ void k_rotary_table(float* table, const int* d_step, const int* pad_count, int rot)
+{
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j < rot / 2) {
+        const int pos = (*d_step - 1) - (pad_count ? pad_count[b] : 0);
+        float     cs, sn;
+        rotary_coef(j, rot, pos, cs, sn);
+        table[((size_t)b * (rot / 2) + j) * 2]     = cs;
+        table[((size_t)b * (rot / 2) + j) * 2 + 1] = sn;
+    }
+}
+
+void launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s)
+{
+    if (rot <= 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k_rotary_table, dim3(B), dim3(64 * ((rot / 2 + 63) / 64)), 0, s, table, d_step, pad_count, rot);
+    FTCF_HIP_CHECK(hipGetLastError());
 }
 
 void launch_mmha(const MmhaParams& p, hipStream_t s)
 {
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh, "rotary_embedding_dim must be even and <= size_per_head");
-    const int    chunk = (((p.s_max + p.nsplit - 1) / p.nsplit) + 15) & ~15;
-    const size_t smem  = (size_t)3 * p.dh * 2 + (8 + 4 * p.dh) * 4 + (size_t)chunk * 4;
+    const size_t smem = mmha_smem_bytes(p.dh, p.s_max, p.nsplit);
     dim3         grid(p.nh, p.B, p.nsplit);
-    FTCF_CHECK_ARG(p.nsplit <= 64 && (p.nsplit == 1 || p.counters != nullptr), "bad split-KV configuration");
+    FTCF_CHECK_ARG(p.nsplit >= 1 && p.nsplit <= 16 && p.gran != nullptr, "bad split-KV configuration");
     if (p.dh == 128) {
         hipLaunchKernelGGL(k_mmha_split<128>, grid, dim3(256), smem, s, p);
     }

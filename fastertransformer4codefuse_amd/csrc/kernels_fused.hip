@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void k_mmha_ln_gemv(const MmhaParams ap, const
     const int      n_gemv = gp.blocks0 + gp.blocks1;
     const int      bid    = (int)blockIdx.x;
     if (bid < n_gemv) {
-        ln_gemv_block<INT8, M>(gp, smem, bid);
+        if (n_attn >= 0) {
+            ln_gemv_block<INT8, M>(gp, smem, bid);
+        }
     }
     else {
         const int a  = bid - n_gemv;
@@ -35,13 +37,16 @@ template<bool INT8, int M>
 static void launch_m(const MmhaParams& ap, const LnGemvParams& gp, hipStream_t s)
 {
     const int    n_attn = ap.nh * ap.B * ap.nsplit;
-    const int    chunk  = (((ap.s_max + ap.nsplit - 1) / ap.nsplit) + 15) & ~15;
-    const size_t smem_a = (size_t)3 * ap.dh * 2 + (8 + 4 * ap.dh) * 4 + (size_t)chunk * 4;
+    const size_t smem_a = mmha_smem_bytes(ap.dh, ap.s_max, ap.nsplit);
     const size_t smem_g = (size_t)M * gp.K * 2 + 64;
     const size_t smem   = std::max(smem_a, smem_g);
-    const int    grid   = n_attn + gp.blocks0 + gp.blocks1;
+    static const int dbg = getenv("FTCF_K2_DEBUG") ? atoi(getenv("FTCF_K2_DEBUG")) : 0;  // timing experiments only
+    int grid = n_attn + gp.blocks0 + gp.blocks1;
+    if (dbg == 1) {
+        grid = gp.blocks0 + gp.blocks1;  // weight stream only (attention skipped: wrong results)
+    }
     if (ap.dh == 128) {
-        hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 128>), dim3(grid), dim3(256), smem, s, ap, gp, n_attn);
+        hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 128>), dim3(grid), dim3(256), smem, s, ap, gp, dbg == 2 ? -1 : n_attn);
     }
     else {
         hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 64>), dim3(grid), dim3(256), smem, s, ap, gp, n_attn);
@@ -52,7 +57,7 @@ void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8
 {
     FTCF_CHECK_ARG(M >= 1 && M <= 4 && M == ap.B, "fused attention + GEMV supports 1..4 rows");
     FTCF_CHECK_ARG(ap.dh == 64 || ap.dh == 128, "size_per_head must be 64 or 128");
-    FTCF_CHECK_ARG(ap.nsplit <= 64 && (ap.nsplit == 1 || ap.counters != nullptr), "bad split-KV configuration");
+    FTCF_CHECK_ARG(ap.nsplit >= 1 && ap.nsplit <= 16 && ap.gran != nullptr, "bad split-KV configuration");
     FTCF_CHECK_ARG(gp.K % 64 == 0, "K must be a multiple of 64");
     if (int8) {
         switch (M) {

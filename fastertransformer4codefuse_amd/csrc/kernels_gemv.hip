@@ -20,6 +20,13 @@ __global__ __launch_bounds__(256) void k_ln_gemv(const LnGemvParams p)
     ln_gemv_block<INT8, M>(p, smem, (int)blockIdx.x);
 }
 
+template<bool INT8, int M>
+__global__ __launch_bounds__(256) void k_ln_gemv_group(const LnGemvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ln_gemv_group_block<INT8, M>(p, smem, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Generic split-K GEMV: one block per 16-column group, its waves split up to two K segments
 // (segment A = x_a * W_a, segment B = x_b * W_b).  Epilogues:
@@ -291,6 +298,37 @@ void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s)
             case 2: launch_ln_gemv_m<false, 2>(p, s); break;
             case 3: launch_ln_gemv_m<false, 3>(p, s); break;
             default: launch_ln_gemv_m<false, 4>(p, s); break;
+        }
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+template<bool INT8, int M>
+static void launch_ln_gemv_group_m(const LnGemvParams& p, int wpg, hipStream_t s)
+{
+    const size_t smem = (size_t)M * p.K * 2 + (2 * wpg + wpg * M * 16) * 4 + 64;
+    hipLaunchKernelGGL((k_ln_gemv_group<INT8, M>), dim3(p.NT0 + p.NT1), dim3(wpg * 64), smem, s, p);
+}
+
+void launch_ln_gemv_group(const LnGemvParams& p, bool int8, int M, int wpg, hipStream_t s)
+{
+    FTCF_CHECK_ARG(M >= 1 && M <= 4, "ln_gemv supports 1..4 rows");
+    FTCF_CHECK_ARG(p.K % 64 == 0, "K must be a multiple of 64");
+    FTCF_CHECK_ARG(wpg >= 1 && wpg <= 4, "1..4 waves per column group");
+    if (int8) {
+        switch (M) {
+            case 1: launch_ln_gemv_group_m<true, 1>(p, wpg, s); break;
+            case 2: launch_ln_gemv_group_m<true, 2>(p, wpg, s); break;
+            case 3: launch_ln_gemv_group_m<true, 3>(p, wpg, s); break;
+            default: launch_ln_gemv_group_m<true, 4>(p, wpg, s); break;
+        }
+    }
+    else {
+        switch (M) {
+            case 1: launch_ln_gemv_group_m<false, 1>(p, wpg, s); break;
+            case 2: launch_ln_gemv_group_m<false, 2>(p, wpg, s); break;
+            case 3: launch_ln_gemv_group_m<false, 3>(p, wpg, s); break;
+            default: launch_ln_gemv_group_m<false, 4>(p, wpg, s); break;
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());

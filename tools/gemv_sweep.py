@@ -23,5 +23,7 @@ def run(k, n, iters=200, m=1):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"k={k:6d} n={n:6d} MB={k*n/1e6:7.1f} us={us:7.2f} TB/s={k*n/us/1e6:5.2f}")
-for (k, n) in [(5120, 1024), (5120, 5120), (5120, 15360), (5120, 35840), (5120, 71680), (5120, 143360), (20480, 5120), (20480, 10240), (20480, 20480), (1024, 5120)]:
+import os
+shapes = [(5120, 15360), (5120, 20480), (5120, 35840)] if os.environ.get('SWEEP') == 'ka' else [(25600, 5120), (20480, 5120), (5120, 5120), (5120, 20480)] if os.environ.get('SWEEP') == 'k3' else [(5120, 1024), (5120, 5120), (5120, 15360), (5120, 35840), (5120, 71680), (5120, 143360), (20480, 5120), (20480, 10240), (20480, 20480), (1024, 5120)]
+for (k, n) in shapes:
     run(k, n)
