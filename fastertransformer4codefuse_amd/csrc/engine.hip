@@ -378,6 +378,8 @@ struct ftcf_gptneox {
     f16 *px = nullptr, *pnrm = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
         *pffn = nullptr;
     float *      logits = nullptr, *gather = nullptr, *mmha_ws = nullptr, *rot_table = nullptr;
+    unsigned long long* chunk_ws = nullptr;
+    int          k3_q = 1;  // chunks per column group of the K3 launch (0: legacy one-workgroup-per-group form)
     void*        samp_ws = nullptr;
     DecodeState* state = nullptr;
     uint8_t *    finished = nullptr, *masked = nullptr;
@@ -486,6 +488,7 @@ struct ftcf_gptneox {
             mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
             samp_ws            = c.take<char>(sampling_workspace_bytes(B, V));
             rot_table          = c.take<float>((size_t)B * 256);
+            chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, B <= 4 ? B : 1, 8) / 8);
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -688,25 +691,50 @@ struct ftcf_gptneox {
                 f.blocks1 = (f.NT1 + 3) / 4;
                 f.eps = 1e-5f;
                 timed(KIND_FUSED, wbytes * H * (double)il, [&] { launch_mmha_ln_gemv(mp, f, int8, B, stream); });
-                SplitKParams c{};
-                c.x_a = ctx;
-                c.x_b = mid;
-                c.W_a = w.attn_out.kernel;
-                c.W_b = w.ffn2.kernel;
-                c.scale_a = w.attn_out.scale;
-                c.scale_b = w.ffn2.scale;
-                c.bias = w.ffn2.bias;
-                c.x_in = x;
-                c.out = x;
-                c.N = H;
                 const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
-                c.KT_a = hl / tk;
-                c.KT_b = il / tk;
-                c.tp = cfg.tensor_para_size;
-                c.inplace_variant = inplace;
-                plan_splitk(c, int8, B, GEMV_SPLITK_MAX_WAVES);
-                timed(KIND_SPLITK, wbytes * H * ((double)hl + il),
-                      [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
+                if (k3_q > 0) {
+                    ChunkParams c{};
+                    c.x_a = ctx;
+                    c.x_b = mid;
+                    c.W_a = w.attn_out.kernel;
+                    c.W_b = w.ffn2.kernel;
+                    c.scale_a = w.attn_out.scale;
+                    c.scale_b = w.ffn2.scale;
+                    c.bias = w.ffn2.bias;
+                    c.x_in = x;
+                    c.out = x;
+                    c.N = H;
+                    c.KT_a = hl / tk;
+                    c.KT_b = il / tk;
+                    c.Q = k3_q;
+                    c.T = (c.KT_a + c.KT_b + c.Q - 1) / c.Q;
+                    c.tp = cfg.tensor_para_size;
+                    c.inplace_variant = inplace;
+                    c.gran = chunk_ws;
+                    c.d_step = &state->step;
+                    c.salt = l;
+                    timed(KIND_SPLITK, wbytes * H * ((double)hl + il), [&] { launch_gemv_chunked(c, int8, B, stream); });
+                }
+                else {
+                    SplitKParams c{};
+                    c.x_a = ctx;
+                    c.x_b = mid;
+                    c.W_a = w.attn_out.kernel;
+                    c.W_b = w.ffn2.kernel;
+                    c.scale_a = w.attn_out.scale;
+                    c.scale_b = w.ffn2.scale;
+                    c.bias = w.ffn2.bias;
+                    c.x_in = x;
+                    c.out = x;
+                    c.N = H;
+                    c.KT_a = hl / tk;
+                    c.KT_b = il / tk;
+                    c.tp = cfg.tensor_para_size;
+                    c.inplace_variant = inplace;
+                    plan_splitk(c, int8, B, 10);
+                    timed(KIND_SPLITK, wbytes * H * ((double)hl + il),
+                          [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
+                }
             }
             else {
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
@@ -830,6 +858,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     hipEvent_t e0 = get_event(), e1 = get_event();
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
+    FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, B <= 4 ? B : 1, 8), stream));
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
     if (S > 1) {
         launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
@@ -1127,6 +1156,10 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         if (const char* m = getenv("FTCF_DECODE_MODE")) {
             e->decode_mode = atoi(m);
+        }
+        e->k3_q = chunk_pick_q(e->H / 16, (e->hl + e->il) / (e->int8 ? TILE_K_I8 : TILE_K_F16));
+        if (const char* m = getenv("FTCF_K3_Q")) {
+            e->k3_q = atoi(m);
         }
         if (const char* m = getenv("FTCF_K1_WPG")) {
             e->k1_wpg = atoi(m);

@@ -38,6 +38,24 @@ struct SplitKParams {
     int        wave_seg[GEMV_SPLITK_MAX_WAVES], wave_t0[GEMV_SPLITK_MAX_WAVES], wave_nt[GEMV_SPLITK_MAX_WAVES];
 };
 
+// K3 in its balanced form: every 16-column group is cut into Q chunks of the concatenated K range [x_a ; x_b]; one
+// 2-wave workgroup per (group, chunk), partial sums handed to the chunk-0 workgroup as {tag,value} granules.
+struct ChunkParams {
+    const f16 *x_a, *x_b;
+    const void *W_a, *W_b;
+    const f16 *scale_a, *scale_b;
+    const f16* bias;
+    const f16* x_in;
+    f16*       out;
+    int        N, KT_a, KT_b, Q, T;  // T = tiles per chunk
+    int        tp, inplace_variant;
+    unsigned long long* gran;  // [N/16][Q][2][M][16]
+    const int* d_step;
+    int        step, salt;
+};
+int    chunk_pick_q(int NT, int KT_total);
+size_t chunk_workspace_bytes(int N, int M, int Q);
+void   launch_gemv_chunked(const ChunkParams& p, bool int8, int M, hipStream_t s);
 void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s);
 // one 16-column group per workgroup of `wpg` waves (balanced form, grid = NT0 + NT1)
 void launch_ln_gemv_group(const LnGemvParams& p, bool int8, int M, int wpg, hipStream_t s);

@@ -9,6 +9,8 @@
 // Roofline: HBM.  Every weight byte is read exactly once per token; algorithmic bytes per launch = K*N (int8)
 // or 2*K*N (fp16) (+ 2N scales).  One wave-level load instruction fetches one 1 KiB tile (16 B per lane,
 // non-temporal), 8 tiles are kept in flight per wave while the previous 8 are consumed from registers.
+#include <cmath>
+
 #include "gemv_device.cuh"
 
 namespace ftcf {
@@ -431,6 +433,264 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
         default: throw Error(-1, "lm_head GEMV supports 1..4 rows");
     }
 #undef FTCF_LM
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3, balanced: out = residual(half(x_a * W_a), half(x_b * W_b))  (out-proj U FFN2 -> add_residual_kernels.cu:116-152)
+// The one-workgroup-per-column-group form has N/16 = 320 workgroups for 256 CUs: the 64 CUs that get two of them set
+// the kernel time (+35 %).  Here each group's concatenated K range is cut into Q chunks -> NT*Q = 1280 two-wave
+// workgroups = exactly 5 per CU.  Partials travel as granules to the chunk-0 workgroup (only it waits; bounded spin).
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned long long u64g;
+__device__ __forceinline__ void st_gran(u64g* g, unsigned tag, float v)
+{
+    __hip_atomic_store(g, ((u64g)tag << 32) | (u64g)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template<bool INT8, int M>
+__global__ __launch_bounds__(128) void k_gemv_chunked(const ChunkParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TK   = TileK<INT8>::value;
+    const int     lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int     grp = blockIdx.x / p.Q, q = blockIdx.x % p.Q;
+    const int     c = lane & 15, g = lane >> 4;
+    const int     KTt = p.KT_a + p.KT_b;
+    // flat tile range of this wave
+    const int lo = min(q * p.T, KTt), hi = min(lo + p.T, KTt);
+    const int half = (hi - lo + 1) / 2;
+    const int w_lo = min(lo + wid * half, hi), w_hi = min(w_lo + half, hi);
+    // pieces: A = [w_lo, w_hi) ^ [0, KT_a) ; B = [w_lo, w_hi) ^ [KT_a, KTt) shifted by KT_a
+    const int a0 = min(w_lo, p.KT_a), a1 = min(w_hi, p.KT_a);
+    const int b0 = max(w_lo, p.KT_a) - p.KT_a, b1 = max(w_hi, p.KT_a) - p.KT_a;
+    const int ntA = a1 - a0, ntB = b1 - b0;
+    const int slice = (p.T / 2 + 2) * TK;  // halves per wave per row
+    f16*      xs    = reinterpret_cast<f16*>(smem) + (size_t)wid * M * slice;
+    const u32x4* wpA = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W_a)
+                                                      + (((size_t)grp * p.KT_a + a0) * 64 + lane) * 16);
+    const u32x4* wpB = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W_b)
+                                                      + (((size_t)grp * p.KT_b + b0) * 64 + lane) * 16);
+    WaveStream<INT8, M> ws;
+    // x slices (L2 hits) first, then the first weight batch
+    {
+        const int nhA = ntA * TK, nhB = ntB * TK;
+        constexpr int SV = (M == 1) ? 8 : ((M == 2) ? 4 : 2);
+        if (nhA + nhB <= 512 * SV) {
+            f16x8 xv[M][SV];
+#pragma unroll
+            for (int j = 0; j < SV; j++) {
+                const int i = lane * 8 + j * 512;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (i < nhA) {
+                        v = *reinterpret_cast<const f16x8*>(p.x_a + (size_t)m * p.KT_a * TK + (size_t)a0 * TK + i);
+                    }
+                    else if (i < nhA + nhB) {
+                        v = *reinterpret_cast<const f16x8*>(p.x_b + (size_t)m * p.KT_b * TK + (size_t)b0 * TK + (i - nhA));
+                    }
+                    xv[m][j] = v;
+                }
+            }
+            if (ntA > 0) {
+                ws.prime(wpA, ntA);
+            }
+            else {
+                ws.prime(wpB, ntB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < SV; j++) {
+                const int i = lane * 8 + j * 512;
+                if (i < nhA + nhB) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        *reinterpret_cast<f16x8*>(xs + (size_t)m * slice + i) = xv[m][j];
+                    }
+                }
+            }
+        }
+        else {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                for (int i = lane * 8; i < nhA + nhB; i += 512) {
+                    *reinterpret_cast<f16x8*>(xs + (size_t)m * slice + i) =
+                        (i < nhA) ? *reinterpret_cast<const f16x8*>(p.x_a + (size_t)m * p.KT_a * TK + (size_t)a0 * TK + i) :
+                                    *reinterpret_cast<const f16x8*>(p.x_b + (size_t)m * p.KT_b * TK + (size_t)b0 * TK + (i - nhA));
+                }
+            }
+            if (ntA > 0) {
+                ws.prime(wpA, ntA);
+            }
+            else {
+                ws.prime(wpB, ntB);
+            }
+        }
+    }
+    const int n = grp * 16 + c;
+    float     accA[M], accB[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        accA[m] = 0.f;
+        accB[m] = 0.f;
+    }
+    if (ntA > 0) {
+        f16x2 sc2 = {(f16)1.0f, (f16)1.0f};
+        if constexpr (INT8) {
+            const f16 sc = p.scale_a[n];
+            sc2          = f16x2{sc, sc};
+        }
+        ws.run(wpA, ntA, xs + g * (TK / 4), slice, sc2, accA);
+        if (ntB > 0) {
+            ws.prime(wpB, ntB);
+        }
+    }
+    if (ntB > 0) {
+        f16x2 sc2 = {(f16)1.0f, (f16)1.0f};
+        if constexpr (INT8) {
+            const f16 sc = p.scale_b[n];
+            sc2          = f16x2{sc, sc};
+        }
+        ws.run(wpB, ntB, xs + (size_t)ntA * TK + g * (TK / 4), slice, sc2, accB);
+    }
+    fold_groups<M>(accA);
+    fold_groups<M>(accB);
+    // two-wave reduce in LDS, fixed order
+    float* part = reinterpret_cast<float*>(smem + (size_t)2 * M * slice * 2);  // [2 waves][2][M][16]
+    if (g == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            part[((wid * 2 + 0) * M + m) * 16 + c] = accA[m];
+            part[((wid * 2 + 1) * M + m) * 16 + c] = accB[m];
+        }
+    }
+    __syncthreads();
+    const int      step = p.d_step ? *p.d_step : p.step;
+    const unsigned tag  = (unsigned)(step * 256 + p.salt) + 1u;
+    u64g*          gg   = p.gran + (size_t)grp * p.Q * 2 * M * 16;
+    if (threadIdx.x < 2 * M * 16) {  // index = (s*M + m)*16 + c
+        const float v = part[threadIdx.x] + part[2 * M * 16 + threadIdx.x];
+        if (p.Q > 1) {
+            st_gran(&gg[(size_t)q * 2 * M * 16 + threadIdx.x], tag, v);
+        }
+        else {
+            part[threadIdx.x] = v;
+        }
+    }
+    if (q != 0) {
+        return;
+    }
+    __syncthreads();
+    if (threadIdx.x < M * 16) {
+        const int m = threadIdx.x >> 4, cc = threadIdx.x & 15;
+        float     sa = 0.f, sb = 0.f;
+        if (p.Q > 1) {
+            u64g va[8], vb[8];
+            int  spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k < p.Q) {
+                        va[k] = __hip_atomic_load(&gg[(size_t)k * 2 * M * 16 + (0 * M + m) * 16 + cc], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                        vb[k] = __hip_atomic_load(&gg[(size_t)k * 2 * M * 16 + (1 * M + m) * 16 + cc], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (k < p.Q) {
+                        ok &= ((unsigned)(va[k] >> 32) == tag) && ((unsigned)(vb[k] >> 32) == tag);
+                    }
+                }
+                if (ok || ++spins > (1 << 22)) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {  // chunk order: deterministic
+                if (k < p.Q) {
+                    sa += __uint_as_float((unsigned)va[k]);
+                    sb += __uint_as_float((unsigned)vb[k]);
+                }
+            }
+        }
+        else {
+            sa = part[(0 * M + m) * 16 + cc];
+            sb = part[(1 * M + m) * 16 + cc];
+        }
+        const int    nn   = grp * 16 + cc;
+        const size_t oidx = (size_t)m * p.N + nn;
+        const f16    attn = (f16)sa, ffn = (f16)sb;
+        const f16    xin  = (f16)((float)p.x_in[oidx] / (float)p.tp);
+        const f16    b    = p.bias[nn];
+        f16          r;
+        if (p.inplace_variant) {
+            r = (f16)((float)xin + (float)ffn + (float)attn + (float)b);
+        }
+        else {
+            r = ((ffn + attn) + b) + xin;
+        }
+        p.out[oidx] = r;
+    }
+}
+
+int chunk_pick_q(int NT, int KT_total)
+{
+    int    best = 1;
+    double best_cost = 1e30;
+    for (int Q = 1; Q <= 8; Q *= 2) {
+        const int T = (KT_total + Q - 1) / Q;
+        if (Q > 1 && T / 2 < 16) {
+            break;  // keep >= 16 tiles per wave
+        }
+        const double per_cu = (double)NT * Q / 256.0;
+        const double cost   = std::ceil(per_cu) / per_cu + 0.01 * Q;  // imbalance factor, slight preference for small Q
+        if (cost < best_cost) {
+            best_cost = cost;
+            best      = Q;
+        }
+    }
+    return best;
+}
+
+size_t chunk_workspace_bytes(int N, int M, int Q)
+{
+    return (size_t)(N / 16) * Q * 2 * M * 16 * sizeof(unsigned long long);
+}
+
+template<bool INT8, int M>
+static void launch_chunked_m(const ChunkParams& p, hipStream_t s)
+{
+    const int    TK    = INT8 ? TILE_K_I8 : TILE_K_F16;
+    const int    slice = (p.T / 2 + 2) * TK;
+    const size_t smem  = (size_t)2 * M * slice * 2 + (size_t)2 * 2 * M * 16 * 4;
+    hipLaunchKernelGGL((k_gemv_chunked<INT8, M>), dim3((p.N / 16) * p.Q), dim3(128), smem, s, p);
+}
+
+void launch_gemv_chunked(const ChunkParams& p, bool int8, int M, hipStream_t s)
+{
+    FTCF_CHECK_ARG(M >= 1 && M <= 4, "gemv supports 1..4 rows");
+    FTCF_CHECK_ARG(p.N % 16 == 0 && p.Q >= 1 && p.Q <= 8 && (p.Q == 1 || p.gran != nullptr), "bad chunked GEMV config");
+    if (int8) {
+        switch (M) {
+            case 1: launch_chunked_m<true, 1>(p, s); break;
+            case 2: launch_chunked_m<true, 2>(p, s); break;
+            case 3: launch_chunked_m<true, 3>(p, s); break;
+            default: launch_chunked_m<true, 4>(p, s); break;
+        }
+    }
+    else {
+        switch (M) {
+            case 1: launch_chunked_m<false, 1>(p, s); break;
+            case 2: launch_chunked_m<false, 2>(p, s); break;
+            case 3: launch_chunked_m<false, 3>(p, s); break;
+            default: launch_chunked_m<false, 4>(p, s); break;
+        }
+    }
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
