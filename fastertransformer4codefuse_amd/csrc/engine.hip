@@ -280,7 +280,8 @@ extern "C" int ftcf_masked_multihead_attention(const void* qkv, const void* qkv_
         p.ctx = (f16*)ctx;
         p.gran = (unsigned long long*)workspace;
         p.layer = 0;
-        p.nsplit = mmha_pick_nsplit(B, nh, s_max);
+        p.dbg_stop = getenv("FTCF_MMHA_DBG") ? atoi(getenv("FTCF_MMHA_DBG")) : 0;
+        p.nsplit = getenv("FTCF_MMHA_NSPLIT") ? atoi(getenv("FTCF_MMHA_NSPLIT")) : mmha_pick_nsplit(B, nh, s_max);
         FTCF_CHECK_ARG(workspace_bytes >= mmha_workspace_bytes(B, nh, dh, p.nsplit), "MMHA workspace too small");
         // the granule tags must not match anything left from an earlier call
         FTCF_HIP_CHECK(hipMemsetAsync(p.gran, 0, mmha_workspace_bytes(B, nh, dh, p.nsplit), (hipStream_t)stream));

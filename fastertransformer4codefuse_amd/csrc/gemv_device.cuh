@@ -15,46 +15,47 @@ struct TileK {
     static constexpr int value = INT8 ? TILE_K_I8 : TILE_K_F16;
 };
 
-// Consumes one 16-byte weight fragment against M rows of x held in LDS.
+// Consumes one 16-byte weight fragment against the M (<= 16) rows of x held in LDS -- on the MATRIX pipe.
+// The lane's 16 bytes are exactly its B fragment(s) of v_mfma_f32_16x16x32_f16 (column lane&15, k group lane>>4); the
+// A fragment is x[row][same k order] with row = min(lane&15, M-1) (rows >= M are duplicates whose results are never
+// read).  D[row][col] accumulates over every tile in one f32x4 per lane: lane (g, c) register j = row 4g+j, column c.
+// Compared with the VALU dot2c form this removes 8 of 32 VALU instructions per tile-lane (and the slow dot2c ones),
+// leaves only the exact u8->f16 dequant on the VALU, needs no cross-lane fold, and costs the same for 1..16 rows.
 template<bool INT8, int M>
-__device__ __forceinline__ void consume_tile(const u32x4 w, const f16* xl, const int xstride, const f16x2 scale2,
-                                             float (&acc)[M])
+__device__ __forceinline__ void consume_tile(const u32x4 w, const f16* xr, const f16x2 scale2, f32x4& acc)
 {
     if constexpr (INT8) {
-        f16x2 b[8];
-        dequant4(w.x, scale2, b[0], b[1]);
-        dequant4(w.y, scale2, b[2], b[3]);
-        dequant4(w.z, scale2, b[4], b[5]);
-        dequant4(w.w, scale2, b[6], b[7]);
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
-            const f16x8 x1 = *reinterpret_cast<const f16x8*>(xl + m * xstride + 8);
-            float       a  = acc[m];
-            a              = dot2(b[0], f16x2{x0[0], x0[1]}, a);
-            a              = dot2(b[1], f16x2{x0[2], x0[3]}, a);
-            a              = dot2(b[2], f16x2{x0[4], x0[5]}, a);
-            a              = dot2(b[3], f16x2{x0[6], x0[7]}, a);
-            a              = dot2(b[4], f16x2{x1[0], x1[1]}, a);
-            a              = dot2(b[5], f16x2{x1[2], x1[3]}, a);
-            a              = dot2(b[6], f16x2{x1[4], x1[5]}, a);
-            a              = dot2(b[7], f16x2{x1[6], x1[7]}, a);
-            acc[m]         = a;
-        }
+        f16x2 d[8];
+        dequant4(w.x, scale2, d[0], d[1]);
+        dequant4(w.y, scale2, d[2], d[3]);
+        dequant4(w.z, scale2, d[4], d[5]);
+        dequant4(w.w, scale2, d[6], d[7]);
+        const f16x8 b0 = {d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
+        const f16x8 b1 = {d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(xr);
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(xr + 8);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc, 0, 0, 0);
     }
     else {
-        const f16x8 b = __builtin_bit_cast(f16x8, w);
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const f16x8 x0 = *reinterpret_cast<const f16x8*>(xl + m * xstride);
-            float       a  = acc[m];
-            a              = dot2(f16x2{b[0], b[1]}, f16x2{x0[0], x0[1]}, a);
-            a              = dot2(f16x2{b[2], b[3]}, f16x2{x0[2], x0[3]}, a);
-            a              = dot2(f16x2{b[4], b[5]}, f16x2{x0[4], x0[5]}, a);
-            a              = dot2(f16x2{b[6], b[7]}, f16x2{x0[6], x0[7]}, a);
-            acc[m]         = a;
-        }
+        const f16x8 b0 = __builtin_bit_cast(f16x8, w);
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(xr);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
     }
+}
+
+// LDS pointer of this lane's A fragments: row min(lane&15, M-1), k group lane>>4 of the first tile
+template<bool INT8, int M>
+__device__ __forceinline__ const f16* a_frag_ptr(const f16* xs_tile0, const int xstride, const int lane)
+{
+    const int r = (M == 1) ? 0 : (((lane & 15) < M) ? (lane & 15) : (M - 1));
+    return xs_tile0 + (size_t)r * xstride + (lane >> 4) * (INT8 ? 16 : 8);
+}
+
+// value of output row m, column lane&15 (valid on lanes 0..15 for m < 4)
+__device__ __forceinline__ float acc_row(const f32x4& acc, const int m)
+{
+    return m == 0 ? acc[0] : (m == 1 ? acc[1] : (m == 2 ? acc[2] : acc[3]));
 }
 
 // Streams `ntiles` consecutive tiles of one column group.  wp: this lane's 16 B of the first tile.
@@ -72,13 +73,13 @@ struct WaveStream {
             r[u] = __builtin_nontemporal_load(wp + (size_t)(batch * GEMV_U + u) * 64);
         }
     }
-    __device__ __forceinline__ void consume(const u32x4 (&r)[GEMV_U], int batch, const f16* xl, const int xstride,
-                                            const f16x2 scale2, float (&acc)[M])
+    __device__ __forceinline__ void consume(const u32x4 (&r)[GEMV_U], int batch, const f16* xr, const f16x2 scale2,
+                                            f32x4& acc)
     {
         constexpr int TK = TileK<INT8>::value;
 #pragma unroll
         for (int u = 0; u < GEMV_U; u++) {
-            consume_tile<INT8, M>(r[u], xl + (batch * GEMV_U + u) * TK, xstride, scale2, acc);
+            consume_tile<INT8, M>(r[u], xr + (batch * GEMV_U + u) * TK, scale2, acc);
         }
     }
     // issue the first batch early (before a prologue that does not depend on the weights)
@@ -88,8 +89,9 @@ struct WaveStream {
             load(A, wp, 0);
         }
     }
-    __device__ __forceinline__ void run(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
-                                        const f16x2 scale2, float (&acc)[M])
+    // xr: this lane's A-fragment pointer for the first tile (a_frag_ptr)
+    __device__ __forceinline__ void run(const u32x4* __restrict__ wp, int ntiles, const f16* xr, const f16x2 scale2,
+                                        f32x4& acc)
     {
         constexpr int TK = TileK<INT8>::value;
         const int     nb = ntiles / GEMV_U;
@@ -99,45 +101,25 @@ struct WaveStream {
             // registers), which serialises load and compute -- the pipeline must keep one batch in flight
             load(B, wp, b + 1);
             __builtin_amdgcn_sched_barrier(0);
-            consume(A, b, xl, xstride, scale2, acc);
+            consume(A, b, xr, scale2, acc);
             __builtin_amdgcn_sched_barrier(0);
             // unconditional (clamped) reload keeps the loop body branch free; the last one is a harmless re-read
             load(A, wp, (b + 2 < nb) ? b + 2 : nb - 1);
             __builtin_amdgcn_sched_barrier(0);
-            consume(B, b + 1, xl, xstride, scale2, acc);
+            consume(B, b + 1, xr, scale2, acc);
             __builtin_amdgcn_sched_barrier(0);
             b += 2;
         }
         if (b < nb) {
-            consume(A, b, xl, xstride, scale2, acc);
+            consume(A, b, xr, scale2, acc);
             b++;
         }
         for (int t = nb * GEMV_U; t < ntiles; t++) {
             const u32x4 w = __builtin_nontemporal_load(wp + (size_t)t * 64);
-            consume_tile<INT8, M>(w, xl + t * TK, xstride, scale2, acc);
+            consume_tile<INT8, M>(w, xr + t * TK, scale2, acc);
         }
     }
 };
-
-template<bool INT8, int M>
-__device__ __forceinline__ void wave_stream(const u32x4* __restrict__ wp, int ntiles, const f16* xl, const int xstride,
-                                            const f16x2 scale2, float (&acc)[M])
-{
-    WaveStream<INT8, M> ws;
-    ws.prime(wp, ntiles);
-    ws.run(wp, ntiles, xl, xstride, scale2, acc);
-}
-
-// After wave_stream lane (g, c) holds the partial of column c over its k sub-chunks; fold the 4 lane groups.
-template<int M>
-__device__ __forceinline__ void fold_groups(float (&acc)[M])
-{
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        acc[m] += __shfl_xor(acc[m], 16, 64);
-        acc[m] += __shfl_xor(acc[m], 32, 64);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // K_A: y0 = LN1(x) * W0        (QKV, no bias: the attention kernel adds it like the reference's MMHA)
@@ -261,19 +243,14 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
         const f16 sc = (seg ? p.scale1 : p.scale0)[n];
         scale2       = f16x2{sc, sc};
     }
-    float acc[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        acc[m] = 0.f;
-    }
-    ws.run(wp, KT, xs + g * (TK / 4), K, scale2, acc);
-    fold_groups<M>(acc);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ws.run(wp, KT, a_frag_ptr<INT8, M>(xs, K, lane), scale2, acc);
     if (g == 0) {
         f16*      out = seg ? p.out1 : p.out0;
         const int N   = NT * 16;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            float v = acc[m];
+            float v = acc_row(acc, m);
             if (seg == 1) {
                 if constexpr (INT8) {
                     // fused epilogue in fp32 (epilogue_helpers.h:52-62): bias + gelu, one rounding
@@ -403,18 +380,13 @@ __device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char*
         const f16 sc = (seg ? p.scale1 : p.scale0)[n];
         scale2       = f16x2{sc, sc};
     }
-    float acc[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        acc[m] = 0.f;
-    }
-    ws.run(wp, nt, xs + (size_t)t0 * TK + g * (TK / 4), K, scale2, acc);
-    fold_groups<M>(acc);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ws.run(wp, nt, a_frag_ptr<INT8, M>(xs + (size_t)t0 * TK, K, lane), scale2, acc);
     float* part = red + 2 * nw;  // [nw][M][16]
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            part[(wid * M + m) * 16 + c] = acc[m];
+            part[(wid * M + m) * 16 + c] = acc_row(acc, m);
         }
     }
     __syncthreads();

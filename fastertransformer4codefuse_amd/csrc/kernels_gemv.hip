@@ -103,20 +103,15 @@ __global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(cons
         const f16 sc = (seg ? p.scale_b : p.scale_a)[n];
         scale2       = f16x2{sc, sc};
     }
-    float acc[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        acc[m] = 0.f;
-    }
-    ws.run(wp, nt, xs + g * (TK / 4), p.slice_halves, scale2, acc);
-    fold_groups<M>(acc);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    ws.run(wp, nt, a_frag_ptr<INT8, M>(xs, p.slice_halves, lane), scale2, acc);
 
     // cross-wave reduction in a fixed order (deterministic)
     float* red = reinterpret_cast<float*>(smem + (size_t)nw * M * p.slice_halves * 2);  // [nw][M][16]
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            red[(wid * M + m) * 16 + c] = acc[m];
+            red[(wid * M + m) * 16 + c] = acc_row(acc, m);
         }
     }
     __syncthreads();
@@ -529,19 +524,14 @@ __global__ __launch_bounds__(128) void k_gemv_chunked(const ChunkParams p)
         }
     }
     const int n = grp * 16 + c;
-    float     accA[M], accB[M];
-#pragma unroll
-    for (int m = 0; m < M; m++) {
-        accA[m] = 0.f;
-        accB[m] = 0.f;
-    }
+    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
     if (ntA > 0) {
         f16x2 sc2 = {(f16)1.0f, (f16)1.0f};
         if constexpr (INT8) {
             const f16 sc = p.scale_a[n];
             sc2          = f16x2{sc, sc};
         }
-        ws.run(wpA, ntA, xs + g * (TK / 4), slice, sc2, accA);
+        ws.run(wpA, ntA, a_frag_ptr<INT8, M>(xs, slice, lane), sc2, accA);
         if (ntB > 0) {
             ws.prime(wpB, ntB);
         }
@@ -552,17 +542,15 @@ __global__ __launch_bounds__(128) void k_gemv_chunked(const ChunkParams p)
             const f16 sc = p.scale_b[n];
             sc2          = f16x2{sc, sc};
         }
-        ws.run(wpB, ntB, xs + (size_t)ntA * TK + g * (TK / 4), slice, sc2, accB);
+        ws.run(wpB, ntB, a_frag_ptr<INT8, M>(xs + (size_t)ntA * TK, slice, lane), sc2, accB);
     }
-    fold_groups<M>(accA);
-    fold_groups<M>(accB);
     // two-wave reduce in LDS, fixed order
     float* part = reinterpret_cast<float*>(smem + (size_t)2 * M * slice * 2);  // [2 waves][2][M][16]
     if (g == 0) {
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            part[((wid * 2 + 0) * M + m) * 16 + c] = accA[m];
-            part[((wid * 2 + 1) * M + m) * 16 + c] = accB[m];
+            part[((wid * 2 + 0) * M + m) * 16 + c] = acc_row(accA, m);
+            part[((wid * 2 + 1) * M + m) * 16 + c] = acc_row(accB, m);
         }
     }
     __syncthreads();
