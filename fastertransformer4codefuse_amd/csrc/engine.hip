@@ -352,7 +352,7 @@ struct Carver {
     }
 };
 
-enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND_COUNT = 4 };
+enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND_PERSIST = 4, KIND_COUNT = 5 };
 
 }  // namespace
 
@@ -390,6 +390,17 @@ struct ftcf_gptneox {
     uint64_t *draws = nullptr, *d_seed = nullptr;
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
+    // persistent decode layers (kernels_persist.hip): 0 off, 1 on when the shape is eligible
+    int                 persist = 0, persist_per_layer = 0, persist_nb = 0, persist_ctrl_share = 12;
+    int                 num_cu = 0;
+    PersistPlan         pplan{};
+    PersistLayer*       d_players = nullptr;  // device [L]
+    unsigned long long *ps_gq = nullptr, *ps_gm = nullptr, *ps_gc = nullptr, *ps_gx = nullptr, *ps_gp = nullptr,
+                       *ps_ga = nullptr;
+    size_t              ps_slab_n = 0;
+    int*                ps_err = nullptr;
+    long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
+    std::string         ps_ts_file;
 
     // profiling
     bool               profiling = false;
@@ -490,6 +501,23 @@ struct ftcf_gptneox {
             samp_ws            = c.take<char>(sampling_workspace_bytes(B, V));
             rot_table          = c.take<float>((size_t)B * 256);
             chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, B <= 4 ? B : 1, 8) / 8);
+            pplan = PersistPlan{};
+            if (persist && B <= 2) {
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_ctrl_share);
+            }
+            if (pplan.ok) {
+                ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
+                            + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 + (size_t)B * nhl * pplan.nsplit * (dh + 2);
+                ps_gq       = c.take<unsigned long long>(ps_slab_n + 8);
+                ps_gm       = ps_gq ? ps_gq + (size_t)B * 3 * hl / 2 : nullptr;
+                ps_gc       = ps_gq ? ps_gm + (size_t)B * il / 2 : nullptr;
+                ps_gx       = ps_gq ? ps_gc + (size_t)B * hl / 2 : nullptr;
+                ps_gp       = ps_gq ? ps_gx + (size_t)B * H / 2 : nullptr;
+                ps_ga       = ps_gq ? ps_gp + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 : nullptr;
+                ps_err      = ps_gq ? reinterpret_cast<int*>(ps_gq + ps_slab_n) : nullptr;
+                d_players   = c.take<PersistLayer>(L);
+                ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 32);
+            }
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -557,11 +585,67 @@ struct ftcf_gptneox {
         }
     }
 
+    PersistParams persist_params(int B, int s_max)
+    {
+        PersistParams pp{};
+        pp.layers = d_players;
+        pp.L = L;
+        pp.x_in = x;
+        pp.x_out = x;
+        pp.gq = ps_gq;
+        pp.gm = ps_gm;
+        pp.gc = ps_gc;
+        pp.gx = ps_gx;
+        pp.gp = ps_gp;
+        pp.ga = ps_ga;
+        pp.err = ps_err;
+        pp.H = H;
+        pp.Hl = hl;
+        pp.Il = il;
+        pp.nh = nhl;
+        pp.dh = dh;
+        pp.rot = cfg.rotary_embedding_dim;
+        pp.s_max = s_max;
+        pp.B = B;
+        pp.tp = cfg.tensor_para_size;
+        pp.plan = pplan;
+        pp.d_step = &state->step;
+        pp.seq_len = seq_len;
+        pp.pad_count = pad_count;
+        pp.masked_tokens = masked;
+        pp.finished = finished;
+        pp.rot_table = rot_table;
+        pp.eps = 1e-5f;
+        pp.ctrl_share = persist_ctrl_share;
+        pp.ts = ps_ts;
+        return pp;
+    }
+
     // GptNeoXDecoder::forward (GptNeoXDecoder.cc:245-384)
     void decoder(int B, int s_max)
     {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         const double wbytes  = int8 ? 1.0 : 2.0;
+        if (pplan.ok) {
+            // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
+            // there is no collective between the layers
+            PersistParams pp = persist_params(B, s_max);
+            const double layer_bytes = wbytes * ((double)H * 3 * hl + (double)H * il + (double)hl * H + (double)il * H);
+            if (cfg.tensor_para_size == 1 && !persist_per_layer) {
+                pp.l_begin = 0;
+                pp.l_end   = L;
+                timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_persistent(pp, int8, stream); });
+            }
+            else {
+                for (int l = 0; l < L; l++) {
+                    pp.l_begin = l;
+                    pp.l_end   = l + 1;
+                    timed(KIND_PERSIST, layer_bytes, [&] { launch_decode_persistent(pp, int8, stream); });
+                    allreduce(x, (size_t)B * H);
+                }
+            }
+            return;
+        }
         for (int l = 0; l < L; l++) {
             const LayerWeights& w = layers[l];
             // layer_input/output alias for 0 < l < L-1 in the reference (:249-250) -> which residual form it runs
@@ -689,7 +773,7 @@ struct ftcf_gptneox {
                 f.NT0 = 0;
                 f.NT1 = il / 16;
                 f.blocks0 = 0;
-                f.blocks1 = (f.NT1 + 3) / 4;
+                f.blocks1 = f.NT1 / 2;  // two column groups per workgroup (NT1 is even: local inter is a multiple of 64)
                 f.eps = 1e-5f;
                 timed(KIND_FUSED, wbytes * H * (double)il, [&] { launch_mmha_ln_gemv(mp, f, int8, B, stream); });
                 const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
@@ -860,6 +944,34 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
     FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, B <= 4 ? B : 1, 8), stream));
+    if (pplan.ok) {
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        std::vector<PersistLayer> pl(L);
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            PersistLayer&       r = pl[l];
+            r.ln1_g = w.ln1_g;
+            r.ln1_b = w.ln1_b;
+            r.ln2_g = w.ln2_g;
+            r.ln2_b = w.ln2_b;
+            r.w_qkv = w.qkv.kernel;
+            r.w_ffn1 = w.ffn1.kernel;
+            r.w_out = w.attn_out.kernel;
+            r.w_ffn2 = w.ffn2.kernel;
+            r.s_qkv = w.qkv.scale;
+            r.s_ffn1 = w.ffn1.scale;
+            r.s_out = w.attn_out.scale;
+            r.s_ffn2 = w.ffn2.scale;
+            r.b_qkv = w.qkv.bias;
+            r.b_ffn1 = w.ffn1.bias;
+            r.b_res = w.ffn2.bias;
+            r.k_cache = k_cache + l * cache_l;
+            r.v_cache = v_cache + l * cache_l;
+        }
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_players, pl.data(), sizeof(PersistLayer) * L, hipMemcpyHostToDevice, stream));
+        FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
+        FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // `pl` dies at scope exit
+    }
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
     if (S > 1) {
         launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
@@ -1043,6 +1155,10 @@ void ftcf_gptneox::finish()
     if (a.cum_log_probs) {
         FTCF_HIP_CHECK(hipMemcpyAsync(a.cum_log_probs, cum, (size_t)ses.B * 4, hipMemcpyDeviceToDevice, stream));
     }
+    int ps_error = 0;
+    if (pplan.ok) {
+        FTCF_HIP_CHECK(hipMemcpyAsync(&ps_error, ps_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    }
     FTCF_HIP_CHECK(hipStreamSynchronize(stream));
     float ms = 0.f;
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ses.e0, ses.e1));
@@ -1056,6 +1172,20 @@ void ftcf_gptneox::finish()
         ses.graph_exec = nullptr;
     }
     drain_events();
+    if (pplan.ok && ps_ts) {
+        std::vector<long long> h((size_t)pplan.NB * L * 32);
+        FTCF_HIP_CHECK(hipMemcpy(h.data(), ps_ts, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(ps_ts_file.c_str(), "wb")) {
+            const int hdr[4] = {pplan.NB, L, 2, 16};
+            fwrite(hdr, 4, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+    if (ps_error != 0) {
+        throw Error(-2, "persistent decode kernel gave up waiting for a hand-off (code " + std::to_string(ps_error)
+                            + "): not every workgroup was resident");
+    }
 }
 
 extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gptneox_weights* w, ftcf_gptneox_t* out)
@@ -1164,6 +1294,26 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_K1_WPG")) {
             e->k1_wpg = atoi(m);
+        }
+        {
+            hipDeviceProp_t prop;
+            FTCF_HIP_CHECK(hipGetDeviceProperties(&prop, cfg->device));
+            e->num_cu = prop.multiProcessorCount;
+        }
+        if (const char* m = getenv("FTCF_PERSIST")) {
+            e->persist = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_PER_LAYER")) {
+            e->persist_per_layer = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_TS")) {
+            e->ps_ts_file = m;
+        }
+        if (const char* m = getenv("FTCF_PERSIST_NB")) {
+            e->persist_nb = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_CTRL_SHARE")) {
+            e->persist_ctrl_share = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_USE_GRAPH")) {

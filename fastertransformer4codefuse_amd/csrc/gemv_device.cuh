@@ -278,19 +278,24 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
 // Segment 0 blocks are [0, NT0), segment 1 blocks [NT0, NT0 + NT1).
 // ---------------------------------------------------------------------------------------------------------------
 template<bool INT8, int M>
-__device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char* smem, const int block_id)
+__device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char* smem, const int block_id,
+                                                    const int gpb = 1)
 {
+    // gpb column groups per workgroup (the waves are dealt to the groups evenly; NT0 must be a multiple of gpb)
     const int nw   = blockDim.x >> 6;
+    const int wpg  = nw / gpb;
     f16*      xs   = reinterpret_cast<f16*>(smem);                          // [M][K]
     float*    red  = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*nw floats (LN), then [nw][M][16]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int seg  = (block_id >= p.NT0) ? 1 : 0;
-    const int grp  = seg ? block_id - p.NT0 : block_id;
+    const int gsel = wid / wpg, kw = wid - gsel * wpg;
+    const int gi   = block_id * gpb + gsel;
+    const int seg  = (gi >= p.NT0) ? 1 : 0;
+    const int grp  = seg ? gi - p.NT0 : gi;
     const int K    = p.K;
     constexpr int TK = TileK<INT8>::value;
     const int     KT = K / TK;
     const int     c = lane & 15, g = lane >> 4;
-    const int     t0 = (int)((long)KT * wid / nw), t1 = (int)((long)KT * (wid + 1) / nw);
+    const int     t0 = (int)((long)KT * kw / wpg), t1 = (int)((long)KT * (kw + 1) / wpg);
     const int     nt = t1 - t0;
     const char*   wbase = reinterpret_cast<const char*>(seg ? p.W1 : p.W0);
     const u32x4*  wp    = reinterpret_cast<const u32x4*>(wbase + (((size_t)grp * KT + t0) * 64 + lane) * 16);
@@ -390,16 +395,19 @@ __device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char*
         }
     }
     __syncthreads();
-    if (threadIdx.x < M * 16) {
-        const int m = threadIdx.x >> 4, cc = threadIdx.x & 15;
-        const int nn = grp * 16 + cc;
-        float     v  = 0.f;
-        for (int w = 0; w < nw; w++) {
+    if (threadIdx.x < gpb * M * 16) {
+        const int gs = threadIdx.x / (M * 16), r = threadIdx.x - gs * (M * 16);
+        const int m = r >> 4, cc = r & 15;
+        const int go   = block_id * gpb + gs;
+        const int oseg = (go >= p.NT0) ? 1 : 0;
+        const int nn   = (oseg ? go - p.NT0 : go) * 16 + cc;
+        float     v    = 0.f;
+        for (int w = gs * wpg; w < (gs + 1) * wpg; w++) {
             v += part[(w * M + m) * 16 + cc];
         }
-        f16*      out = seg ? p.out1 : p.out0;
-        const int N   = (seg ? p.NT1 : p.NT0) * 16;
-        if (seg == 1) {
+        f16*      out = oseg ? p.out1 : p.out0;
+        const int N   = (oseg ? p.NT1 : p.NT0) * 16;
+        if (oseg == 1) {
             if constexpr (INT8) {
                 out[(size_t)m * N + nn] = (f16)gelu_f32(v + (float)p.bias1[nn]);  // epilogue_helpers.h:52-62
             }

@@ -120,6 +120,53 @@ void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* 
 // ---- fused attention + FFN1 weight stream : kernels_fused.hip ----
 void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8, int M, hipStream_t s);
 
+// ---- persistent decode layers : kernels_persist.hip ----
+// One launch runs layers [l_begin, l_end) of the m <= 2 decode step on ONE resident workgroup per CU; the stages of a
+// layer hand their vectors over inside the launch (sc1 stores + counters, {tag,value} granules) and every wave already
+// holds the first weight batches of the next stage while the hand-off is in flight.
+struct PersistLayer {
+    const f16 *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const void *w_qkv, *w_ffn1, *w_out, *w_ffn2;  // engine tile images
+    const f16 *s_qkv, *s_ffn1, *s_out, *s_ffn2;   // int8 scales
+    const f16 *b_qkv, *b_ffn1, *b_res;            // qkv bias (added by attention), ffn1 bias, residual-epilogue bias
+    f16 *      k_cache, *v_cache;                 // [B, nh, s_max, dh] of this layer
+};
+struct PersistPlan {
+    int    ok;        // 0: shape not eligible (caller uses the per-kernel path)
+    int    NB;        // workgroups (<= CUs)
+    int    nsplit;    // split-KV factor of the attention stage
+    int    PA, PB;    // K pieces per 16-column group of out-proj / FFN2
+    int    RLa, RLb;  // tiles per piece
+    int    xs_halves; // LDS x region
+    int    e1, e3;    // tile-table entries per wave (P1 / P3)
+    int    ctrl_share;
+    size_t smem;
+};
+struct PersistParams {
+    const PersistLayer* layers;  // device array [L]
+    int                 L, l_begin, l_end;
+    const f16*          x_in;        // [M][H] input of layer l_begin (plain memory)
+    f16*                x_out;       // [M][H] output of layer l_end-1
+    // granule slabs (pairs of halves unless noted): qkv [M][3Hl/2], mid [M][Il/2], ctx [M][Hl/2], x' [M][H/2],
+    // K pieces [NG*(PA+PB)][M*16] (fp32), attention partials [B][nh][nsplit][dh+2] (fp32); zero at request start
+    unsigned long long *gq, *gm, *gc, *gx, *gp, *ga;
+    int*                err;              // sticky give-up flag (0 = fine)
+    int                 H, Hl, Il, nh, dh, rot, s_max, B, tp;
+    PersistPlan         plan;
+    const int*          d_step;
+    const int*          seq_len;
+    const int*          pad_count;
+    const uint8_t*      masked_tokens;
+    const uint8_t*      finished;
+    const float*        rot_table;
+    float               eps;
+    int                 ctrl_share;  // stream share of the two control waves in 1/16 of a streamer wave's
+    long long*          ts;          // optional [NB][L][2][16] wall-clock stamps (100 MHz) of wave 0 / wave 2, or NULL
+};
+PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
+                         int ctrl_share);
+void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
+
 // ---- dynamic decode : kernels_sampling.hip ----
 struct DecodeState {  // device resident, one per engine
     int step;         // current step (max_input_len .. total-1)

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_mmha_ln_gemv(const MmhaParams ap, const
     const int      bid    = (int)blockIdx.x;
     if (bid < n_gemv) {
         if (n_attn >= 0) {
-            ln_gemv_block<INT8, M>(gp, smem, bid);
+            ln_gemv_group_block<INT8, M>(gp, smem, bid, 2);  // 2 column groups x 2 K-halves per 4-wave workgroup
         }
     }
     else {
@@ -38,7 +38,7 @@ static void launch_m(const MmhaParams& ap, const LnGemvParams& gp, hipStream_t s
 {
     const int    n_attn = ap.nh * ap.B * ap.nsplit;
     const size_t smem_a = mmha_smem_bytes(ap.dh, ap.s_max, ap.nsplit);
-    const size_t smem_g = (size_t)M * gp.K * 2 + 64;
+    const size_t smem_g = (size_t)M * gp.K * 2 + (2 * 4 + 4 * M * 16) * sizeof(float);
     const size_t smem   = std::max(smem_a, smem_g);
     static const int dbg = getenv("FTCF_K2_DEBUG") ? atoi(getenv("FTCF_K2_DEBUG")) : 0;  // timing experiments only
     int grid = n_attn + gp.blocks0 + gp.blocks1;

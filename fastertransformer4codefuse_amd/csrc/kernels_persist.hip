@@ -1,0 +1,1402 @@
+// Persistent decode layers (m <= 2 rows): ONE launch runs layers [l_begin, l_end) of the decode step of
+// GptNeoXDecoder<T>::forward (models/gptneox/GptNeoXDecoder.cc:245-384) on one resident 8-wave workgroup per CU.
+//
+// Why: as separate launches every stage pays its own ramp and tail (the last waves of a grid stream alone while the rest
+// of the chip idles) and the attention's latency chain sits on the critical path; measured 25 of 75 us per layer.  Inside
+// one launch the weight stream of the NEXT stage is already in flight (four register batches per wave, 32 KiB) while the
+// vectors of the previous stage are handed over, so HBM stays busy across the dependency edges.
+//
+// Stages of a layer (all workgroups run all stages, SPMD):
+//   S0  gather the layer input x (granules published by the previous layer's mergers), LN1 / LN2
+//   P1  stream [QKV u FFN1] column groups -> qkv (no bias, like the reference's MMHA), mid = gelu(.+b)
+//   AT  split-KV attention of one (row, head, split) per workgroup -> ctx
+//   P3  stream [FFN2 pieces, then out-proj pieces] -> fp32 partials; the owner of a group's last out-proj piece merges
+//       them in fixed order, applies invokeAddBiasAttentionFfnResidual and publishes x' for the next layer
+// Every hand-off is made of 8-byte {tag, value} GRANULES (cdna_hip_programming.md G16 recipe R2): one relaxed agent-scope
+// (sc1, write-through) store per granule, consumers re-read until every tag matches -- no flag, fence, drain or counter
+// (a first version with drained counters spent 15 us per edge in the 256 -> 1 fan-in and its pollers).  A consumer only
+// sweeps the slice it needs: an attention workgroup its head's q/k/v (192 granules), a P3 workgroup the K range of its
+// pieces (mid: 1280, ctx: 640 granules at CodeFuse-13B), every workgroup the layer input x (2560).
+// Waves 0..1 are "control" waves: they do the latency-critical sweeps and therefore start their weight prefetch last;
+// a wave's memory returns are in order, so a sweep issued behind 32 KiB of prefetch would wait for all of it.  For the
+// same reason the per-layer constants (scales, biases, LayerNorm parameters) are fetched into registers one stage
+// ahead, before that stage's prefetch is issued.
+// The work split is static: a workgroup owns whole runs (a column group, or a K piece of one), its waves cut the runs'
+// tiles back to back into contiguous shares, and per-wave tile tables (built once per launch in LDS) drive the stream.
+// Every spin is bounded (PS_SPIN) and reports through PersistParams::err instead of hanging the GPU.
+#include <type_traits>
+
+#include "attn_device.cuh"
+#include "gemv_device.cuh"
+
+namespace ftcf {
+
+constexpr int PS_NW       = 8;           // waves per workgroup (2 per SIMD -> 256 VGPRs each)
+constexpr int PS_NT       = PS_NW * 64;
+constexpr int PS_NC       = 2;           // control waves
+constexpr int PS_U        = 8;           // tiles per register batch
+constexpr int PS_NBUF     = 4;           // register batches per wave (3 in flight while one is consumed)
+constexpr int PS_RMAX     = 24;          // runs per workgroup and stage
+constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
+constexpr int PS_MAXP     = 16;          // PA + PB
+constexpr int PS_SPIN     = 1 << 18;
+constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane
+constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
+
+#define PS_RLX __ATOMIC_RELAXED
+#define PS_AGT __HIP_MEMORY_SCOPE_AGENT
+// pointers that come out of the per-layer table in memory are GLOBAL: say so (a flat access also counts on lgkmcnt)
+#define PS_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
+
+// consume-table entry: bits 0..16 LDS half offset of the tile's x, 17..21 run, 22 flush after, 23 valid, 24 x stride select
+constexpr unsigned PS_CT_FLUSH = 1u << 22, PS_CT_VALID = 1u << 23, PS_CT_XSEL = 1u << 24;
+// batch-table entry: bit 0 fast (PS_U valid tiles of one run), 1 flush after the batch, 2..6 run, 8..24 x offset, 25 stride select
+constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25;
+
+struct RunRec {  // static per launch (LDS)
+    int tile0;  // first tile of the run inside its weight array
+    int sel;    // weight array of the stage (0 / 1)
+    int nt;     // tiles
+    int xoff;   // LDS half offset (inside the x region) of the run's first k
+    int xsel;   // x row stride select
+    int rid;    // stage specific id (P1: combined group, P3: global piece id)
+    int grp;    // 16-column group
+    int pad;
+};
+
+__device__ __forceinline__ int ps_rfl(int v)
+{
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void st_granule_u32(u64* g, unsigned tag, unsigned v)
+{
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)v, PS_RLX, PS_AGT);
+}
+__device__ __forceinline__ unsigned short f16_bits(f16 v)
+{
+    return __builtin_bit_cast(unsigned short, v);
+}
+__device__ __forceinline__ f16 bits_f16(unsigned v)
+{
+    return __builtin_bit_cast(f16, (unsigned short)(v & 0xffffu));
+}
+__device__ __forceinline__ bool ps_give_up(int& spins, int* err, const int code)
+{
+    if (++spins > PS_SPIN) {
+        __hip_atomic_store(err, code, PS_RLX, PS_AGT);
+        return true;
+    }
+    return (spins & 255) == 0 && __hip_atomic_load(err, PS_RLX, PS_AGT) != 0;
+}
+// `nthr` threads (whole waves, tid = 0..nthr-1) re-read granules [0, n) of `g` until every tag matches, NPER granules
+// per thread and pass, and hand the 32-bit payloads to sink(index, value)
+template<int NPER, typename F>
+__device__ __forceinline__ void ps_sweep(const u64* g, const int n, const int tid, const int nthr, const unsigned tag,
+                                         int* err, const int code, F&& sink)
+{
+    for (int base = 0; base < n; base += nthr * NPER) {
+        u64 gv[NPER];
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NPER; k++) {
+                const int i = base + k * nthr + tid;
+                gv[k]       = ld_granule(&g[i < n ? i : n - 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < NPER; k++) {
+                ok &= ((unsigned)(gv[k] >> 32) == tag);
+            }
+            if (__all(ok)) {
+                break;
+            }
+            if (ps_give_up(spins, err, code)) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < NPER; k++) {
+            const int i = base + k * nthr + tid;
+            if (i < n) {
+                sink(i, (unsigned)gv[k]);
+            }
+        }
+    }
+}
+
+// wave w's share of T tiles: control waves get cs/16 of a streamer wave's share
+__host__ __device__ inline void ps_wave_range(const int T, const int w, const int cs, int& tb, int& te)
+{
+    const int total = PS_NC * cs + (PS_NW - PS_NC) * 16;
+    const int c0    = (w < PS_NC) ? w * cs : PS_NC * cs + (w - PS_NC) * 16;
+    const int c1    = c0 + ((w < PS_NC) ? cs : 16);
+    tb              = (int)((long)T * c0 / total);
+    te              = (int)((long)T * c1 / total);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight stream of one wave over its share [tb, te) of the workgroup's flat tile space, driven by two per-wave LDS
+// tables: lt[i] = {weight array select, tile index}, ct[i] = {x offset, run, flush, valid}.  PS_NBUF register batches
+// of PS_U tiles rotate; the tables are padded to a whole number of rotations with entries that re-read tile 0 of the
+// stage (an L2 / MALL hit, never HBM) and are not consumed, so the loop has NO conditional load: the compiler counts
+// vmcnt exactly and three batches stay in flight while one is consumed.  The accumulator is flushed to
+// part[run][wave] after the last tile of the wave's piece of a run (a wave meets a run in ONE contiguous piece).
+// ---------------------------------------------------------------------------------------------------------------
+struct PsStage {
+    const unsigned *lt, *ct, *bt;  // per tile: load / consume entries; per batch: fast-path descriptor
+    int             nrot;  // rotations (PS_NBUF batches each), >= 1
+    const char *    w0, *w1;
+    int             xs0, xs1;
+};
+
+template<bool INT8, int M>
+struct PsStream {
+    static constexpr int TK = TileK<INT8>::value;
+    u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
+    f32x4      acc;
+    PsStage    g;
+    const f16* rsc;
+    const f16* xs;
+    float*     part;
+    int        lane, wid;
+
+    __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx)
+    {
+        g    = g_;
+        rsc  = rsc_;
+        xs   = xs_;
+        part = part_;
+        lane = tx & 63;
+        wid  = ps_rfl(tx >> 6);
+        acc  = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void load(u32x4 (&r)[PS_U], const int i)
+    {
+#pragma unroll
+        for (int u = 0; u < PS_U; u++) {
+            const unsigned e    = g.lt[i * PS_U + u];
+            const char*    base = (e >> 31) ? g.w1 : g.w0;
+            r[u] = __builtin_nontemporal_load(
+                (const __attribute__((address_space(1))) u32x4*)(base + ((size_t)(e & 0x7fffffffu) * 64 + lane) * 16));
+        }
+    }
+    __device__ __forceinline__ void flush(const int j)
+    {
+        if (lane < 16) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                part[((size_t)j * PS_NW + wid) * (M * 16) + m * 16 + lane] = acc_row(acc, m);
+            }
+        }
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void consume(const u32x4 (&r)[PS_U], const int i)
+    {
+        const unsigned bd = (unsigned)ps_rfl((int)g.bt[i]);
+        if (bd & PS_BT_FAST) {
+            // all PS_U tiles valid, one run, consecutive k: straight-line code like the per-kernel GEMV stream
+            const int  j   = (bd >> 2) & 31;
+            const f16* xr  = a_frag_ptr<INT8, M>(xs + ((bd >> 8) & 0x1ffffu), (bd & PS_BT_XSEL) ? g.xs1 : g.xs0, lane);
+            f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
+            if constexpr (INT8) {
+                const f16 sc = rsc[j * 16 + (lane & 15)];
+                sc2          = f16x2{sc, sc};
+            }
+#pragma unroll
+            for (int u = 0; u < PS_U; u++) {
+                consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
+            }
+            if (bd & PS_BT_FLUSH) {
+                flush(j);
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < PS_U; u++) {
+            const unsigned d = (unsigned)ps_rfl((int)g.ct[i * PS_U + u]);
+            if (d & PS_CT_VALID) {
+                const int  j   = (d >> 17) & 31;
+                const f16* xr  = a_frag_ptr<INT8, M>(xs + (d & 0x1ffffu), (d & PS_CT_XSEL) ? g.xs1 : g.xs0, lane);
+                f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
+                if constexpr (INT8) {
+                    const f16 sc = rsc[j * 16 + (lane & 15)];
+                    sc2          = f16x2{sc, sc};
+                }
+                consume_tile<INT8, M>(r[u], xr, sc2, acc);
+                if (d & PS_CT_FLUSH) {
+                    flush(j);
+                }
+            }
+        }
+    }
+    // the first rotation: issued before the hand-off this stage waits for
+    __device__ __forceinline__ void prime()
+    {
+        load(R0, 0);
+        load(R1, 1);
+        load(R2, 2);
+        load(R3, 3);
+    }
+    __device__ __forceinline__ void run()
+    {
+        const int last = (g.nrot - 1) * PS_NBUF;
+        for (int i = 0; i < last; i += PS_NBUF) {
+            consume(R0, i);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R0, i + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R1, i + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R2, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R2, i + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R3, i + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R3, i + 7);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        consume(R0, last);
+        consume(R1, last + 1);
+        consume(R2, last + 2);
+        consume(R3, last + 3);
+    }
+};
+
+// one wave fills its tile tables for a stage from the workgroup's static run table (entries past the share: dummy)
+template<int TK>
+__device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
+                                                unsigned* lt, unsigned* ct, const int entries)
+{
+    const int lane = threadIdx.x & 63;
+    const int n    = te - tb;
+    for (int i = lane; i < entries; i += 64) {
+        unsigned l = 0u, c = 0u;  // dummy: tile 0 of array 0, not valid
+        if (i < n) {
+            const int t = tb + i;
+            int       j = 0, pre = 0;
+            while (j + 1 < nruns && t >= pre + rt[j].nt) {
+                pre += rt[j].nt;
+                j++;
+            }
+            const RunRec r   = rt[j];
+            const int    off = t - pre;
+            const int    se  = te < pre + r.nt ? te : pre + r.nt;
+            l = ((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off);
+            c = (unsigned)(r.xoff + off * TK) | ((unsigned)j << 17) | ((t + 1 == se) ? PS_CT_FLUSH : 0u) | PS_CT_VALID
+                | (r.xsel ? PS_CT_XSEL : 0u);
+        }
+        lt[i] = l;
+        ct[i] = c;
+    }
+}
+
+// after the consume tables are visible: one descriptor per batch
+__device__ __forceinline__ void ps_build_batches(const unsigned* ct, unsigned* bt, const int nbatch)
+{
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < nbatch; i += 64) {
+        const unsigned d0   = ct[i * PS_U];
+        bool           fast = true;
+#pragma unroll
+        for (int u = 0; u < PS_U; u++) {
+            const unsigned d = ct[i * PS_U + u];
+            fast = fast && (d & PS_CT_VALID) && (((d >> 17) & 31) == ((d0 >> 17) & 31))
+                   && (u == PS_U - 1 || !(d & PS_CT_FLUSH));
+        }
+        const unsigned dl = ct[i * PS_U + PS_U - 1];
+        bt[i] = fast ? (PS_BT_FAST | ((dl & PS_CT_FLUSH) ? PS_BT_FLUSH : 0u) | (((d0 >> 17) & 31) << 2)
+                        | ((d0 & 0x1ffffu) << 8) | ((d0 & PS_CT_XSEL) ? PS_BT_XSEL : 0u))
+                     : 0u;
+    }
+}
+
+struct PsSmem {
+    f16*      xraw;  // [M][H]
+    f16*      xs;    // x region (P1: LN1(x) | LN2(x) ; P3: mid | ctx)
+    float*    part;  // [RMAX][NW][M*16]
+    char*     att;   // attention scratch
+    RunRec*   rt1;   // [RMAX] P1 runs
+    RunRec*   rt3;   // [RMAX] P3 runs
+    f16*      rsc;   // [RMAX][16] scales of the current stage
+    float*    red;   // 64
+    int*      misc;  // 64: [0] nmerge, [1..8] merge groups
+    unsigned *lt1, *ct1, *lt3, *ct3;  // [NW][e1], [NW][e3]
+    unsigned *bt1, *bt3;              // [NW][e1 / PS_U], [NW][e3 / PS_U]
+};
+
+__host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
+{
+    const int chunk = ((((s_max + nsplit - 1) / nsplit) + 15) & ~15);
+    size_t    a     = (size_t)3 * dh * 2 + (size_t)(2 * PS_NW + PS_NW * dh) * 4 + (size_t)chunk * 4;
+    size_t    b     = (size_t)(nsplit * (dh + 2) + nsplit + 4) * 4;
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention of one (row b, head h, split sp) on the whole 8-wave workgroup
+// (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.cuh::mmha_partial)
+// ---------------------------------------------------------------------------------------------------------------
+template<int DH>
+struct PsAttn {
+    static constexpr int LPK = DH / 8;
+    static constexpr int KPI = 64 / LPK;
+    u32x4 kreg[PS_UK], vreg[PS_UK];
+    unsigned mask_bits, bias2;
+    int      tl, chunk, t_beg;
+    float    rot_cs, rot_sn;
+    bool     fin;
+
+    // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table
+    __device__ __forceinline__ void issue(const PersistParams& p, const PersistLayer& lw, int h, int b, int sp, const int tx)
+    {
+        const int lane = tx & 63, wid = tx >> 6;
+        const int sub = lane % LPK, grp = lane / LPK;
+        chunk = (((p.s_max + p.plan.nsplit - 1) / p.plan.nsplit) + 15) & ~15;
+        t_beg = sp * chunk;
+        const auto* kc = PS_G(f16, lw.k_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
+        const auto* vc = PS_G(f16, lw.v_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
+#pragma unroll
+        for (int u = 0; u < PS_UK; u++) {
+            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            t       = t < p.s_max ? t : p.s_max - 1;
+            kreg[u] = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PS_UK; u++) {
+            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            t       = t < p.s_max ? t : p.s_max - 1;
+            vreg[u] = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+        }
+        mask_bits = 0u;
+        if (p.masked_tokens && sub == 0) {
+#pragma unroll
+            for (int u = 0; u < PS_UK; u++) {
+                int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+                t     = t < p.s_max ? t : p.s_max - 1;
+                mask_bits |= (p.masked_tokens[(size_t)b * p.s_max + t] ? 1u : 0u) << u;
+            }
+        }
+        rot_cs = 1.f;
+        rot_sn = 0.f;
+        if (p.rot > 0 && tx < p.rot / 2) {
+            rot_cs = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2];
+            rot_sn = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2 + 1];
+        }
+        bias2 = 0u;
+        if (tx < 3 * DH / 2) {  // this thread's pair of q / k / v bias values (sweep_qkv)
+            const int seg = tx / (DH / 2), i = tx % (DH / 2);
+            bias2 = *PS_G(unsigned, reinterpret_cast<const unsigned*>(lw.b_qkv + (size_t)seg * p.nh * DH + h * DH) + i);
+        }
+        fin = p.finished && p.finished[b];
+        tl  = p.seq_len[b];
+    }
+    // q/k/v of the current token: granules published by the QKV stage of THIS launch (pairs of halves); + bias -> LDS
+    __device__ __forceinline__ void sweep_qkv(const PersistParams& p, char* smem, const unsigned tag, int h, int b, const int tx)
+    {
+        if (fin) {
+            return;
+        }
+        f16* s_q = reinterpret_cast<f16*>(smem);  // [DH] q | [DH] k | [DH] v
+        if (tx < 3 * DH / 2) {
+            const int  seg = tx / (DH / 2), i = tx % (DH / 2);
+            const int  hl  = p.nh * DH;
+            const u64* g   = p.gq + ((size_t)b * 3 * hl + (size_t)seg * hl + h * DH) / 2 + i;
+            u64        v;
+            int        spins = 0;
+            for (;;) {
+                v = ld_granule(g);
+                if ((unsigned)(v >> 32) == tag) {
+                    break;
+                }
+                if (++spins > PS_SPIN) {
+                    __hip_atomic_store(p.err, 5, PS_RLX, PS_AGT);
+                    break;
+                }
+                if ((spins & 255) == 0 && __hip_atomic_load(p.err, PS_RLX, PS_AGT) != 0) {
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const f16 x0 = bits_f16((unsigned)v), x1 = bits_f16((unsigned)v >> 16);
+            s_q[seg * DH + 2 * i]     = x0 + bits_f16(bias2);
+            s_q[seg * DH + 2 * i + 1] = x1 + bits_f16(bias2 >> 16);
+        }
+    }
+    // returns false when the row is finished (nothing published)
+    __device__ __forceinline__ bool compute(const PersistParams& p, const PersistLayer& lw, char* smem, u64* gout,
+                                            const unsigned tag, int h, int b, const int tx)
+    {
+        const int lane = tx & 63, wid = tx >> 6;
+        const int sub = lane % LPK, grp = lane / LPK;
+        if (fin) {
+            return false;  // :1176
+        }
+        int t_end = t_beg + chunk;
+        if (t_end > tl + 1) {
+            t_end = tl + 1;
+        }
+        if (t_beg > tl) {  // empty split
+            if (tx < DH) {
+                st_granule(&gout[tx], tag, 0.f);
+            }
+            if (tx == 0) {
+                st_granule(&gout[DH], tag, -INFINITY);
+                st_granule(&gout[DH + 1], tag, 0.f);
+            }
+            return true;
+        }
+        const bool owns_cur     = (tl >= t_beg && tl < t_end);
+        const int  t_cached_end = owns_cur ? tl : t_end;
+        f16*   s_q   = reinterpret_cast<f16*>(smem);
+        f16*   s_k   = s_q + DH;
+        f16*   s_v   = s_k + DH;
+        float* s_red = reinterpret_cast<float*>(s_v + DH);  // [2*NW + NW*DH]
+        float* s_p   = s_red + 2 * PS_NW + PS_NW * DH;      // [chunk]
+        __syncthreads();  // q | k | v (+ bias) written by sweep_qkv
+        if (p.rot > 0 && tx < p.rot / 2) {
+            const int j = tx;
+            f16       a = s_q[j], c = s_q[j + p.rot / 2];
+            rotary_apply(a, c, rot_cs, rot_sn);
+            s_q[j]             = a;
+            s_q[j + p.rot / 2] = c;
+            if (owns_cur) {
+                f16 ka = s_k[j], kc2 = s_k[j + p.rot / 2];
+                rotary_apply(ka, kc2, rot_cs, rot_sn);
+                s_k[j]             = ka;
+                s_k[j + p.rot / 2] = kc2;
+            }
+        }
+        __syncthreads();
+        if (owns_cur && tx < DH) {  // append to the cache (:1397, :1837)
+            ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
+            ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
+        }
+        const float inv_sqrt_dh = rsqrtf((float)DH);
+        const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+        float       lmax        = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < PS_UK; u++) {
+            const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            const f16x8 kv = __builtin_bit_cast(f16x8, kreg[u]);
+            float       a  = 0.f;
+            a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
+            a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
+            a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
+            a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
+            a              = group_sum(a, LPK) * inv_sqrt_dh;
+            if (t < t_cached_end && sub == 0) {
+                const bool m   = ((mask_bits >> u) & 1u) != 0u;
+                s_p[t - t_beg] = m ? -INFINITY : a;
+                if (!m) {
+                    lmax = fmaxf(lmax, a);
+                }
+            }
+        }
+        if (owns_cur && wid == 0) {  // current token from LDS (:1407-1437)
+            float a = 0.f;
+            if (lane < LPK) {
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
+                const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
+                a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
+                a              = dot2(f16x2{q8[2], q8[3]}, f16x2{kv[2], kv[3]}, a);
+                a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
+                a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
+            }
+            a = wave_sum(a) * inv_sqrt_dh;
+            if (lane == 0) {
+                s_p[tl - t_beg] = a;
+                lmax            = fmaxf(lmax, a);
+            }
+        }
+        lmax = wave_max(lmax);
+        if (lane == 0) {
+            s_red[wid] = lmax;
+        }
+        __syncthreads();
+        float m_loc = s_red[0];
+#pragma unroll
+        for (int w = 1; w < PS_NW; w++) {
+            m_loc = fmaxf(m_loc, s_red[w]);
+        }
+        float lsum = 0.f;
+        for (int i = tx; i < t_end - t_beg; i += PS_NT) {
+            const float e = (s_p[i] == -INFINITY) ? 0.f : __expf(s_p[i] - m_loc);
+            s_p[i]        = e;
+            lsum += e;
+        }
+        lsum = wave_sum(lsum);
+        __syncthreads();
+        if (lane == 0) {
+            s_red[PS_NW + wid] = lsum;
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < PS_UK; u++) {
+            const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
+                const float pt = s_p[t - t_beg];
+                const f16x8 vv = __builtin_bit_cast(f16x8, vreg[u]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+                }
+            }
+        }
+        if (owns_cur && wid == 0 && grp == 0) {
+            const float pt = s_p[tl - t_beg];
+            const f16x8 vv = *reinterpret_cast<const f16x8*>(s_v + sub * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            for (int o = LPK; o < 64; o <<= 1) {
+                acc[j] += __shfl_xor(acc[j], o, 64);
+            }
+        }
+        float* s_o = s_red + 2 * PS_NW;  // [NW][DH]
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                s_o[wid * DH + sub * 8 + j] = acc[j];
+            }
+        }
+        __syncthreads();
+        if (tx < DH) {
+            const int d = tx;
+            float     o = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_NW; w++) {
+                o += s_o[w * DH + d];
+            }
+            st_granule(&gout[d], tag, o);
+        }
+        if (tx == 0) {
+            float ls = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_NW; w++) {
+                ls += s_red[PS_NW + w];
+            }
+            st_granule(&gout[DH], tag, m_loc);
+            st_granule(&gout[DH + 1], tag, ls);
+        }
+        return true;
+    }
+};
+
+// split-0 workgroup of a (row, head): wave 0 sweeps the nsplit partials, merges in split order, stores ctx (sc1)
+template<int DH>
+__device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem, u64* gall, const unsigned tag, int h,
+                                              int b, const int tx)
+{
+    const int ne = DH + 2, ns = p.plan.nsplit;
+    const int ng = ns * ne;
+    float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
+    __syncthreads();                                  // scratch reuse
+    if (tx < 64) {
+        for (int base = 0; base < ng; base += 64 * 8) {
+            u64 gv[8];
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = base + k * 64 + tx;
+                    gv[k]       = ld_granule(&gall[i < ng ? i : ng - 1]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    ok &= ((unsigned)(gv[k] >> 32) == tag);
+                }
+                if (__all(ok)) {
+                    break;
+                }
+                if (++spins > PS_SPIN) {
+                    __hip_atomic_store(p.err, 2, PS_RLX, PS_AGT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = base + k * 64 + tx;
+                if (i < ng) {
+                    sval[i] = __uint_as_float((unsigned)gv[k]);
+                }
+            }
+        }
+        // weights (same wave: DS operations of one wave execute in order)
+        float ms = -INFINITY, ls = 0.f;
+        if (tx < ns) {
+            ms = sval[tx * ne + DH];
+            ls = sval[tx * ne + DH + 1];
+        }
+        const float m = wave_max(ms);
+        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+        float*      sw = sval + ns * ne;
+        if (tx < ns) {
+            sw[tx] = w;
+        }
+        float L = 0.f;
+        for (int s2 = 0; s2 < ns; s2++) {
+            L += __shfl(w * ls, s2, 64);
+        }
+        if (tx == 0) {
+            sw[ns] = L;
+        }
+    }
+    __syncthreads();
+    if (tx < DH) {
+        const float* sw = sval + ns * ne;
+        const int    d  = tx;
+        float        o  = 0.f;
+        for (int s2 = 0; s2 < ns; s2++) {
+            o += sw[s2] * sval[s2 * ne + d];
+        }
+        const float    inv = 1.f / (sw[ns] + 1.e-6f);  // :1632
+        const unsigned b0  = f16_bits((f16)(o * inv));
+        const unsigned b1  = __shfl_down(b0, 1, 64);
+        if ((d & 1) == 0) {
+            st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
+        }
+    }
+}
+
+// finished row: its ctx is never consumed (:1176) but the out-proj stage still waits for the granules
+template<int DH>
+__device__ __forceinline__ void ps_attn_publish_zero(const PersistParams& p, const unsigned tag, int h, int b, const int tx)
+{
+    if (tx < DH / 2) {
+        st_granule_u32(&p.gc[(((size_t)b * p.nh * DH + h * DH) >> 1) + tx], tag, 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template<bool INT8, int M, int DH>
+__global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TK = TileK<INT8>::value;
+    const int     H = p.H, Hl = p.Hl, Il = p.Il;
+    const int     NB = p.plan.NB, bid = blockIdx.x;
+    const int     lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int     KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK;
+    const int     NT0 = 3 * Hl / 16, NG = H / 16;
+    const int     PA = p.plan.PA, PB = p.plan.PB, RLa = p.plan.RLa, RLb = p.plan.RLb;
+    const int     E1 = p.plan.e1, E3 = p.plan.e3;
+
+    PsSmem s;
+    {
+        char* q = smem;
+        s.xraw  = reinterpret_cast<f16*>(q);
+        q += (size_t)M * H * 2;
+        s.xs = reinterpret_cast<f16*>(q);
+        q += (size_t)p.plan.xs_halves * 2;
+        s.part = reinterpret_cast<float*>(q);
+        q += (size_t)PS_RMAX * PS_NW * M * 16 * 4;
+        s.att = q;
+        q += ps_att_bytes(DH, p.s_max, p.plan.nsplit);
+        s.rt1 = reinterpret_cast<RunRec*>(q);
+        q += sizeof(RunRec) * PS_RMAX;
+        s.rt3 = reinterpret_cast<RunRec*>(q);
+        q += sizeof(RunRec) * PS_RMAX;
+        s.rsc = reinterpret_cast<f16*>(q);
+        q += PS_RMAX * 16 * 2;
+        s.red = reinterpret_cast<float*>(q);
+        q += 64 * 4;
+        s.misc = reinterpret_cast<int*>(q);
+        q += 64 * 4;
+        s.lt1 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E1 * 4;
+        s.ct1 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E1 * 4;
+        s.lt3 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E3 * 4;
+        s.ct3 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E3 * 4;
+        s.bt1 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * (E1 / PS_U) * 4;
+        s.bt3 = reinterpret_cast<unsigned*>(q);
+    }
+    const int      step     = *p.d_step;
+    const unsigned tag_base = (unsigned)step * 256u + 1u;
+
+    // ---- the workgroup's static share of the streaming stages ----
+    const int G   = NT0 + Il / 16;
+    const int g0  = (int)((long)G * bid / NB), g1 = (int)((long)G * (bid + 1) / NB);
+    const int rB0 = (int)((long)NG * PB * bid / NB), rB1 = (int)((long)NG * PB * (bid + 1) / NB);
+    const int rA0 = (int)((long)NG * PA * bid / NB), rA1 = (int)((long)NG * PA * (bid + 1) / NB);
+    const int nB = rB1 - rB0, nA = rA1 - rA0;
+    const int nruns1 = g1 - g0, nruns3 = nB + nA;
+    const int n_items = p.B * p.nh * p.plan.nsplit;
+    if (threadIdx.x == 0) {
+        s.misc[0] = 0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nruns1) {  // P1: [QKV u FFN1] column groups g0..g1, full K each
+        const int  j   = threadIdx.x;
+        const int  cg  = g0 + j;
+        const bool seg = cg >= NT0;
+        const int  g   = seg ? cg - NT0 : cg;
+        RunRec     r;
+        r.tile0  = g * KT;
+        r.sel    = seg ? 1 : 0;
+        r.nt     = KT;
+        r.xoff   = seg ? M * H : 0;
+        r.xsel   = 0;
+        r.rid    = cg;
+        r.grp    = g;
+        r.pad    = 0;
+        s.rt1[j] = r;
+    }
+    if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
+        const int  j     = threadIdx.x;
+        const bool isA   = j >= nB;
+        const int  idx   = isA ? rA0 + (j - nB) : rB0 + j;
+        const int  piece = idx / NG, g = idx % NG;
+        RunRec     r;
+        if (isA) {
+            const int t0 = piece * RLa;
+            r.tile0      = g * KT_a + t0;
+            r.sel        = 1;
+            r.nt         = (KT_a - t0 < RLa) ? KT_a - t0 : RLa;
+            r.xoff       = M * Il + t0 * TK;
+            r.xsel       = 1;
+            r.rid        = NG * PB + idx;
+            if (piece == PA - 1) {  // owner of a group's last out-proj piece merges the group
+                const int k = atomicAdd(&s.misc[0], 1);
+                if (k < PS_MAXMERGE) {
+                    s.misc[1 + k] = g;
+                }
+            }
+        }
+        else {
+            const int t0 = piece * RLb;
+            r.tile0      = g * KT_b + t0;
+            r.sel        = 0;
+            r.nt         = (KT_b - t0 < RLb) ? KT_b - t0 : RLb;
+            r.xoff       = t0 * TK;
+            r.xsel       = 0;
+            r.rid        = idx;
+        }
+        r.grp    = g;
+        r.pad    = 0;
+        s.rt3[j] = r;
+    }
+    __syncthreads();
+    PsStage sg1{}, sg3{};
+    int     mid_lo = 0, mid_hi = 0, ctx_lo = 0, ctx_hi = 0;  // K ranges (halves) of mid / ctx this workgroup consumes
+    {
+        int T1 = 0, T3 = 0;
+        for (int j = 0; j < nruns1; j++) {
+            T1 += s.rt1[j].nt;
+        }
+        bool fb = true, fa = true;
+        for (int j = 0; j < nruns3; j++) {
+            const RunRec r = s.rt3[j];
+            T3 += r.nt;
+            if (r.sel == 0) {
+                const int lo = r.xoff, hi = r.xoff + r.nt * TK;
+                mid_lo = fb ? lo : (lo < mid_lo ? lo : mid_lo);
+                mid_hi = fb ? hi : (hi > mid_hi ? hi : mid_hi);
+                fb     = false;
+            }
+            else {
+                const int lo = r.xoff - M * Il, hi = lo + r.nt * TK;
+                ctx_lo = fa ? lo : (lo < ctx_lo ? lo : ctx_lo);
+                ctx_hi = fa ? hi : (hi > ctx_hi ? hi : ctx_hi);
+                fa     = false;
+            }
+        }
+        T1 = ps_rfl(T1);
+        T3 = ps_rfl(T3);
+        mid_lo = ps_rfl(mid_lo);
+        mid_hi = ps_rfl(mid_hi);
+        ctx_lo = ps_rfl(ctx_lo);
+        ctx_hi = ps_rfl(ctx_hi);
+        const int w = ps_rfl(wid);
+        int       tb, te;
+        ps_wave_range(T1, w, p.ctrl_share, tb, te);
+        sg1.lt   = s.lt1 + (size_t)w * E1;
+        sg1.ct   = s.ct1 + (size_t)w * E1;
+        sg1.nrot = (te - tb + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
+        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.ct1 + (size_t)w * E1,
+                            sg1.nrot * PS_U * PS_NBUF);
+        ps_wave_range(T3, w, p.ctrl_share, tb, te);
+        sg3.lt   = s.lt3 + (size_t)w * E3;
+        sg3.ct   = s.ct3 + (size_t)w * E3;
+        sg3.nrot = (te - tb + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
+        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.ct3 + (size_t)w * E3,
+                            sg3.nrot * PS_U * PS_NBUF);
+        sg1.xs0 = sg1.xs1 = H;
+        sg3.xs0 = Il;
+        sg3.xs1 = Hl;
+        sg1.bt  = s.bt1 + (size_t)w * (E1 / PS_U);
+        sg3.bt  = s.bt3 + (size_t)w * (E3 / PS_U);
+        __syncthreads();
+        ps_build_batches(sg1.ct, s.bt1 + (size_t)w * (E1 / PS_U), sg1.nrot * PS_NBUF);
+        ps_build_batches(sg3.ct, s.bt3 + (size_t)w * (E3 / PS_U), sg3.nrot * PS_NBUF);
+    }
+    __syncthreads();
+
+    // Control waves and streamer waves run SEPARATE instantiations of the layer loop (same barriers, in the same order):
+    // with a shared body the register batches of the role that primes early stay live, as far as the compiler can tell,
+    // through every section of the other role and spill.  Whole waves take one side, s_barrier only counts arrivals.
+    auto body = [&](auto role) {
+        constexpr bool    CTRL = decltype(role)::value;
+        int               tid  = threadIdx.x;
+        PsStream<INT8, M> st;
+        auto stamp = [&](const int l, const int k) {
+            const int lane = tid & 63, wid = tid >> 6;
+            if (p.ts && lane == 0 && (wid == 0 || wid == 2)) {
+                p.ts[(((size_t)bid * p.L + l) * 2 + (wid ? 1 : 0)) * 16 + k] = wall_clock64();
+            }
+        };
+        // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
+        f16   r_sc1 = (f16)1.f, r_sc3 = (f16)1.f;  // scale of (run tid/16, column tid%16) of P1 / P3
+        f16   r_b1[2], r_bres[2];                  // ffn1 bias of the P1 epilogue items / residual bias of the merge items
+        f16x8 r_ln[4][PS_NLN];                     // ln1_g, ln1_b, ln2_g, ln2_b vectors tid, tid + 512
+        auto  load_sc1 = [&](const int l) {
+            if constexpr (INT8) {
+                if (tid < nruns1 * 16) {
+                    const PersistLayer& lw = p.layers[l];
+                    const RunRec&       r  = s.rt1[tid >> 4];
+                    r_sc1 = PS_G(f16, r.sel ? lw.s_ffn1 : lw.s_qkv)[r.grp * 16 + (tid & 15)];
+                }
+            }
+        };
+        auto load_p1_consts = [&](const int l) {  // LN parameters, ffn1 bias, P3 scales of layer l
+            const PersistLayer& lw = p.layers[l];
+#pragma unroll
+            for (int k = 0; k < PS_NLN; k++) {
+                const int v = tid + k * PS_NT;
+                if (v * 8 < H) {
+                    r_ln[0][k] = *PS_G(f16x8, lw.ln1_g + v * 8);
+                    r_ln[1][k] = *PS_G(f16x8, lw.ln1_b + v * 8);
+                    r_ln[2][k] = *PS_G(f16x8, lw.ln2_g + v * 8);
+                    r_ln[3][k] = *PS_G(f16x8, lw.ln2_b + v * 8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int idx = tid + k * PS_NT;
+                r_b1[k]       = (f16)0.f;
+                if (idx < nruns1 * M * 16) {
+                    const int cg = g0 + idx / (M * 16);
+                    if (cg >= NT0) {
+                        r_b1[k] = PS_G(f16, lw.b_ffn1)[(cg - NT0) * 16 + (idx & 15)];
+                    }
+                }
+            }
+            if constexpr (INT8) {
+                if (tid < nruns3 * 16) {
+                    const RunRec& r = s.rt3[tid >> 4];
+                    r_sc3 = PS_G(f16, r.sel ? lw.s_out : lw.s_ffn2)[r.grp * 16 + (tid & 15)];
+                }
+            }
+        };
+        auto load_p3_consts = [&](const int l) {  // residual bias of layer l, P1 scales of layer l + 1
+            if constexpr (CTRL) {
+                const PersistLayer& lw = p.layers[l];
+                const int           nm = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int t = tid + k * PS_NC * 64;
+                    r_bres[k]   = (f16)0.f;
+                    if (t < nm * M * 16) {
+                        r_bres[k] = PS_G(f16, lw.b_res)[s.misc[1 + t / (M * 16)] * 16 + (t & 15)];
+                    }
+                }
+            }
+            if (l + 1 < p.l_end) {
+                load_sc1(l + 1);
+            }
+        };
+        // per layer: scales of the stage's runs -> LDS, zero the partial buffer, bind the stream
+        auto setup_p1 = [&](const int l) {
+            const PersistLayer& lw = p.layers[l];
+            if constexpr (INT8) {
+                if (tid < nruns1 * 16) {
+                    s.rsc[tid] = r_sc1;
+                }
+            }
+            for (int i = tid; i < nruns1 * PS_NW * M * 16; i += PS_NT) {
+                s.part[i] = 0.f;
+            }
+            load_p1_consts(l);
+            sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
+            sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
+            st.bind(sg1, s.rsc, s.xs, s.part, tid);
+            if constexpr (!CTRL) {
+                st.prime();
+            }
+        };
+        auto setup_p3 = [&](const int l) {
+            const PersistLayer& lw = p.layers[l];
+            if constexpr (INT8) {
+                if (tid < nruns3 * 16) {
+                    s.rsc[tid] = r_sc3;
+                }
+            }
+            for (int i = tid; i < nruns3 * PS_NW * M * 16; i += PS_NT) {
+                s.part[i] = 0.f;
+            }
+            load_p3_consts(l);
+            sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
+            sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
+            st.bind(sg3, s.rsc, s.xs, s.part, tid);
+        };
+
+        load_sc1(p.l_begin);
+        setup_p1(p.l_begin);
+        for (int l = p.l_begin; l < p.l_end; l++) {
+            // opaque copies: keeps per-thread address arithmetic from being hoisted out of the layer loop, where it
+            // becomes dozens of long-lived VGPRs that spill around the register batches
+            asm volatile("" : "+v"(tid));
+            const int           lane = tid & 63, wid = tid >> 6;
+            const PersistLayer& lw  = p.layers[l];
+            const unsigned      tag = tag_base + (unsigned)l;
+            stamp(l, 0);
+            // =========================== S0: layer input -> xraw (control waves) =================================
+            if constexpr (CTRL) {
+                if (l == p.l_begin) {
+                    for (int i = tid * 8; i < M * H; i += PS_NC * 64 * 8) {
+                        *reinterpret_cast<f16x8*>(s.xraw + i) = *reinterpret_cast<const f16x8*>(p.x_in + i);
+                    }
+                }
+                else {
+                    ps_sweep<20>(p.gx, M * H / 2, tid, PS_NC * 64, tag_base + (unsigned)(l - 1), p.err, 3,
+                                [&](const int i, const unsigned v) { reinterpret_cast<unsigned*>(s.xraw)[i] = v; });
+                }
+            }
+            __syncthreads();
+            stamp(l, 1);
+            // =========================== P1: LN1 / LN2, [QKV u FFN1] ===============================================
+            {
+                // LayerNorm x2 (layernorm_kernels.cu:157-286 arithmetic: fp32 statistics, var = E[x^2] - mean^2, half
+                // normalise); both norms share the statistics of x
+                float s0[M], s1[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    s0[m] = 0.f;
+                    s1[m] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < PS_NLN; k++) {
+                        const int v = tid + k * PS_NT;
+                        if (v * 8 < H) {
+                            const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const float f = (float)x8[e];
+                                s0[m] += f;
+                                s1[m] += f * f;
+                            }
+                        }
+                    }
+                    s0[m] = wave_sum(s0[m]);
+                    s1[m] = wave_sum(s1[m]);
+                    if (lane == 0) {
+                        s.red[(m * PS_NW + wid) * 2]     = s0[m];
+                        s.red[(m * PS_NW + wid) * 2 + 1] = s1[m];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < PS_NW; w++) {
+                        a0 += s.red[(m * PS_NW + w) * 2];
+                        a1 += s.red[(m * PS_NW + w) * 2 + 1];
+                    }
+                    const float mean = a0 / (float)H;
+                    const float rstd = rsqrtf(a1 / (float)H - mean * mean + p.eps);
+                    const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+                    for (int k = 0; k < PS_NLN; k++) {
+                        const int v = tid + k * PS_NT;
+                        if (v * 8 < H) {
+                            const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
+                            f16x8       o1, o2;
+#pragma unroll
+                            for (int e = 0; e < 8; e++) {
+                                const f16 nrm = (x8[e] - mh) * rh;
+                                o1[e]         = (nrm * r_ln[0][k][e]) + r_ln[1][k][e];
+                                o2[e]         = (nrm * r_ln[2][k][e]) + r_ln[3][k][e];
+                            }
+                            *reinterpret_cast<f16x8*>(s.xs + (size_t)m * H + v * 8)       = o1;
+                            *reinterpret_cast<f16x8*>(s.xs + (size_t)(M + m) * H + v * 8) = o2;
+                        }
+                    }
+                }
+                if constexpr (CTRL) {
+                    st.prime();
+                }
+                stamp(l, 2);
+                __syncthreads();
+                st.run();
+                stamp(l, 3);
+                __syncthreads();
+                // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int idx = tid + k * PS_NT;
+                    if (idx < nruns1 * M * 16) {
+                        const int j = idx / (M * 16), r = idx % (M * 16), m = r >> 4, c = r & 15;
+                        float     v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < PS_NW; w++) {
+                            v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                        }
+                        const int cg = g0 + j;
+                        f16       o;
+                        u64*      dst;
+                        if (cg < NT0) {
+                            o   = (f16)v;
+                            dst = p.gq + (((size_t)m * 3 * Hl + cg * 16 + c) >> 1);
+                        }
+                        else {
+                            if constexpr (INT8) {
+                                o = (f16)gelu_f32(v + (float)r_b1[k]);  // epilogue_helpers.h:52-62
+                            }
+                            else {
+                                o = gelu_f16((f16)v + r_b1[k]);  // activation_kernels.cu:401-426
+                            }
+                            dst = p.gm + (((size_t)m * Il + (cg - NT0) * 16 + c) >> 1);
+                        }
+                        const unsigned b0 = f16_bits(o);
+                        const unsigned b1 = __shfl_down(b0, 1, 64);
+                        if ((c & 1) == 0) {
+                            st_granule_u32(dst, tag, b0 | (b1 << 16));
+                        }
+                    }
+                }
+                stamp(l, 4);
+            }
+
+            // =========================== attention ===============================================================
+            asm volatile("" : "+v"(tid));
+            PsAttn<DH> at;
+            const bool has_item = bid < n_items;
+            int        a_sp = 0, a_h = 0, a_b = 0;
+            if (has_item) {
+                a_sp         = bid % p.plan.nsplit;
+                const int hb = bid / p.plan.nsplit;
+                a_h          = hb % p.nh;
+                a_b          = hb / p.nh;
+            }
+            __syncthreads();  // part / scales reuse
+            setup_p3(l);
+            stamp(l, 5);
+            bool live = false;
+            u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
+            if (has_item) {
+                // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
+                at.issue(p, lw, a_h, a_b, a_sp, tid);
+                at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
+                stamp(l, 6);
+                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid);
+            }
+            stamp(l, 7);
+            if constexpr (!CTRL) {
+                st.prime();  // the streamer waves issue no load between here and the end of the P3 stream
+            }
+            if (has_item && a_sp == 0) {
+                if (live) {
+                    ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
+                }
+                else {
+                    ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
+                }
+            }
+            stamp(l, 8);
+            // =========================== P3: [FFN2 u out-proj] -> residual ========================================
+            if constexpr (CTRL) {  // the K ranges of mid and ctx this workgroup's pieces read -> LDS
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
+                                 p.err, 6, [&](const int i, const unsigned v) {
+                                     reinterpret_cast<unsigned*>(s.xs + (size_t)m * Il + mid_lo)[i] = v;
+                                 });
+                }
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    ps_sweep<5>(p.gc + (((size_t)m * Hl + ctx_lo) >> 1), (ctx_hi - ctx_lo) >> 1, tid, PS_NC * 64, tag,
+                                p.err, 7, [&](const int i, const unsigned v) {
+                                    reinterpret_cast<unsigned*>(s.xs + (size_t)M * Il + (size_t)m * Hl + ctx_lo)[i] = v;
+                                });
+                }
+                st.prime();
+            }
+            stamp(l, 9);
+            __syncthreads();
+            st.run();
+            stamp(l, 10);
+            __syncthreads();
+            asm volatile("" : "+v"(tid));
+            // K pieces -> granules
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int idx = tid + k * PS_NT;
+                if (idx < nruns3 * M * 16) {
+                    const int j = idx / (M * 16), r = idx % (M * 16);
+                    float     v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < PS_NW; w++) {
+                        v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                    }
+                    st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
+                }
+            }
+            const int  nmerge = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
+            const bool last   = (l == p.l_end - 1);
+            // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
+            const int inplace = (l > 0 && l < p.L - 1) ? 1 : 0;
+            __syncthreads();  // part / scales are free: the streamer waves start the next layer's weight stream now
+            if (l + 1 < p.l_end) {
+                setup_p1(l + 1);
+            }
+            stamp(l, 11);
+            // merge the groups this workgroup owns (control waves) -> x'
+            if constexpr (CTRL) {
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const int t = tid + k2 * PS_NC * 64;
+                    if (t < nmerge * M * 16) {
+                        const int k = t / (M * 16), r = t % (M * 16), m = r >> 4, c = r & 15;
+                        const int g = s.misc[1 + k];
+                        u64       gv[PS_MAXP];
+                        int       spins = 0;
+                        for (;;) {
+                            bool ok = true;
+#pragma unroll
+                            for (int q = 0; q < PS_MAXP; q++) {
+                                if (q < PA + PB) {
+                                    const int rid = (q < PA) ? NG * PB + q * NG + g : (q - PA) * NG + g;
+                                    gv[q]         = ld_granule(&p.gp[(size_t)rid * (M * 16) + r]);
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < PS_MAXP; q++) {
+                                if (q < PA + PB) {
+                                    ok &= ((unsigned)(gv[q] >> 32) == tag);
+                                }
+                            }
+                            if (ok || ps_give_up(spins, p.err, 4)) {
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        float sa = 0.f, sb = 0.f;
+#pragma unroll
+                        for (int q = 0; q < PS_MAXP; q++) {  // piece order: deterministic
+                            if (q < PA) {
+                                sa += __uint_as_float((unsigned)gv[q]);
+                            }
+                            else if (q < PA + PB) {
+                                sb += __uint_as_float((unsigned)gv[q]);
+                            }
+                        }
+                        const int    n    = g * 16 + c;
+                        const size_t oidx = (size_t)m * H + n;
+                        const f16    attn = (f16)sa, ffn = (f16)sb;
+                        const f16    xin  = (f16)((float)s.xraw[oidx] / (float)p.tp);
+                        const f16    bb   = r_bres[k2];
+                        f16          o;
+                        if (inplace) {
+                            o = (f16)((float)xin + (float)ffn + (float)attn + (float)bb);  // add_residual_kernels.cu:116-152
+                        }
+                        else {
+                            o = ((ffn + attn) + bb) + xin;
+                        }
+                        if (last) {
+                            p.x_out[oidx] = o;
+                        }
+                        else {
+                            const unsigned b0 = f16_bits(o);
+                            const unsigned b1 = __shfl_down(b0, 1, 64);
+                            if ((c & 1) == 0) {
+                                st_granule_u32(&p.gx[oidx >> 1], tag, b0 | (b1 << 16));
+                            }
+                        }
+                    }
+                }
+            }
+            stamp(l, 12);
+            __syncthreads();  // xraw is rewritten by the next layer's gather
+        }
+    };
+    if (wid < PS_NC) {
+        body(std::true_type{});
+    }
+    else {
+        body(std::false_type{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3)
+{
+    return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)PS_RMAX * PS_NW * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
+           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)2 * PS_NW * (e1 + e3) * 4
+           + (size_t)PS_NW * (e1 + e3) / PS_U * 4;
+}
+
+PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
+                         int ctrl_share)
+{
+    PersistPlan pl{};
+    const int   M  = B;
+    const int   TK = int8 ? TILE_K_I8 : TILE_K_F16;
+    if (M < 1 || M > 2 || (dh != 64 && dh != 128) || H % TK || Hl % TK || Il % TK || H % 16 || Hl % 16 || Il % 16) {
+        return pl;
+    }
+    if (ctrl_share < 1 || ctrl_share > 16 || H > PS_NLN * PS_NT * 8) {
+        return pl;
+    }
+    const int NB = force_nb > 0 ? force_nb : num_cu;
+    if (NB < 1 || B * nh > NB) {
+        return pl;
+    }
+    const int KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK, NG = H / 16, G = 3 * Hl / 16 + Il / 16;
+    if ((G + NB - 1) / NB > PS_RMAX) {
+        return pl;
+    }
+    int nsplit = NB / (B * nh);
+    nsplit     = nsplit > MMHA_MAX_SPLIT ? MMHA_MAX_SPLIT : nsplit;
+    const int chunk = ((((s_max + nsplit - 1) / nsplit) + 15) & ~15);
+    if (chunk > PS_NW * (64 / (dh / 8)) * PS_UK) {
+        return pl;  // the K/V rows of a split must fit the registers of one trip
+    }
+    // K pieces: best balanced tile count per workgroup
+    double best = 1e30;
+    long   t3max = 0;
+    for (int PA = 1; PA <= 8; PA *= 2) {
+        for (int PB = 1; PB <= 16; PB *= 2) {
+            if (PA + PB > PS_MAXP) {
+                continue;
+            }
+            const int RLa = (KT_a + PA - 1) / PA, RLb = (KT_b + PB - 1) / PB;
+            if ((PA - 1) * RLa >= KT_a || (PB - 1) * RLb >= KT_b || (PA > 1 && RLa < 4) || (PB > 1 && RLb < 4)) {
+                continue;
+            }
+            long mx = 0, tot = 0;
+            bool ok = true;
+            for (int b = 0; b < NB && ok; b++) {
+                const int rB0 = (int)((long)NG * PB * b / NB), rB1 = (int)((long)NG * PB * (b + 1) / NB);
+                const int rA0 = (int)((long)NG * PA * b / NB), rA1 = (int)((long)NG * PA * (b + 1) / NB);
+                if (rB1 - rB0 + rA1 - rA0 > PS_RMAX) {
+                    ok = false;
+                }
+                long t  = 0;
+                int  nm = 0;
+                for (int i = rB0; i < rB1; i++) {
+                    const int t0 = (i / NG) * RLb;
+                    t += std::min(RLb, KT_b - t0);
+                }
+                for (int i = rA0; i < rA1; i++) {
+                    const int t0 = (i / NG) * RLa;
+                    t += std::min(RLa, KT_a - t0);
+                    nm += (i / NG == PA - 1);
+                }
+                if (nm > PS_MAXMERGE) {
+                    ok = false;
+                }
+                mx = std::max(mx, t);
+                tot += t;
+            }
+            if (!ok || tot == 0) {
+                continue;
+            }
+            const double cost = (double)mx * NB / (double)tot + 0.004 * (PA + PB);
+            if (cost < best) {
+                best   = cost;
+                pl.PA  = PA;
+                pl.PB  = PB;
+                pl.RLa = RLa;
+                pl.RLb = RLb;
+                t3max  = mx;
+            }
+        }
+    }
+    if (best > 1e29) {
+        return pl;
+    }
+    // tile-table entries per wave: largest wave share of the largest workgroup share, rounded up to whole rotations
+    const long t1max   = (long)((G + NB - 1) / NB) * KT;
+    const int  total   = PS_NC * ctrl_share + (PS_NW - PS_NC) * 16;
+    auto       entries = [&](long T) {
+        const long per = (T * 16 + total - 1) / total + 1;
+        const int  rot = PS_U * PS_NBUF;
+        return (int)((per + rot - 1) / rot * rot);
+    };
+    pl.e1         = entries(t1max);
+    pl.e3         = entries(t3max);
+    pl.NB         = NB;
+    pl.nsplit     = nsplit;
+    pl.ctrl_share = ctrl_share;
+    pl.xs_halves  = M * std::max(2 * H, Il + Hl);
+    if (pl.xs_halves > 0x1ffff) {
+        return pl;
+    }
+    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3);
+    if (pl.smem > 160 * 1024) {
+        return pl;
+    }
+    pl.ok = 1;
+    return pl;
+}
+
+template<bool INT8, int M, int DH>
+static void launch_ps(const PersistParams& p, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        FTCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_decode_persistent<INT8, M, DH>), dim3(p.plan.NB), dim3(PS_NT), p.plan.smem, s, p);
+}
+
+void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
+{
+    FTCF_CHECK_ARG(p.plan.ok && p.B >= 1 && p.B <= 2, "persistent decode: shape not eligible");
+    FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
+    FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
+    FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
+    FTCF_CHECK_ARG(p.ctrl_share == p.plan.ctrl_share, "plan was made for another control-wave share");
+#define PS_CASE(I8, MM, D)                                                                                             \
+    if (int8 == I8 && p.B == MM && p.dh == D) {                                                                        \
+        launch_ps<I8, MM, D>(p, s);                                                                                    \
+    }
+    PS_CASE(true, 1, 128)
+#ifndef PS_ONLY_ONE
+    PS_CASE(true, 2, 128)
+    PS_CASE(true, 1, 64)
+    PS_CASE(true, 2, 64)
+    PS_CASE(false, 1, 128)
+    PS_CASE(false, 2, 128)
+    PS_CASE(false, 1, 64)
+    PS_CASE(false, 2, 64)
+#endif
+#undef PS_CASE
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ftcf
