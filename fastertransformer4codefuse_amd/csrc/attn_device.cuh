@@ -39,13 +39,16 @@ __device__ __forceinline__ void rotary_pair(f16& a, f16& b, int j, int rot, int 
 // drain / ticket / fence round trip on the latency chain (cdna_hip_programming.md G16 recipe R2, MI355X_MICROARCH.md
 // row "handoff-1to1").  tag = f(step, layer) + 1 is unique per launch; the slab is zeroed when a request begins.
 typedef unsigned long long u64;
+// (granule slabs always live in global memory: the explicit address space keeps these from becoming FLAT accesses, which
+// count on lgkmcnt as well and serialise with LDS waits, when the pointer comes out of a struct)
+typedef __attribute__((address_space(1))) u64 gu64;
 __device__ __forceinline__ void st_granule(u64* g, unsigned tag, float v)
 {
-    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64*)g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 ld_granule(const u64* g)
 {
-    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 constexpr int MMHA_MAX_SPLIT = 16;

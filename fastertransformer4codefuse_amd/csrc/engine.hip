@@ -391,7 +391,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): 0 off, 1 on when the shape is eligible
-    int                 persist = 0, persist_per_layer = 0, persist_nb = 0, persist_ctrl_share = 12;
+    int                 persist = 0, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 14, persist_cs3 = 8;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -503,7 +503,7 @@ struct ftcf_gptneox {
             chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, B <= 4 ? B : 1, 8) / 8);
             pplan = PersistPlan{};
             if (persist && B <= 2) {
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_ctrl_share);
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
             }
             if (pplan.ok) {
                 ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
@@ -516,7 +516,7 @@ struct ftcf_gptneox {
                 ps_ga       = ps_gq ? ps_gp + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 : nullptr;
                 ps_err      = ps_gq ? reinterpret_cast<int*>(ps_gq + ps_slab_n) : nullptr;
                 d_players   = c.take<PersistLayer>(L);
-                ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 32);
+                ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
@@ -616,7 +616,6 @@ struct ftcf_gptneox {
         pp.finished = finished;
         pp.rot_table = rot_table;
         pp.eps = 1e-5f;
-        pp.ctrl_share = persist_ctrl_share;
         pp.ts = ps_ts;
         return pp;
     }
@@ -1173,10 +1172,10 @@ void ftcf_gptneox::finish()
     }
     drain_events();
     if (pplan.ok && ps_ts) {
-        std::vector<long long> h((size_t)pplan.NB * L * 32);
+        std::vector<long long> h((size_t)pplan.NB * L * 128);
         FTCF_HIP_CHECK(hipMemcpy(h.data(), ps_ts, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(ps_ts_file.c_str(), "wb")) {
-            const int hdr[4] = {pplan.NB, L, 2, 16};
+            const int hdr[4] = {pplan.NB, L, 8, 16};
             fwrite(hdr, 4, 4, f);
             fwrite(h.data(), 8, h.size(), f);
             fclose(f);
@@ -1312,8 +1311,11 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_PERSIST_NB")) {
             e->persist_nb = atoi(m);
         }
-        if (const char* m = getenv("FTCF_PERSIST_CTRL_SHARE")) {
-            e->persist_ctrl_share = atoi(m);
+        if (const char* m = getenv("FTCF_PERSIST_CS1")) {
+            e->persist_cs1 = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_CS3")) {
+            e->persist_cs3 = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_USE_GRAPH")) {

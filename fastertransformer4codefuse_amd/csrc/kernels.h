@@ -139,7 +139,7 @@ struct PersistPlan {
     int    RLa, RLb;  // tiles per piece
     int    xs_halves; // LDS x region
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
-    int    ctrl_share;
+    int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
     size_t smem;
 };
 struct PersistParams {
@@ -160,11 +160,10 @@ struct PersistParams {
     const uint8_t*      finished;
     const float*        rot_table;
     float               eps;
-    int                 ctrl_share;  // stream share of the two control waves in 1/16 of a streamer wave's
-    long long*          ts;          // optional [NB][L][2][16] wall-clock stamps (100 MHz) of wave 0 / wave 2, or NULL
+    long long*          ts;          // optional [NB][L][8 waves][16] wall-clock stamps (100 MHz), or NULL
 };
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int ctrl_share);
+                         int cs1, int cs3);
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
 
 // ---- dynamic decode : kernels_sampling.hip ----

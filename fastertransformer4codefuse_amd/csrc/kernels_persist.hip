@@ -48,10 +48,9 @@ constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) 
 // pointers that come out of the per-layer table in memory are GLOBAL: say so (a flat access also counts on lgkmcnt)
 #define PS_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
 
-// consume-table entry: bits 0..16 LDS half offset of the tile's x, 17..21 run, 22 flush after, 23 valid, 24 x stride select
-constexpr unsigned PS_CT_FLUSH = 1u << 22, PS_CT_VALID = 1u << 23, PS_CT_XSEL = 1u << 24;
-// batch-table entry: bit 0 fast (PS_U valid tiles of one run), 1 flush after the batch, 2..6 run, 8..24 x offset, 25 stride select
-constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25;
+// batch-table entry (one per PS_U tiles of ONE run, consecutive k): bit 0 valid, 1 flush after the batch, 2..6 run,
+// 8..24 LDS half offset of the first tile's x, 25 x stride select, 26 wait for the late x vector, 27..30 valid tiles
+constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25, PS_BT_WAIT = 1u << 26;
 
 struct RunRec {  // static per launch (LDS)
     int tile0;  // first tile of the run inside its weight array
@@ -70,7 +69,7 @@ __device__ __forceinline__ int ps_rfl(int v)
 }
 __device__ __forceinline__ void st_granule_u32(u64* g, unsigned tag, unsigned v)
 {
-    __hip_atomic_store(g, ((u64)tag << 32) | (u64)v, PS_RLX, PS_AGT);
+    __hip_atomic_store((gu64*)g, ((u64)tag << 32) | (u64)v, PS_RLX, PS_AGT);
 }
 __device__ __forceinline__ unsigned short f16_bits(f16 v)
 {
@@ -83,10 +82,10 @@ __device__ __forceinline__ f16 bits_f16(unsigned v)
 __device__ __forceinline__ bool ps_give_up(int& spins, int* err, const int code)
 {
     if (++spins > PS_SPIN) {
-        __hip_atomic_store(err, code, PS_RLX, PS_AGT);
+        __hip_atomic_store((__attribute__((address_space(1))) int*)err, code, PS_RLX, PS_AGT);
         return true;
     }
-    return (spins & 255) == 0 && __hip_atomic_load(err, PS_RLX, PS_AGT) != 0;
+    return (spins & 255) == 0 && __hip_atomic_load((__attribute__((address_space(1))) int*)err, PS_RLX, PS_AGT) != 0;
 }
 // `nthr` threads (whole waves, tid = 0..nthr-1) re-read granules [0, n) of `g` until every tag matches, NPER granules
 // per thread and pass, and hand the 32-bit payloads to sink(index, value)
@@ -126,14 +125,31 @@ __device__ __forceinline__ void ps_sweep(const u64* g, const int n, const int ti
     }
 }
 
-// wave w's share of T tiles: control waves get cs/16 of a streamer wave's share
+// wave w's share of T tiles: control waves get cs/16 of a streamer wave's share and sit at the END of the flat space
+// (P3 puts the out-proj pieces there: the control waves are the ones that wait for ctx anyway).  Shares start at whole
+// batches, so that with run lengths that are multiples of PS_U every batch lies inside one run.
 __host__ __device__ inline void ps_wave_range(const int T, const int w, const int cs, int& tb, int& te)
 {
     const int total = PS_NC * cs + (PS_NW - PS_NC) * 16;
-    const int c0    = (w < PS_NC) ? w * cs : PS_NC * cs + (w - PS_NC) * 16;
+    const int c0    = (w >= PS_NC) ? (w - PS_NC) * 16 : (PS_NW - PS_NC) * 16 + w * cs;
     const int c1    = c0 + ((w < PS_NC) ? cs : 16);
-    tb              = (int)((long)T * c0 / total);
-    te              = (int)((long)T * c1 / total);
+    tb              = (int)((long)T * c0 / total) / PS_U * PS_U;
+    te              = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
+}
+// table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
+template<typename NT>
+__host__ __device__ inline int ps_wave_entries(const int nruns, NT&& run_nt, const int tb, const int te)
+{
+    int e = 0, pre = 0;
+    for (int j = 0; j < nruns; j++) {
+        const int nt = run_nt(j);
+        const int a = tb > pre ? tb : pre, b = te < pre + nt ? te : pre + nt;
+        if (b > a) {
+            e += (b - a + PS_U - 1) / PS_U * PS_U;
+        }
+        pre += nt;
+    }
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -145,7 +161,7 @@ __host__ __device__ inline void ps_wave_range(const int T, const int w, const in
 // part[run][wave] after the last tile of the wave's piece of a run (a wave meets a run in ONE contiguous piece).
 // ---------------------------------------------------------------------------------------------------------------
 struct PsStage {
-    const unsigned *lt, *ct, *bt;  // per tile: load / consume entries; per batch: fast-path descriptor
+    const unsigned *lt, *bt;  // per tile: {array select, tile index}; per batch: descriptor (see PS_BT_*)
     int             nrot;  // rotations (PS_NBUF batches each), >= 1
     const char *    w0, *w1;
     int             xs0, xs1;
@@ -160,10 +176,15 @@ struct PsStream {
     const f16* rsc;
     const f16* xs;
     float*     part;
+    const int* flag;    // LDS arrival counter of the second x vector
+    int        target;  // value it reaches when that vector is staged
     int        lane, wid;
 
-    __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx)
+    __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx,
+                                         const int* flag_ = nullptr, const int target_ = 0)
     {
+        flag   = flag_;
+        target = target_;
         g    = g_;
         rsc  = rsc_;
         xs   = xs_;
@@ -195,52 +216,65 @@ struct PsStream {
     __device__ __forceinline__ void consume(const u32x4 (&r)[PS_U], const int i)
     {
         const unsigned bd = (unsigned)ps_rfl((int)g.bt[i]);
-        if (bd & PS_BT_FAST) {
-            // all PS_U tiles valid, one run, consecutive k: straight-line code like the per-kernel GEMV stream
-            const int  j   = (bd >> 2) & 31;
-            const f16* xr  = a_frag_ptr<INT8, M>(xs + ((bd >> 8) & 0x1ffffu), (bd & PS_BT_XSEL) ? g.xs1 : g.xs0, lane);
-            f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
-            if constexpr (INT8) {
-                const f16 sc = rsc[j * 16 + (lane & 15)];
-                sc2          = f16x2{sc, sc};
+        if (!(bd & PS_BT_FAST)) {
+            return;  // padding batch
+        }
+        if (bd & PS_BT_WAIT) {  // rare: only the first batch of a wave that touches the late vector actually spins
+            while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)flag) < target) {
+                __builtin_amdgcn_s_sleep(1);
             }
+        }
+        const int  j   = (bd >> 2) & 31;
+        const int  cnt = (bd >> 27) & 15;
+        const f16* xr  = a_frag_ptr<INT8, M>(xs + ((bd >> 8) & 0x1ffffu), (bd & PS_BT_XSEL) ? g.xs1 : g.xs0, lane);
+        f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
+        if constexpr (INT8) {
+            const f16 sc = rsc[j * 16 + (lane & 15)];
+            sc2          = f16x2{sc, sc};
+        }
+        if (cnt == PS_U) {  // straight-line code like the per-kernel GEMV stream
 #pragma unroll
             for (int u = 0; u < PS_U; u++) {
                 consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
             }
-            if (bd & PS_BT_FLUSH) {
-                flush(j);
-            }
-            return;
         }
+        else {
 #pragma unroll
-        for (int u = 0; u < PS_U; u++) {
-            const unsigned d = (unsigned)ps_rfl((int)g.ct[i * PS_U + u]);
-            if (d & PS_CT_VALID) {
-                const int  j   = (d >> 17) & 31;
-                const f16* xr  = a_frag_ptr<INT8, M>(xs + (d & 0x1ffffu), (d & PS_CT_XSEL) ? g.xs1 : g.xs0, lane);
-                f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
-                if constexpr (INT8) {
-                    const f16 sc = rsc[j * 16 + (lane & 15)];
-                    sc2          = f16x2{sc, sc};
-                }
-                consume_tile<INT8, M>(r[u], xr, sc2, acc);
-                if (d & PS_CT_FLUSH) {
-                    flush(j);
+            for (int u = 0; u < PS_U; u++) {
+                if (u < cnt) {
+                    consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
                 }
             }
+        }
+        if (bd & PS_BT_FLUSH) {
+            flush(j);
         }
     }
-    // the first rotation: issued before the hand-off this stage waits for
-    __device__ __forceinline__ void prime()
+    // the first rotation: issued before the hand-off this stage waits for.  The streamer waves issue only half of it
+    // there and the rest when they start consuming: a 192 KiB burst per CU sits in FRONT of the control waves' sweeps in
+    // the CU's memory pipeline and stretched each hand-off hop to 6-7 us (measured)
+    __device__ __forceinline__ void prime_lo()
     {
         load(R0, 0);
         load(R1, 1);
+    }
+    __device__ __forceinline__ void prime_hi()
+    {
         load(R2, 2);
         load(R3, 3);
     }
+    __device__ __forceinline__ void prime()
+    {
+        prime_lo();
+        prime_hi();
+    }
+    template<bool HI>
     __device__ __forceinline__ void run()
     {
+        if constexpr (HI) {
+            prime_hi();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const int last = (g.nrot - 1) * PS_NBUF;
         for (int i = 0; i < last; i += PS_NBUF) {
             consume(R0, i);
@@ -267,51 +301,38 @@ struct PsStream {
     }
 };
 
-// one wave fills its tile tables for a stage from the workgroup's static run table (entries past the share: dummy)
+// One wave fills its tables for a stage from the workgroup's static run table: every piece of a run the wave owns is
+// padded to whole batches (padding tiles re-read tile 0 of array 0 and are never consumed), so a batch never spans two
+// runs.  Serial on lane 0: ~100 entries, once per launch.
 template<int TK>
 __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
-                                                unsigned* lt, unsigned* ct, const int entries)
+                                                unsigned* lt, unsigned* bt, const int entries)
 {
-    const int lane = threadIdx.x & 63;
-    const int n    = te - tb;
-    for (int i = lane; i < entries; i += 64) {
-        unsigned l = 0u, c = 0u;  // dummy: tile 0 of array 0, not valid
-        if (i < n) {
-            const int t = tb + i;
-            int       j = 0, pre = 0;
-            while (j + 1 < nruns && t >= pre + rt[j].nt) {
-                pre += rt[j].nt;
-                j++;
-            }
-            const RunRec r   = rt[j];
-            const int    off = t - pre;
-            const int    se  = te < pre + r.nt ? te : pre + r.nt;
-            l = ((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off);
-            c = (unsigned)(r.xoff + off * TK) | ((unsigned)j << 17) | ((t + 1 == se) ? PS_CT_FLUSH : 0u) | PS_CT_VALID
-                | (r.xsel ? PS_CT_XSEL : 0u);
-        }
-        lt[i] = l;
-        ct[i] = c;
+    if ((threadIdx.x & 63) != 0) {
+        return;
     }
-}
-
-// after the consume tables are visible: one descriptor per batch
-__device__ __forceinline__ void ps_build_batches(const unsigned* ct, unsigned* bt, const int nbatch)
-{
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < nbatch; i += 64) {
-        const unsigned d0   = ct[i * PS_U];
-        bool           fast = true;
-#pragma unroll
-        for (int u = 0; u < PS_U; u++) {
-            const unsigned d = ct[i * PS_U + u];
-            fast = fast && (d & PS_CT_VALID) && (((d >> 17) & 31) == ((d0 >> 17) & 31))
-                   && (u == PS_U - 1 || !(d & PS_CT_FLUSH));
+    int e = 0, pre = 0;
+    for (int j = 0; j < nruns; j++) {
+        const RunRec r = rt[j];
+        const int    a = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
+        for (int t = a; t < b; t += PS_U) {
+            const int cnt = (b - t < PS_U) ? b - t : PS_U;
+            const int off = t - pre;
+            for (int u = 0; u < PS_U; u++) {
+                lt[e + u] = (u < cnt) ? (((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off + u)) : 0u;
+            }
+            bt[e / PS_U] = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
+                           | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
+                           | ((unsigned)cnt << 27);
+            e += PS_U;
         }
-        const unsigned dl = ct[i * PS_U + PS_U - 1];
-        bt[i] = fast ? (PS_BT_FAST | ((dl & PS_CT_FLUSH) ? PS_BT_FLUSH : 0u) | (((d0 >> 17) & 31) << 2)
-                        | ((d0 & 0x1ffffu) << 8) | ((d0 & PS_CT_XSEL) ? PS_BT_XSEL : 0u))
-                     : 0u;
+        pre += r.nt;
+    }
+    for (; e < entries; e += PS_U) {
+        for (int u = 0; u < PS_U; u++) {
+            lt[e + u] = 0u;
+        }
+        bt[e / PS_U] = 0u;
     }
 }
 
@@ -325,8 +346,8 @@ struct PsSmem {
     f16*      rsc;   // [RMAX][16] scales of the current stage
     float*    red;   // 64
     int*      misc;  // 64: [0] nmerge, [1..8] merge groups
-    unsigned *lt1, *ct1, *lt3, *ct3;  // [NW][e1], [NW][e3]
-    unsigned *bt1, *bt3;              // [NW][e1 / PS_U], [NW][e3 / PS_U]
+    unsigned *lt1, *lt3;  // [NW][e1], [NW][e3]
+    unsigned *bt1, *bt3;  // [NW][e1 / PS_U], [NW][e3 / PS_U]
 };
 
 __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
@@ -595,7 +616,8 @@ struct PsAttn {
     }
 };
 
-// split-0 workgroup of a (row, head): wave 0 sweeps the nsplit partials, merges in split order, stores ctx (sc1)
+// split-0 workgroup of a (row, head): WAVE 0 alone sweeps the nsplit partials, merges them in split order and publishes
+// ctx as granules (one wave: no workgroup barrier, the other waves are already streaming the next stage)
 template<int DH>
 __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem, u64* gall, const unsigned tag, int h,
                                               int b, const int tx)
@@ -603,70 +625,32 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
     const int ne = DH + 2, ns = p.plan.nsplit;
     const int ng = ns * ne;
     float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
-    __syncthreads();                                  // scratch reuse
-    if (tx < 64) {
-        for (int base = 0; base < ng; base += 64 * 8) {
-            u64 gv[8];
-            int spins = 0;
-            for (;;) {
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int i = base + k * 64 + tx;
-                    gv[k]       = ld_granule(&gall[i < ng ? i : ng - 1]);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    ok &= ((unsigned)(gv[k] >> 32) == tag);
-                }
-                if (__all(ok)) {
-                    break;
-                }
-                if (++spins > PS_SPIN) {
-                    __hip_atomic_store(p.err, 2, PS_RLX, PS_AGT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = base + k * 64 + tx;
-                if (i < ng) {
-                    sval[i] = __uint_as_float((unsigned)gv[k]);
-                }
-            }
-        }
-        // weights (same wave: DS operations of one wave execute in order)
-        float ms = -INFINITY, ls = 0.f;
-        if (tx < ns) {
-            ms = sval[tx * ne + DH];
-            ls = sval[tx * ne + DH + 1];
-        }
-        const float m = wave_max(ms);
-        const float w = (ms == -INFINITY) ? 0.f : __expf(ms - m);
-        float*      sw = sval + ns * ne;
-        if (tx < ns) {
-            sw[tx] = w;
-        }
-        float L = 0.f;
-        for (int s2 = 0; s2 < ns; s2++) {
-            L += __shfl(w * ls, s2, 64);
-        }
-        if (tx == 0) {
-            sw[ns] = L;
-        }
+    ps_sweep<8>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
+    // weights (same wave: DS operations of one wave execute in order)
+    float ms = -INFINITY, ls = 0.f;
+    if (tx < ns) {
+        ms = sval[tx * ne + DH];
+        ls = sval[tx * ne + DH + 1];
     }
-    __syncthreads();
-    if (tx < DH) {
-        const float* sw = sval + ns * ne;
-        const int    d  = tx;
-        float        o  = 0.f;
+    const float m  = wave_max(ms);
+    const float w  = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+    float*      sw = sval + ns * ne;
+    if (tx < ns) {
+        sw[tx] = w;
+    }
+    float L = 0.f;
+    for (int s2 = 0; s2 < ns; s2++) {
+        L += __shfl(w * ls, s2, 64);
+    }
+    const float inv = 1.f / (L + 1.e-6f);  // :1632
+#pragma unroll
+    for (int d = tx; d < DH; d += 64) {
+        float o = 0.f;
         for (int s2 = 0; s2 < ns; s2++) {
             o += sw[s2] * sval[s2 * ne + d];
         }
-        const float    inv = 1.f / (sw[ns] + 1.e-6f);  // :1632
-        const unsigned b0  = f16_bits((f16)(o * inv));
-        const unsigned b1  = __shfl_down(b0, 1, 64);
+        const unsigned b0 = f16_bits((f16)(o * inv));
+        const unsigned b1 = __shfl_down(b0, 1, 64);
         if ((d & 1) == 0) {
             st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
         }
@@ -719,11 +703,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         q += 64 * 4;
         s.lt1 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * E1 * 4;
-        s.ct1 = reinterpret_cast<unsigned*>(q);
-        q += (size_t)PS_NW * E1 * 4;
         s.lt3 = reinterpret_cast<unsigned*>(q);
-        q += (size_t)PS_NW * E3 * 4;
-        s.ct3 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * E3 * 4;
         s.bt1 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * (E1 / PS_U) * 4;
@@ -741,7 +721,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     const int nruns1 = g1 - g0, nruns3 = nB + nA;
     const int n_items = p.B * p.nh * p.plan.nsplit;
     if (threadIdx.x == 0) {
-        s.misc[0] = 0;
+        s.misc[0]  = 0;
+        s.misc[32] = 0;  // ctx arrival counter (+PS_NC per layer)
+        s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
     }
     __syncthreads();
     if ((int)threadIdx.x < nruns1) {  // P1: [QKV u FFN1] column groups g0..g1, full K each
@@ -827,28 +809,25 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         ctx_hi = ps_rfl(ctx_hi);
         const int w = ps_rfl(wid);
         int       tb, te;
-        ps_wave_range(T1, w, p.ctrl_share, tb, te);
+        ps_wave_range(T1, w, p.plan.cs1, tb, te);
+        int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
         sg1.lt   = s.lt1 + (size_t)w * E1;
-        sg1.ct   = s.ct1 + (size_t)w * E1;
-        sg1.nrot = (te - tb + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
+        sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
         sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
-        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.ct1 + (size_t)w * E1,
+        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
                             sg1.nrot * PS_U * PS_NBUF);
-        ps_wave_range(T3, w, p.ctrl_share, tb, te);
+        ps_wave_range(T3, w, p.plan.cs3, tb, te);
+        ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
         sg3.lt   = s.lt3 + (size_t)w * E3;
-        sg3.ct   = s.ct3 + (size_t)w * E3;
-        sg3.nrot = (te - tb + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
+        sg3.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
         sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
-        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.ct3 + (size_t)w * E3,
+        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
                             sg3.nrot * PS_U * PS_NBUF);
         sg1.xs0 = sg1.xs1 = H;
         sg3.xs0 = Il;
         sg3.xs1 = Hl;
-        sg1.bt  = s.bt1 + (size_t)w * (E1 / PS_U);
-        sg3.bt  = s.bt3 + (size_t)w * (E3 / PS_U);
-        __syncthreads();
-        ps_build_batches(sg1.ct, s.bt1 + (size_t)w * (E1 / PS_U), sg1.nrot * PS_NBUF);
-        ps_build_batches(sg3.ct, s.bt3 + (size_t)w * (E3 / PS_U), sg3.nrot * PS_NBUF);
     }
     __syncthreads();
 
@@ -861,8 +840,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         PsStream<INT8, M> st;
         auto stamp = [&](const int l, const int k) {
             const int lane = tid & 63, wid = tid >> 6;
-            if (p.ts && lane == 0 && (wid == 0 || wid == 2)) {
-                p.ts[(((size_t)bid * p.L + l) * 2 + (wid ? 1 : 0)) * 16 + k] = wall_clock64();
+            if (p.ts && lane == 0) {
+                p.ts[(((size_t)bid * p.L + l) * PS_NW + wid) * 16 + k] = wall_clock64();
             }
         };
         // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
@@ -941,7 +920,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
             st.bind(sg1, s.rsc, s.xs, s.part, tid);
             if constexpr (!CTRL) {
-                st.prime();
+                st.prime_lo();
             }
         };
         auto setup_p3 = [&](const int l) {
@@ -957,7 +936,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             load_p3_consts(l);
             sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
             sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
-            st.bind(sg3, s.rsc, s.xs, s.part, tid);
+            st.bind(sg3, s.rsc, s.xs, s.part, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
         };
 
         load_sc1(p.l_begin);
@@ -1043,11 +1022,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                     }
                 }
                 if constexpr (CTRL) {
-                    st.prime();
+                    st.prime_lo();
                 }
                 stamp(l, 2);
                 __syncthreads();
-                st.run();
+                st.template run<true>();
                 stamp(l, 3);
                 __syncthreads();
                 // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
@@ -1110,27 +1089,40 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 stamp(l, 6);
                 live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid);
             }
-            stamp(l, 7);
-            if constexpr (!CTRL) {
-                st.prime();  // the streamer waves issue no load between here and the end of the P3 stream
-            }
-            if (has_item && a_sp == 0) {
-                if (live) {
-                    ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
-                }
-                else {
-                    ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
-                }
-            }
-            stamp(l, 8);
-            // =========================== P3: [FFN2 u out-proj] -> residual ========================================
-            if constexpr (CTRL) {  // the K ranges of mid and ctx this workgroup's pieces read -> LDS
+            if constexpr (CTRL) {
+                // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there).
+                // Before the barrier, i.e. before the streamer waves' prefetch burst (a sweep queued behind the burst
+                // took 5 us), and after the attention (ahead of it, it made the attention wait for the slowest FFN1)
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
                                  p.err, 6, [&](const int i, const unsigned v) {
                                      reinterpret_cast<unsigned*>(s.xs + (size_t)m * Il + mid_lo)[i] = v;
                                  });
+                }
+            }
+            stamp(l, 7);
+            __syncthreads();  // mid staged, attention scratch free
+            stamp(l, 8);
+            if constexpr (!CTRL) {
+                // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
+                // and the control waves, which carry the attention's critical path, must not wait for it
+                st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
+            }
+            // =========================== P3: [FFN2 u out-proj] -> residual ========================================
+            // The streamer waves start on the FFN2 pieces at once; the control waves finish the attention (merge of the
+            // split partials by wave 0 of the split-0 workgroups), stage the K range of ctx the out-proj pieces read and
+            // announce it through an LDS counter that gates every batch touching ctx; their own share is the END of the
+            // workgroup's tile space, i.e. the out-proj pieces.
+            if constexpr (CTRL) {
+                if (has_item && a_sp == 0 && wid == 0) {
+                    if (live) {
+                        ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
+                    }
+                    else {
+                        ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
+                    }
+                    stamp(l, 13);
                 }
 #pragma unroll
                 for (int m = 0; m < M; m++) {
@@ -1139,11 +1131,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                                     reinterpret_cast<unsigned*>(s.xs + (size_t)M * Il + (size_t)m * Hl + ctx_lo)[i] = v;
                                 });
                 }
-                st.prime();
+                stamp(l, 14);
+                if (lane == 0) {
+                    atomicAdd(&s.misc[32], 1);  // DS operations of a wave execute in order: the writes above are visible
+                }
+                st.prime_lo();
             }
             stamp(l, 9);
-            __syncthreads();
-            st.run();
+            st.template run<true>();
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));
@@ -1236,7 +1231,18 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 }
             }
             stamp(l, 12);
-            __syncthreads();  // xraw is rewritten by the next layer's gather
+            // xraw is rewritten by the next layer's gather: only the two control waves touch it between here and the
+            // barrier after that gather, so they synchronise among themselves (the streamer waves are busy issuing
+            // their prefetch; a workgroup barrier here would make the gather wait for that)
+            if constexpr (CTRL) {
+                if (lane == 0) {
+                    atomicAdd(&s.misc[33], 1);
+                }
+                const int want = (l - p.l_begin + 1) * PS_NC;
+                while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[33]) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
         }
     };
     if (wid < PS_NC) {
@@ -1253,12 +1259,12 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
 static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3)
 {
     return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)PS_RMAX * PS_NW * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
-           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)2 * PS_NW * (e1 + e3) * 4
+           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (e1 + e3) * 4
            + (size_t)PS_NW * (e1 + e3) / PS_U * 4;
 }
 
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int ctrl_share)
+                         int cs1, int cs3)
 {
     PersistPlan pl{};
     const int   M  = B;
@@ -1266,7 +1272,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (M < 1 || M > 2 || (dh != 64 && dh != 128) || H % TK || Hl % TK || Il % TK || H % 16 || Hl % 16 || Il % 16) {
         return pl;
     }
-    if (ctrl_share < 1 || ctrl_share > 16 || H > PS_NLN * PS_NT * 8) {
+    if (cs1 < 1 || cs1 > 16 || cs3 < 1 || cs3 > 16 || H > PS_NLN * PS_NT * 8) {
         return pl;
     }
     const int NB = force_nb > 0 ? force_nb : num_cu;
@@ -1337,19 +1343,42 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (best > 1e29) {
         return pl;
     }
-    // tile-table entries per wave: largest wave share of the largest workgroup share, rounded up to whole rotations
-    const long t1max   = (long)((G + NB - 1) / NB) * KT;
-    const int  total   = PS_NC * ctrl_share + (PS_NW - PS_NC) * 16;
-    auto       entries = [&](long T) {
-        const long per = (T * 16 + total - 1) / total + 1;
-        const int  rot = PS_U * PS_NBUF;
-        return (int)((per + rot - 1) / rot * rot);
-    };
-    pl.e1         = entries(t1max);
-    pl.e3         = entries(t3max);
+    // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations
+    int e1 = 0, e3 = 0;
+    for (int b = 0; b < NB; b++) {
+        const int g0 = (int)((long)G * b / NB), g1 = (int)((long)G * (b + 1) / NB);
+        const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
+        const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);
+        const int nB = rB1 - rB0, nA = rA1 - rA0;
+        auto nt1 = [&](int) { return KT; };
+        auto nt3 = [&](int j) {
+            if (j < nB) {
+                const int t0 = ((rB0 + j) / NG) * pl.RLb;
+                return std::min(pl.RLb, KT_b - t0);
+            }
+            const int t0 = ((rA0 + j - nB) / NG) * pl.RLa;
+            return std::min(pl.RLa, KT_a - t0);
+        };
+        int T3 = 0;
+        for (int j = 0; j < nB + nA; j++) {
+            T3 += nt3(j);
+        }
+        for (int w = 0; w < PS_NW; w++) {
+            int tb, te;
+            ps_wave_range((g1 - g0) * KT, w, cs1, tb, te);
+            e1 = std::max(e1, ps_wave_entries(g1 - g0, nt1, tb, te));
+            ps_wave_range(T3, w, cs3, tb, te);
+            e3 = std::max(e3, ps_wave_entries(nB + nA, nt3, tb, te));
+        }
+    }
+    const int rot = PS_U * PS_NBUF;
+    pl.e1         = std::max(rot, (e1 + rot - 1) / rot * rot);
+    pl.e3         = std::max(rot, (e3 + rot - 1) / rot * rot);
+    (void)t3max;
     pl.NB         = NB;
     pl.nsplit     = nsplit;
-    pl.ctrl_share = ctrl_share;
+    pl.cs1        = cs1;
+    pl.cs3        = cs3;
     pl.xs_halves  = M * std::max(2 * H, Il + Hl);
     if (pl.xs_halves > 0x1ffff) {
         return pl;
@@ -1380,7 +1409,6 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    FTCF_CHECK_ARG(p.ctrl_share == p.plan.ctrl_share, "plan was made for another control-wave share");
 #define PS_CASE(I8, MM, D)                                                                                             \
     if (int8 == I8 && p.B == MM && p.dh == D) {                                                                        \
         launch_ps<I8, MM, D>(p, s);                                                                                    \
