@@ -225,6 +225,9 @@ def main():
         e2e_ms = (time.perf_counter() - t2) * 1e3
 
     # ---- roofline leg: HIP events around every weight-streaming launch of a short profiled run ----
+    KIND_NAMES = {0: "k_ln_gemv_group (LN1 -> QKV weight stream)", 1: "k_gemv_chunked (out-proj + FFN2 weight stream)",
+                  2: "k_lm_head", 3: "k_mmha_ln_gemv (attention || LN2 -> FFN1 weight stream)",
+                  4: "k_decode_persistent (all layers of one token: weights + KV cache)"}
     roof = None
     if a.profile_steps > 0:
         op.set_profiling(True)
@@ -239,8 +242,7 @@ def main():
             avg_ms = ps["gemv_ms_sum"] / ps["gemv_launches"]
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": None, "kernel": "k_ln_gemv (LN + QKV + FFN1 weight stream) or k_gemv_splitk, whichever "
-                    "dominates", "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
+                    "traffic": None, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
                     "launches": ps["gemv_launches"], "measured_over": f"{a.profile_steps} profiled decode steps"}
 
     if rank != 0:

@@ -390,8 +390,8 @@ struct ftcf_gptneox {
     uint64_t *draws = nullptr, *d_seed = nullptr;
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
-    // persistent decode layers (kernels_persist.hip): 0 off, 1 on when the shape is eligible
-    int                 persist = 0, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 14, persist_cs3 = 8;
+    // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
+    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 14, persist_cs3 = 8;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -625,11 +625,14 @@ struct ftcf_gptneox {
     {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         const double wbytes  = int8 ? 1.0 : 2.0;
+        stats.decode_path = pplan.ok ? 1 : (B <= 4 ? 0 : 2);
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
             // there is no collective between the layers
             PersistParams pp = persist_params(B, s_max);
-            const double layer_bytes = wbytes * ((double)H * 3 * hl + (double)H * il + (double)hl * H + (double)il * H);
+            // algorithmic bytes of a layer: its four weight matrices + the K/V rows of the current length
+            const double layer_bytes = wbytes * ((double)H * 3 * hl + (double)H * il + (double)hl * H + (double)il * H)
+                                       + 4.0 * ses.next_step * hl * B;
             if (cfg.tensor_para_size == 1 && !persist_per_layer) {
                 pp.l_begin = 0;
                 pp.l_end   = L;
@@ -1373,6 +1376,7 @@ extern "C" int ftcf_gptneox_get_stats(ftcf_gptneox_t h, ftcf_forward_stats* s)
                 best = k;
             }
         }
+        s->gemv_kind     = best;
         s->gemv_ms_sum   = (float)h->kind_ms[best];
         s->gemv_launches = h->kind_n[best];
         s->gemv_bytes    = h->kind_bytes[best];

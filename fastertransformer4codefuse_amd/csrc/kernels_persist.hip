@@ -41,6 +41,14 @@ constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
 constexpr int PS_MAXP     = 16;          // PA + PB
 constexpr int PS_SPIN     = 1 << 18;
 constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane
+#ifndef PS_FULL_P1_V
+#define PS_FULL_P1_V false
+#endif
+#ifndef PS_FULL_P3_V
+#define PS_FULL_P3_V false
+#endif
+// streamer waves: issue the whole first rotation (32 KiB) before the hand-off instead of half of it
+constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
 constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
 
 #define PS_RLX __ATOMIC_RELAXED
@@ -268,6 +276,8 @@ struct PsStream {
         prime_lo();
         prime_hi();
     }
+    // HI: the second half of the first rotation is still to be issued.  Compile time: a load under a run-time condition
+    // makes the compiler's vmcnt bookkeeping conservative for the whole stream (measured: 340 -> 192 tokens/s)
     template<bool HI>
     __device__ __forceinline__ void run()
     {
@@ -311,15 +321,21 @@ __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nrun
     if ((threadIdx.x & 63) != 0) {
         return;
     }
-    int e = 0, pre = 0;
+    int      e = 0, pre = 0;
+    unsigned pad = 0u;  // padding entries re-read the wave's OWN first tile (one shared address would be a hot spot)
+    bool     first = true;
     for (int j = 0; j < nruns; j++) {
         const RunRec r = rt[j];
         const int    a = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
         for (int t = a; t < b; t += PS_U) {
             const int cnt = (b - t < PS_U) ? b - t : PS_U;
             const int off = t - pre;
+            if (first) {
+                pad   = ((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off);
+                first = false;
+            }
             for (int u = 0; u < PS_U; u++) {
-                lt[e + u] = (u < cnt) ? (((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off + u)) : 0u;
+                lt[e + u] = (u < cnt) ? (((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off + u)) : pad;
             }
             bt[e / PS_U] = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
                            | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
@@ -330,7 +346,7 @@ __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nrun
     }
     for (; e < entries; e += PS_U) {
         for (int u = 0; u < PS_U; u++) {
-            lt[e + u] = 0u;
+            lt[e + u] = pad;
         }
         bt[e / PS_U] = 0u;
     }
@@ -921,6 +937,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             st.bind(sg1, s.rsc, s.xs, s.part, tid);
             if constexpr (!CTRL) {
                 st.prime_lo();
+                if constexpr (PS_FULL_P1) {
+                    st.prime_hi();
+                }
             }
         };
         auto setup_p3 = [&](const int l) {
@@ -1026,7 +1045,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 }
                 stamp(l, 2);
                 __syncthreads();
-                st.template run<true>();
+                st.template run<CTRL || !PS_FULL_P1>();
                 stamp(l, 3);
                 __syncthreads();
                 // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
@@ -1108,6 +1127,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
                 // and the control waves, which carry the attention's critical path, must not wait for it
                 st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
+                if constexpr (PS_FULL_P3) {
+                    st.prime_hi();
+                }
             }
             // =========================== P3: [FFN2 u out-proj] -> residual ========================================
             // The streamer waves start on the FFN2 pieces at once; the control waves finish the attention (merge of the
@@ -1138,7 +1160,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 st.prime_lo();
             }
             stamp(l, 9);
-            st.template run<true>();
+            st.template run<CTRL || !PS_FULL_P3>();
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));

@@ -16,6 +16,14 @@ def gh():
     return gpu_helpers
 
 
+@pytest.fixture(params=["persistent", "launches"], autouse=True)
+def decode_path(request, monkeypatch):
+    """Every engine test runs twice: with the persistent decode-layer kernel (default for B <= 2) and with the per-stage
+    launches (FTCF_PERSIST=0, also what B = 3, 4 always use).  The engine reads the variable when it is created."""
+    monkeypatch.setenv("FTCF_PERSIST", "1" if request.param == "persistent" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def tiny():
     cfg, w, z = load_tiny()
@@ -28,10 +36,11 @@ def _logit_close(got, ref, frac=0.02):
     assert np.abs(got - ref).max() <= frac * scale, (np.abs(got - ref).max(), scale)
 
 
-def test_tiny_fp16_greedy_is_token_exact_vs_hf_golden_and_oracle(gh, tiny):
+def test_tiny_fp16_greedy_is_token_exact_vs_hf_golden_and_oracle(gh, tiny, decode_path):
     cfg, w, layers, glob, z = tiny
     op = gh.make_op(cfg, w)
     r = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == (1 if decode_path == "persistent" else 0)  # the path under test really ran
     assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
     o = orc.Model(dict(cfg, fp16=1), layers, glob).generate(z["prompt"][None, :], [16], 8, return_logits=True)
     assert r["output_ids"].tolist() == o["output_ids"].tolist()
