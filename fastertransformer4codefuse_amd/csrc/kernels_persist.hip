@@ -312,43 +312,51 @@ struct PsStream {
 };
 
 // One wave fills its tables for a stage from the workgroup's static run table: every piece of a run the wave owns is
-// padded to whole batches (padding tiles re-read tile 0 of array 0 and are never consumed), so a batch never spans two
-// runs.  Serial on lane 0: ~100 entries, once per launch.
+// padded to whole batches (padding tiles re-read the wave's own first tile -- one shared address would be a hot spot --
+// and are never consumed), so a batch never spans two runs.  One lane per batch.
 template<int TK>
 __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
                                                 unsigned* lt, unsigned* bt, const int entries)
 {
-    if ((threadIdx.x & 63) != 0) {
-        return;
-    }
-    int      e = 0, pre = 0;
-    unsigned pad = 0u;  // padding entries re-read the wave's OWN first tile (one shared address would be a hot spot)
-    bool     first = true;
-    for (int j = 0; j < nruns; j++) {
-        const RunRec r = rt[j];
-        const int    a = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
-        for (int t = a; t < b; t += PS_U) {
-            const int cnt = (b - t < PS_U) ? b - t : PS_U;
-            const int off = t - pre;
-            if (first) {
-                pad   = ((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off);
-                first = false;
+    const int lane = threadIdx.x & 63;
+    // the wave's first tile (padding address): uniform
+    unsigned pad = 0u;
+    {
+        int pre = 0;
+        for (int j = 0; j < nruns; j++) {
+            const int nt = rt[j].nt;
+            if (tb < te && tb >= pre && tb < pre + nt) {
+                pad = ((unsigned)rt[j].sel << 31) | (unsigned)(rt[j].tile0 + tb - pre);
             }
-            for (int u = 0; u < PS_U; u++) {
-                lt[e + u] = (u < cnt) ? (((unsigned)r.sel << 31) | (unsigned)(r.tile0 + off + u)) : pad;
-            }
-            bt[e / PS_U] = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
-                           | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
-                           | ((unsigned)cnt << 27);
-            e += PS_U;
+            pre += nt;
         }
-        pre += r.nt;
     }
-    for (; e < entries; e += PS_U) {
+    for (int bi = lane; bi < entries / PS_U; bi += 64) {
+        // locate batch bi: pieces of the runs intersecting [tb, te), each padded to whole batches
+        int      pre = 0, eb = 0;  // tiles before run j, batches before run j's piece
+        unsigned bd  = 0u;
+        int      first = 0, cnt = 0, sel = 0;
+        for (int j = 0; j < nruns; j++) {
+            const RunRec r  = rt[j];
+            const int    a  = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
+            const int    nb = b > a ? (b - a + PS_U - 1) / PS_U : 0;
+            if (bi >= eb && bi < eb + nb) {
+                const int t   = a + (bi - eb) * PS_U;
+                const int off = t - pre;
+                cnt   = (b - t < PS_U) ? b - t : PS_U;
+                first = r.tile0 + off;
+                sel   = r.sel;
+                bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
+                     | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
+                     | ((unsigned)cnt << 27);
+            }
+            eb += nb;
+            pre += r.nt;
+        }
         for (int u = 0; u < PS_U; u++) {
-            lt[e + u] = pad;
+            lt[bi * PS_U + u] = (u < cnt) ? (((unsigned)sel << 31) | (unsigned)(first + u)) : pad;
         }
-        bt[e / PS_U] = 0u;
+        bt[bi] = bd;
     }
 }
 
@@ -727,6 +735,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     }
     const int      step     = *p.d_step;
     const unsigned tag_base = (unsigned)step * 256u + 1u;
+    if (p.ts && (threadIdx.x & 63) == 0) {  // kernel entry (slot 15 of the first layer)
+        p.ts[(((size_t)blockIdx.x * p.L + p.l_begin) * PS_NW + (threadIdx.x >> 6)) * 16 + 15] = wall_clock64();
+    }
 
     // ---- the workgroup's static share of the streaming stages ----
     const int G   = NT0 + Il / 16;
@@ -1061,10 +1072,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                         }
                         const int cg = g0 + j;
                         f16       o;
-                        u64*      dst;
                         if (cg < NT0) {
-                            o   = (f16)v;
-                            dst = p.gq + (((size_t)m * 3 * Hl + cg * 16 + c) >> 1);
+                            o = (f16)v;
                         }
                         else {
                             if constexpr (INT8) {
@@ -1073,12 +1082,18 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                             else {
                                 o = gelu_f16((f16)v + r_b1[k]);  // activation_kernels.cu:401-426
                             }
-                            dst = p.gm + (((size_t)m * Il + (cg - NT0) * 16 + c) >> 1);
                         }
                         const unsigned b0 = f16_bits(o);
                         const unsigned b1 = __shfl_down(b0, 1, 64);
                         if ((c & 1) == 0) {
-                            st_granule_u32(dst, tag, b0 | (b1 << 16));
+                            // (two stores, not one through a selected pointer: the compiler turns that select into a
+                            // table in scratch memory, and a kernel that uses scratch pays for it at every dispatch)
+                            if (cg < NT0) {
+                                st_granule_u32(p.gq + (((size_t)m * 3 * Hl + cg * 16 + c) >> 1), tag, b0 | (b1 << 16));
+                            }
+                            else {
+                                st_granule_u32(p.gm + (((size_t)m * Il + (cg - NT0) * 16 + c) >> 1), tag, b0 | (b1 << 16));
+                            }
                         }
                     }
                 }

@@ -23,3 +23,8 @@ for k in range(15):
 if L > 1:
     per = ts[:, 1:, 0, 0] - ts[:, :-1, 0, 0]
     print("per-layer time (layer-top to layer-top), us: median %.2f  min %.2f  max %.2f" % (np.median(per), per.min(), per.max()))
+e = ts[:, 0, :, 15]
+if (e > 0).all():
+    print("kernel entry -> first layer top (preamble), us: median %.2f max %.2f ; entry skew across workgroups %.2f" % (
+        np.median(ts[:, 0, :, 0] - e), (ts[:, 0, :, 0] - e).max(), e.max() - e.min()))
+    print("kernel entry (first wg) -> last layer's x' merged (last wg): %.2f us" % (ts[:, L - 1, :, 12].max() - e.min()))
