@@ -80,9 +80,10 @@ MID = dict(head_num=8, size_per_head=128, inter_size=4096, num_layer=2, vocab_si
 
 
 @pytest.mark.parametrize("int8_mode", [0, 1])
-@pytest.mark.parametrize("B", [1, 3, 6])
+@pytest.mark.parametrize("B", [1, 2, 3, 6])
 def test_mid_model_fused_and_general_decode_paths(gh, B, int8_mode):
-    """H=1024/Dh=128: B<=4 runs the fused GEMV path, B=6 the general (MFMA GEMM) path; both must follow the oracle."""
+    """H=1024/Dh=128: B<=2 runs the persistent layer kernel (or the per-stage launches, see `decode_path`), B<=4 the
+    per-stage GEMV launches, B=6 the general (MFMA GEMM) path; all must follow the oracle."""
     cfg = MID
     w = random_model(cfg, seed=B + 10 * int8_mode, std=0.04)
     layers, glob = weight_list_to_layers(cfg, w)
@@ -158,3 +159,41 @@ def test_engine_is_deterministic_across_calls(gh, tiny):
     a = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
     b = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
     assert np.array_equal(a["logits"], b["logits"]) and np.array_equal(a["output_ids"], b["output_ids"])
+
+
+@pytest.mark.parametrize("variant", ["per_layer", "grid24", "grid40"])
+@pytest.mark.parametrize("int8_mode", [0, 1])
+def test_persistent_kernel_variants_agree(gh, monkeypatch, decode_path, variant, int8_mode):
+    """The persistent decode-layer kernel under other launch shapes: one launch per layer (what tensor parallelism uses,
+    the layer input / output then travel through plain memory instead of granules) must be bit-identical to the
+    one-launch-per-token form; a grid of 24 or 40 workgroups (several runs and attention splits per workgroup, other K
+    piece counts) changes the fp32 summation order only, so it stays within the GEMV tolerance of the default grid."""
+    if decode_path != "persistent":
+        pytest.skip("variants of the persistent path only")
+    cfg = MID
+    w = random_model(cfg, seed=77 + int8_mode, std=0.04)
+    rng = np.random.RandomState(5)
+    B, S, out = 2, 21, 10
+    lens = np.array([S, 13], dtype=np.int32)
+    ids = np.full((B, S), cfg["end_id"], dtype=np.int32)
+    for b in range(B):
+        ids[b, :lens[b]] = rng.randint(3, cfg["vocab_size"], size=lens[b])
+    op = gh.make_op(cfg, w, int8_mode=int8_mode)
+    ref = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 1
+    if variant == "per_layer":
+        monkeypatch.setenv("FTCF_PERSIST_PER_LAYER", "1")
+    else:
+        monkeypatch.setenv("FTCF_PERSIST_NB", variant[4:])
+    op2 = gh.make_op(cfg, w, int8_mode=int8_mode)
+    got = gh.run_op(op2, ids, lens, out, cfg["vocab_size"], top_k=1)
+    assert op2.stats()["decode_path"] == 1
+    if variant == "per_layer":
+        np.testing.assert_array_equal(got["logits"], ref["logits"])
+        assert got["output_ids"].tolist() == ref["output_ids"].tolist()
+    else:
+        for t in range(out):
+            for b in range(B):
+                _logit_close(got["logits"][t, b], ref["logits"][t, b], frac=0.02)
+                if got["output_ids"][b, lens[b] + t] != ref["output_ids"][b, lens[b] + t]:
+                    break
