@@ -502,7 +502,10 @@ struct ftcf_gptneox {
             rot_table          = c.take<float>((size_t)B * 256);
             chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, B <= 4 ? B : 1, 8) / 8);
             pplan = PersistPlan{};
-            if (persist && B <= 2) {
+            // With tensor parallelism there is a collective between the layers: the persistent kernel would run one
+            // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
+            // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
+            if (persist && B <= 2 && (cfg.tensor_para_size == 1 || persist_per_layer)) {
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
             }
             if (pplan.ok) {
