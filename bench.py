@@ -241,8 +241,19 @@ def main():
             per_launch_bytes = ps["gemv_bytes"] / ps["gemv_launches"]
             avg_ms = ps["gemv_ms_sum"] / ps["gemv_launches"]
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            # HBM traffic of that kernel from the PMC pass recorded under profiles/ (collected in its own rocprofv3 run, as
+            # the counters cannot ride along with this timing run); only quoted when it was measured on this very config
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_int8_tp1.json")))
+                c = pm["config"]
+                if (ps["gemv_kind"] == 4 and a.dtype == c["dtype"] and world == c["tensor_parallel"] and a.layers == c["layers"]
+                        and H == c["hidden"] and a.inter == c["inter"] and a.batch == 1):
+                    traffic = pm["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": None, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
+                    "traffic": traffic, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
                     "launches": ps["gemv_launches"], "measured_over": f"{a.profile_steps} profiled decode steps"}
 
     if rank != 0:
