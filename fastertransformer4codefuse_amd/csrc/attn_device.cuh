@@ -343,7 +343,7 @@ __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int&
 {
     (void)s_last;
     const int      step = p.d_step ? *p.d_step : p.step;
-    const unsigned tag  = (unsigned)(step * 256 + p.layer) + 1u;  // num_layer <= 256 (checked at create)
+    const unsigned tag  = (unsigned)(step * 1024 + p.layer) + 1u;  // salt < 1024: layer + row group * num_layer
     u64*           gall = p.gran + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
     const bool     live = mmha_partial<DH>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
     if (!live || sp != 0 || p.dbg_stop == 5) {

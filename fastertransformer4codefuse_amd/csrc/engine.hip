@@ -172,7 +172,7 @@ extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, vo
 // kernel-level entry points
 // ---------------------------------------------------------------------------------------------------------------
 static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m,
-                          int n, int k, bool int8, hipStream_t s)
+                          int n, int k, bool int8, hipStream_t s, float* smallm_ws = nullptr, int num_cu = 256)
 {
     if (m <= 4) {
         SplitKParams p{};
@@ -189,6 +189,9 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
         static const int dbg_waves = getenv("FTCF_SPLITK_WAVES") ? atoi(getenv("FTCF_SPLITK_WAVES")) : 4;
         plan_splitk(p, int8, m, dbg_waves);
         launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
+    }
+    else if (m <= 16) {
+        launch_gemm_smallm(A, W, scale, bias, act, C, smallm_ws, m, n, k, int8, num_cu, s);
     }
     else {
         launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s);
@@ -362,11 +365,8 @@ struct ftcf_gptneox {
     bool                      int8 = false;
     // `stream` is the engine's own work stream (capturable, unlike the legacy null stream torch usually hands over);
     // it is ordered after `user_stream` at begin() and drained before forward()/finish() return
-    hipStream_t               stream = nullptr, stream2 = nullptr, user_stream = nullptr;
-    hipEvent_t                ev_fork = nullptr, ev_join = nullptr, ev_user = nullptr;
-    // 0: 3 launches/layer (K1, K2 = MMHA || FFN1, K3) -- default; 2: two concurrent stream chains (measured slower:
-    // cross-stream fork/join costs 5-10 us each on this runtime, profiles/r01 notes)
-    int                       decode_mode = 0;
+    hipStream_t               stream = nullptr, user_stream = nullptr;
+    hipEvent_t                ev_user = nullptr;
     int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
@@ -388,6 +388,7 @@ struct ftcf_gptneox {
         *d_min_length = nullptr;
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
+    float*    smallm_ws = nullptr;  // split-K partials of the batched decode GEMM (5..16 rows)
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
@@ -415,20 +416,11 @@ struct ftcf_gptneox {
         for (void* p : owned) {
             (void)hipFree(p);
         }
-        if (stream2) {
-            (void)hipStreamDestroy(stream2);
-        }
         if (stream) {
             (void)hipStreamDestroy(stream);
         }
         if (ev_user) {
             (void)hipEventDestroy(ev_user);
-        }
-        if (ev_fork) {
-            (void)hipEventDestroy(ev_fork);
-        }
-        if (ev_join) {
-            (void)hipEventDestroy(ev_join);
         }
         if (h_flags) {
             (void)hipHostFree(h_flags);
@@ -500,7 +492,7 @@ struct ftcf_gptneox {
             mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
             samp_ws            = c.take<char>(sampling_workspace_bytes(B, V));
             rot_table          = c.take<float>((size_t)B * 256);
-            chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, B <= 4 ? B : 1, 8) / 8);
+            chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, std::min(B, 4), 8) / 8);
             pplan = PersistPlan{};
             // With tensor parallelism there is a collective between the layers: the persistent kernel would run one
             // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
@@ -521,6 +513,8 @@ struct ftcf_gptneox {
                 d_players   = c.take<PersistLayer>(L);
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
+            smallm_ws = (B > 4 && B <= 16) ? c.take<float>(gemm_smallm_workspace_bytes(B, std::max(std::max(3 * hl, il), H)) / 4)
+                                           : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -555,7 +549,7 @@ struct ftcf_gptneox {
     // ---- FfnLayer / attention projections over M rows (general path) ----
     void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
     {
-        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream);
+        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, smallm_ws, num_cu);
     }
 
     void allreduce(f16* buf, size_t count)
@@ -626,9 +620,8 @@ struct ftcf_gptneox {
     // GptNeoXDecoder::forward (GptNeoXDecoder.cc:245-384)
     void decoder(int B, int s_max)
     {
-        const size_t cache_l = (size_t)B * nhl * s_max * dh;
         const double wbytes  = int8 ? 1.0 : 2.0;
-        stats.decode_path = pplan.ok ? 1 : (B <= 4 ? 0 : 2);
+        stats.decode_path = pplan.ok ? 1 : (B <= STAGE_MAX_ROWS ? 0 : 2);
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
             // there is no collective between the layers
@@ -655,178 +648,20 @@ struct ftcf_gptneox {
             const LayerWeights& w = layers[l];
             // layer_input/output alias for 0 < l < L-1 in the reference (:249-250) -> which residual form it runs
             const int inplace = (l > 0 && l < L - 1) ? 1 : 0;
-            MmhaParams mp{};
-            mp.qkv = qkv;
-            mp.qkv_bias = w.qkv.bias;
-            mp.k_cache = k_cache + l * cache_l;
-            mp.v_cache = v_cache + l * cache_l;
-            mp.seq_len = seq_len;
-            mp.pad_count = pad_count;
-            mp.masked_tokens = masked;
-            mp.finished = finished;
-            mp.d_step = &state->step;
-            mp.rot_table = rot_table;
-            mp.B = B;
-            mp.nh = nhl;
-            mp.dh = dh;
-            mp.rot = cfg.rotary_embedding_dim;
-            mp.s_max = s_max;
-            mp.ctx = ctx;
-            mp.gran = (unsigned long long*)mmha_ws;
-            mp.layer = l;
-            mp.nsplit = nsplit;
-            if (B <= 4 && decode_mode == 2) {
-                // Two concurrent dependency chains per layer (parallel residual, GptNeoXDecoder.cc:267-356):
-                //   chain A (side stream): LN2 -> FFN1 + bias + gelu  ->  FFN2                      (2 x 104.9 MB/TP)
-                //   chain B (main stream): LN1 -> QKV -> MMHA -> [wait A] out-proj + residual       (78.6 + KV + 26.2 MB/TP)
-                // The chains only meet in the residual epilogue, so the attention's latency chain and every kernel's
-                // ramp / tail overlap with the other chain's weight streaming instead of idling HBM.
-                const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
-                FTCF_HIP_CHECK(hipEventRecord(ev_fork, stream));
-                FTCF_HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
-                LnGemvParams f{};
-                f.x = x;
-                f.gamma1 = w.ln2_g;
-                f.beta1 = w.ln2_b;
-                f.W1 = w.ffn1.kernel;
-                f.scale1 = w.ffn1.scale;
-                f.bias1 = w.ffn1.bias;
-                f.out1 = mid;
-                f.K = H;
-                f.NT0 = 0;
-                f.NT1 = il / 16;
-                f.blocks0 = 0;
-                f.blocks1 = (f.NT1 + 3) / 4;
-                f.eps = 1e-5f;
-                launch_ln_gemv(f, int8, B, stream2);
-                SplitKParams f2{};
-                f2.x_a = mid;
-                f2.W_a = w.ffn2.kernel;
-                f2.scale_a = w.ffn2.scale;
-                f2.out = ffn;
-                f2.N = H;
-                f2.KT_a = il / tk;
-                f2.tp = 1;
-                plan_splitk(f2, int8, B, 8);
-                launch_gemv_splitk(f2, int8, B, EPI_PLAIN, stream2);
-                FTCF_HIP_CHECK(hipEventRecord(ev_join, stream2));
-                LnGemvParams a{};
-                a.x = x;
-                a.gamma0 = w.ln1_g;
-                a.beta0 = w.ln1_b;
-                a.W0 = w.qkv.kernel;
-                a.scale0 = w.qkv.scale;
-                a.out0 = qkv;
-                a.K = H;
-                a.NT0 = 3 * hl / 16;
-                a.blocks0 = (a.NT0 + 3) / 4;
-                a.eps = 1e-5f;
-                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] { launch_ln_gemv(a, int8, B, stream); });
-                launch_mmha(mp, stream);
-                FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
-                SplitKParams c{};
-                c.x_a = ctx;
-                c.W_a = w.attn_out.kernel;
-                c.scale_a = w.attn_out.scale;
-                c.bias = w.ffn2.bias;
-                c.x_in = x;
-                c.ffn_in = ffn;
-                c.out = x;
-                c.N = H;
-                c.KT_a = hl / tk;
-                c.tp = cfg.tensor_para_size;
-                c.inplace_variant = inplace;
-                plan_splitk(c, int8, B, 4);
-                timed(KIND_SPLITK, wbytes * H * (double)hl,
-                      [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
-            }
-            else             if (B <= 4) {
-                // fused path, 3 launches per layer:
-                //   K1  LN1 -> QKV                                  (78.6 MB/TP int8)
-                //   K2  MMHA  ||  LN2 -> FFN1 + bias + gelu         (attention hidden under 104.9 MB/TP of streaming)
-                //   K3  [out-proj U FFN2] -> residual               (131 MB/TP)
-                LnGemvParams a{};
-                a.x = x;
-                a.gamma0 = w.ln1_g;
-                a.beta0 = w.ln1_b;
-                a.W0 = w.qkv.kernel;
-                a.scale0 = w.qkv.scale;
-                a.out0 = qkv;
-                a.K = H;
-                a.NT0 = 3 * hl / 16;
-                a.NT1 = 0;
-                a.blocks0 = (a.NT0 + 3) / 4;
-                a.blocks1 = 0;
-                a.eps = 1e-5f;
-                timed(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] {
-                    if (k1_wpg > 0) {
-                        launch_ln_gemv_group(a, int8, B, k1_wpg, stream);
+            if (B <= STAGE_MAX_ROWS) {
+                // Per-stage launches over row groups of <= 4 rows (the GEMV kernels' register budget).  STAGE_MAX_ROWS > 4
+                // would replay every stage per group; measured no faster than the batched GEMM path (the m = 4 forms
+                // of these kernels stream at half the m = 1 rate), so larger batches take the small-m GEMM below.
+                const int ngrp = (B + 3) / 4;
+                for (int stage = 0; stage < 3; stage++) {
+                    for (int rg = 0; rg < ngrp; rg++) {
+                        const int r0 = rg * 4, M = std::min(4, B - r0);
+                        stage_launch(stage, l, w, inplace, B, s_max, r0, M, l + rg * L, ngrp == 1);
                     }
-                    else {
-                        launch_ln_gemv(a, int8, B, stream);
-                    }
-                });
-                LnGemvParams f{};
-                f.x = x;
-                f.gamma1 = w.ln2_g;
-                f.beta1 = w.ln2_b;
-                f.W1 = w.ffn1.kernel;
-                f.scale1 = w.ffn1.scale;
-                f.bias1 = w.ffn1.bias;
-                f.out1 = mid;
-                f.K = H;
-                f.NT0 = 0;
-                f.NT1 = il / 16;
-                f.blocks0 = 0;
-                f.blocks1 = f.NT1 / 2;  // two column groups per workgroup (NT1 is even: local inter is a multiple of 64)
-                f.eps = 1e-5f;
-                timed(KIND_FUSED, wbytes * H * (double)il, [&] { launch_mmha_ln_gemv(mp, f, int8, B, stream); });
-                const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
-                if (k3_q > 0) {
-                    ChunkParams c{};
-                    c.x_a = ctx;
-                    c.x_b = mid;
-                    c.W_a = w.attn_out.kernel;
-                    c.W_b = w.ffn2.kernel;
-                    c.scale_a = w.attn_out.scale;
-                    c.scale_b = w.ffn2.scale;
-                    c.bias = w.ffn2.bias;
-                    c.x_in = x;
-                    c.out = x;
-                    c.N = H;
-                    c.KT_a = hl / tk;
-                    c.KT_b = il / tk;
-                    c.Q = k3_q;
-                    c.T = (c.KT_a + c.KT_b + c.Q - 1) / c.Q;
-                    c.tp = cfg.tensor_para_size;
-                    c.inplace_variant = inplace;
-                    c.gran = chunk_ws;
-                    c.d_step = &state->step;
-                    c.salt = l;
-                    timed(KIND_SPLITK, wbytes * H * ((double)hl + il), [&] { launch_gemv_chunked(c, int8, B, stream); });
-                }
-                else {
-                    SplitKParams c{};
-                    c.x_a = ctx;
-                    c.x_b = mid;
-                    c.W_a = w.attn_out.kernel;
-                    c.W_b = w.ffn2.kernel;
-                    c.scale_a = w.attn_out.scale;
-                    c.scale_b = w.ffn2.scale;
-                    c.bias = w.ffn2.bias;
-                    c.x_in = x;
-                    c.out = x;
-                    c.N = H;
-                    c.KT_a = hl / tk;
-                    c.KT_b = il / tk;
-                    c.tp = cfg.tensor_para_size;
-                    c.inplace_variant = inplace;
-                    plan_splitk(c, int8, B, 10);
-                    timed(KIND_SPLITK, wbytes * H * ((double)hl + il),
-                          [&] { launch_gemv_splitk(c, int8, B, EPI_RESIDUAL, stream); });
                 }
             }
             else {
+                MmhaParams mp = mmha_params(l, w, B, s_max, 0, B, l);
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
                 gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
                 launch_mmha(mp, stream);
@@ -838,6 +673,143 @@ struct ftcf_gptneox {
                                                   true, stream);
             }
             allreduce(x, (size_t)B * H);
+        }
+    }
+
+    static constexpr int STAGE_MAX_ROWS = 4;
+
+    // decoder attention of rows [r0, r0 + M) of the batch (KV cache [L][B][nh][s_max][dh]); `salt` makes the granule
+    // tags of every launch of a token distinct
+    MmhaParams mmha_params(int l, const LayerWeights& w, int B, int s_max, int r0, int M, int salt)
+    {
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        const size_t row_kv  = (size_t)nhl * s_max * dh;
+        MmhaParams   mp{};
+        mp.qkv = qkv + (size_t)r0 * 3 * hl;
+        mp.qkv_bias = w.qkv.bias;
+        mp.k_cache = k_cache + l * cache_l + r0 * row_kv;
+        mp.v_cache = v_cache + l * cache_l + r0 * row_kv;
+        mp.seq_len = seq_len + r0;
+        mp.pad_count = pad_count + r0;
+        mp.masked_tokens = masked + (size_t)r0 * s_max;
+        mp.finished = finished + r0;
+        mp.d_step = &state->step;
+        mp.rot_table = rot_table + (size_t)r0 * (cfg.rotary_embedding_dim / 2) * 2;
+        mp.B = M;
+        mp.nh = nhl;
+        mp.dh = dh;
+        mp.rot = cfg.rotary_embedding_dim;
+        mp.s_max = s_max;
+        mp.ctx = ctx + (size_t)r0 * hl;
+        mp.gran = (unsigned long long*)mmha_ws + (size_t)r0 * nhl * nsplit * (dh + 2);
+        mp.layer = salt;
+        mp.nsplit = nsplit;
+        return mp;
+    }
+
+    // One of the three launches of a layer for rows [r0, r0 + M), M <= 4:
+    //   0: K1  LN1 -> QKV                                  (78.6 MB/TP int8)
+    //   1: K2  MMHA  ||  LN2 -> FFN1 + bias + gelu         (attention hidden under 104.9 MB/TP of streaming)
+    //   2: K3  [out-proj U FFN2] -> residual               (131 MB/TP)
+    void stage_launch(int stage, int l, const LayerWeights& w, int inplace, int B, int s_max, int r0, int M, int salt,
+                      bool time_it)
+    {
+        const double wbytes = int8 ? 1.0 : 2.0;
+        f16*         xr     = x + (size_t)r0 * H;
+        auto run = [&](int kind, double bytes, auto&& f) {
+            if (time_it) {
+                timed(kind, bytes, f);
+            }
+            else {
+                f();
+            }
+        };
+        if (stage == 0) {
+            LnGemvParams a{};
+            a.x = xr;
+            a.gamma0 = w.ln1_g;
+            a.beta0 = w.ln1_b;
+            a.W0 = w.qkv.kernel;
+            a.scale0 = w.qkv.scale;
+            a.out0 = qkv + (size_t)r0 * 3 * hl;
+            a.K = H;
+            a.NT0 = 3 * hl / 16;
+            a.NT1 = 0;
+            a.blocks0 = (a.NT0 + 3) / 4;
+            a.blocks1 = 0;
+            a.eps = 1e-5f;
+            run(KIND_LN_GEMV, wbytes * H * (3.0 * hl), [&] {
+                if (k1_wpg > 0) {
+                    launch_ln_gemv_group(a, int8, M, k1_wpg, stream);
+                }
+                else {
+                    launch_ln_gemv(a, int8, M, stream);
+                }
+            });
+        }
+        else if (stage == 1) {
+            MmhaParams   mp = mmha_params(l, w, B, s_max, r0, M, salt);
+            LnGemvParams f{};
+            f.x = xr;
+            f.gamma1 = w.ln2_g;
+            f.beta1 = w.ln2_b;
+            f.W1 = w.ffn1.kernel;
+            f.scale1 = w.ffn1.scale;
+            f.bias1 = w.ffn1.bias;
+            f.out1 = mid + (size_t)r0 * il;
+            f.K = H;
+            f.NT0 = 0;
+            f.NT1 = il / 16;
+            f.blocks0 = 0;
+            f.blocks1 = f.NT1 / 2;  // two column groups per workgroup (NT1 is even: local inter is a multiple of 64)
+            f.eps = 1e-5f;
+            run(KIND_FUSED, wbytes * H * (double)il, [&] { launch_mmha_ln_gemv(mp, f, int8, M, stream); });
+        }
+        else {
+            const int tk = int8 ? TILE_K_I8 : TILE_K_F16;
+            if (k3_q > 0) {
+                ChunkParams c{};
+                c.x_a = ctx + (size_t)r0 * hl;
+                c.x_b = mid + (size_t)r0 * il;
+                c.W_a = w.attn_out.kernel;
+                c.W_b = w.ffn2.kernel;
+                c.scale_a = w.attn_out.scale;
+                c.scale_b = w.ffn2.scale;
+                c.bias = w.ffn2.bias;
+                c.x_in = xr;
+                c.out = xr;
+                c.N = H;
+                c.KT_a = hl / tk;
+                c.KT_b = il / tk;
+                c.Q = k3_q;
+                c.T = (c.KT_a + c.KT_b + c.Q - 1) / c.Q;
+                c.tp = cfg.tensor_para_size;
+                c.inplace_variant = inplace;
+                c.gran = chunk_ws;
+                c.d_step = &state->step;
+                c.salt = salt;
+                run(KIND_SPLITK, wbytes * H * ((double)hl + il), [&] { launch_gemv_chunked(c, int8, M, stream); });
+            }
+            else {
+                SplitKParams c{};
+                c.x_a = ctx + (size_t)r0 * hl;
+                c.x_b = mid + (size_t)r0 * il;
+                c.W_a = w.attn_out.kernel;
+                c.W_b = w.ffn2.kernel;
+                c.scale_a = w.attn_out.scale;
+                c.scale_b = w.ffn2.scale;
+                c.bias = w.ffn2.bias;
+                c.x_in = xr;
+                c.out = xr;
+                c.N = H;
+                c.KT_a = hl / tk;
+                c.KT_b = il / tk;
+                c.tp = cfg.tensor_para_size;
+                c.inplace_variant = inplace;
+                plan_splitk(c, int8, M, 10);
+                run(KIND_SPLITK, wbytes * H * ((double)hl + il),
+                    [&] { launch_gemv_splitk(c, int8, M, EPI_RESIDUAL, stream); });
+            }
         }
     }
 
@@ -948,7 +920,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     hipEvent_t e0 = get_event(), e1 = get_event();
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
-    FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, B <= 4 ? B : 1, 8), stream));
+    FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, std::min(B, 4), 8), stream));
     if (pplan.ok) {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         std::vector<PersistLayer> pl(L);
@@ -1287,12 +1259,6 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->final_b = (const f16*)w->weights[12 * L + 2];
         e->lm_head = (const f16*)w->weights[12 * L + 3];
         FTCF_CHECK_ARG(e->wte && e->final_g && e->final_b && e->lm_head, "missing embedding / final layernorm / lm_head");
-        FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-        if (const char* m = getenv("FTCF_DECODE_MODE")) {
-            e->decode_mode = atoi(m);
-        }
         e->k3_q = chunk_pick_q(e->H / 16, (e->hl + e->il) / (e->int8 ? TILE_K_I8 : TILE_K_F16));
         if (const char* m = getenv("FTCF_K3_Q")) {
             e->k3_q = atoi(m);

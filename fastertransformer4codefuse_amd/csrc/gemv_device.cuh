@@ -9,6 +9,10 @@ namespace ftcf {
 #define FTCF_GEMV_U 8
 #endif
 constexpr int GEMV_U = FTCF_GEMV_U;  // tiles per batch (x2 batches in flight)
+// The rows of x staged in LDS are XPAD halves (16 B) further apart than their length: K is a multiple of 64 halves, so
+// unpadded rows start in the same bank and the A-fragment reads of m rows conflict m ways (measured: the m = 4 GEMV
+// step took 1.7x the m = 1 step although the MFMA work is identical)
+constexpr int XPAD = 8;
 
 template<bool INT8>
 struct TileK {
@@ -131,7 +135,7 @@ template<bool INT8, int M>
 __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem, const int block_id)
 {
     f16*   xs  = reinterpret_cast<f16*>(smem);                      // [M][K]
-    float* red = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*4 floats
+    float* red = reinterpret_cast<float*>(smem + (size_t)M * (p.K + XPAD) * 2);  // 2*4 floats
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int seg  = (block_id >= p.blocks0) ? 1 : 0;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
                     for (int e = 0; e < 8; e++) {
                         o[e] = (((xv[m][j][e] - mh) * rh) * gv[j][e]) + bv[j][e];
                     }
-                    *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+                    *reinterpret_cast<f16x8*>(xs + (size_t)m * (K + XPAD) + i) = o;
                 }
             }
         }
@@ -226,7 +230,7 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
                 for (int j = 0; j < 8; j++) {
                     o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
                 }
-                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * (K + XPAD) + i) = o;
             }
         }
         if (active) {
@@ -244,7 +248,7 @@ __device__ __forceinline__ void ln_gemv_block(const LnGemvParams& p, char* smem,
         scale2       = f16x2{sc, sc};
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    ws.run(wp, KT, a_frag_ptr<INT8, M>(xs, K, lane), scale2, acc);
+    ws.run(wp, KT, a_frag_ptr<INT8, M>(xs, K + XPAD, lane), scale2, acc);
     if (g == 0) {
         f16*      out = seg ? p.out1 : p.out0;
         const int N   = NT * 16;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char*
     const int nw   = blockDim.x >> 6;
     const int wpg  = nw / gpb;
     f16*      xs   = reinterpret_cast<f16*>(smem);                          // [M][K]
-    float*    red  = reinterpret_cast<float*>(smem + (size_t)M * p.K * 2);  // 2*nw floats (LN), then [nw][M][16]
+    float*    red  = reinterpret_cast<float*>(smem + (size_t)M * (p.K + XPAD) * 2);  // 2*nw floats (LN), then [nw][M][16]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int gsel = wid / wpg, kw = wid - gsel * wpg;
     const int gi   = block_id * gpb + gsel;
@@ -374,7 +378,7 @@ __device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char*
                 for (int j = 0; j < 8; j++) {
                     o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
                 }
-                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
+                *reinterpret_cast<f16x8*>(xs + (size_t)m * (K + XPAD) + i) = o;
             }
         }
     }
@@ -386,7 +390,7 @@ __device__ __forceinline__ void ln_gemv_group_block(const LnGemvParams& p, char*
         scale2       = f16x2{sc, sc};
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    ws.run(wp, nt, a_frag_ptr<INT8, M>(xs + (size_t)t0 * TK, K, lane), scale2, acc);
+    ws.run(wp, nt, a_frag_ptr<INT8, M>(xs + (size_t)t0 * TK, K + XPAD, lane), scale2, acc);
     float* part = red + 2 * nw;  // [nw][M][16]
     if (g == 0) {
 #pragma unroll

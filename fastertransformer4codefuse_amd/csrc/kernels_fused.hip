@@ -38,7 +38,7 @@ static void launch_m(const MmhaParams& ap, const LnGemvParams& gp, hipStream_t s
 {
     const int    n_attn = ap.nh * ap.B * ap.nsplit;
     const size_t smem_a = mmha_smem_bytes(ap.dh, ap.s_max, ap.nsplit);
-    const size_t smem_g = (size_t)M * gp.K * 2 + (2 * 4 + 4 * M * 16) * sizeof(float);
+    const size_t smem_g = (size_t)M * (gp.K + XPAD) * 2 + (2 * 4 + 4 * M * 16) * sizeof(float);
     const size_t smem   = std::max(smem_a, smem_g);
     static const int dbg = getenv("FTCF_K2_DEBUG") ? atoi(getenv("FTCF_K2_DEBUG")) : 0;  // timing experiments only
     int grid = n_attn + gp.blocks0 + gp.blocks1;

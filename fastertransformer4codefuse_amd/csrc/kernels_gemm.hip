@@ -16,6 +16,30 @@
 namespace ftcf {
 
 constexpr int GEMM_KSTEP = 64;
+
+// one 16-byte weight fragment against the 16 rows of x in LDS (xr: this lane's row lane&15, k group lane>>4)
+template<bool INT8>
+__device__ __forceinline__ void consume_tile_raw(const u32x4 w, const f16* xr, const f16x2 scale2, f32x4& acc)
+{
+    if constexpr (INT8) {
+        f16x2 d[8];
+        dequant4(w.x, scale2, d[0], d[1]);
+        dequant4(w.y, scale2, d[2], d[3]);
+        dequant4(w.z, scale2, d[4], d[5]);
+        dequant4(w.w, scale2, d[6], d[7]);
+        const f16x8 b0 = {d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
+        const f16x8 b1 = {d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(xr);
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(xr + 8);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc, 0, 0, 0);
+    }
+    else {
+        const f16x8 b0 = __builtin_bit_cast(f16x8, w);
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(xr);
+        acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
+    }
+}
 constexpr int GEMM_LDA   = GEMM_KSTEP + 8;  // halves per LDS row (16 B pad)
 
 template<bool INT8, int RG>
@@ -195,6 +219,235 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched decode GEMM, 5 <= m <= 16 rows: HBM bound like the GEMV kernels, so it is built like them -- every wave streams
+// the K extent of ONE 16-column group with two register batches of 8 tiles in flight -- while the (L2 resident)
+// activations of the 4 waves' common K range pass through LDS in double-buffered chunks of 8 tiles (one barrier per chunk).
+// A 16x16x32 MFMA tile takes 16 rows for the price of one, so the weights are read once for the whole batch (the tiled
+// GEMM above is shaped for prefill: one 1 KiB weight tile in flight per wave, 11x off the HBM roofline at m = 16).
+// Small n (out-proj, FFN2) are cut along K as well (grid.y): partial sums go to an fp32 workspace [ks][m][n] and
+// k_smallm_reduce adds them in split order and applies the epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SM_U = 8;  // tiles per chunk / register batch
+
+template<bool INT8>
+__global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, const void* __restrict__ W,
+                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
+                                                     int act, f16* __restrict__ C, float* __restrict__ partial, int m,
+                                                     int n, int k)
+{
+    constexpr int TK  = INT8 ? TILE_K_I8 : TILE_K_F16;
+    constexpr int KC  = SM_U * TK;  // k per chunk
+    constexpr int LDA = KC + 8;     // halves per LDS row: rows start in different banks
+    __shared__ __attribute__((aligned(16))) f16 As[2][16 * LDA];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int NT = n / 16, KT = k / TK;
+    const int nt = blockIdx.x * 4 + wid;
+    const bool active = nt < NT;
+    // this block's K range in tiles
+    const int ks = gridDim.y;
+    const int t0 = (int)((long)KT * blockIdx.y / ks), t1 = (int)((long)KT * (blockIdx.y + 1) / ks);
+    const int nch = (t1 - t0 + SM_U - 1) / SM_U;
+
+    const u32x4* wp = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(W)
+                                                     + (((size_t)(active ? nt : 0) * KT + t0) * 64 + lane) * 16);
+    f16x2 scale2 = {(f16)1.f, (f16)1.f};
+    if constexpr (INT8) {
+        if (active) {
+            const f16 sc = scale[nt * 16 + c];
+            scale2       = f16x2{sc, sc};
+        }
+    }
+    // x chunk: 16 rows x KC halves = 16 * KC / 8 16-byte pieces, (16 * KC / 8) / 256 per thread
+    constexpr int XPT = 16 * KC / 8 / 256;  // 4 (int8) / 2 (fp16)
+    u32x4         xreg[XPT];
+    auto load_x = [&](int ch) {
+        const int ch2 = ch < nch ? ch : nch - 1;
+#pragma unroll
+        for (int i = 0; i < XPT; i++) {
+            const int pc  = threadIdx.x + i * 256;  // piece index: row = pc / (KC / 8), column piece = pc % (KC / 8)
+            int       row = pc / (KC / 8);
+            row           = row < m ? row : m - 1;
+            int kk        = (t0 + ch2 * SM_U) * TK + (pc % (KC / 8)) * 8;
+            kk            = kk < k ? kk : k - 8;  // the last chunk of a range may be short
+            xreg[i]       = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + kk);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XPT; i++) {
+            const int pc = threadIdx.x + i * 256;
+            *reinterpret_cast<u32x4*>(&As[buf][(pc / (KC / 8)) * LDA + (pc % (KC / 8)) * 8]) = xreg[i];
+        }
+    };
+    u32x4 RA[SM_U], RB[SM_U];
+    auto load_w = [&](u32x4 (&r)[SM_U], int ch) {
+        const int ch2 = ch < nch ? ch : nch - 1;
+#pragma unroll
+        for (int u = 0; u < SM_U; u++) {
+            int t = ch2 * SM_U + u;
+            t     = t < t1 - t0 ? t : t1 - t0 - 1;
+            r[u]  = __builtin_nontemporal_load(wp + (size_t)t * 64);
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](const u32x4 (&r)[SM_U], int buf, int ch) {
+        const int  nt_ch = (t1 - t0 - ch * SM_U < SM_U) ? t1 - t0 - ch * SM_U : SM_U;
+        const f16* xr    = &As[buf][c * LDA + g * (INT8 ? 16 : 8)];
+        if (nt_ch == SM_U) {
+#pragma unroll
+            for (int u = 0; u < SM_U; u++) {
+                consume_tile_raw<INT8>(r[u], xr + u * TK, scale2, acc);
+            }
+        }
+        else {
+#pragma unroll
+            for (int u = 0; u < SM_U; u++) {
+                if (u < nt_ch) {
+                    consume_tile_raw<INT8>(r[u], xr + u * TK, scale2, acc);
+                }
+            }
+        }
+    };
+    if (nch > 0) {
+        load_x(0);
+        load_w(RA, 0);
+        store_x(0);
+        for (int ch = 0; ch < nch; ch += 2) {
+            __syncthreads();  // chunk ch staged, buffer 1 free
+            load_x(ch + 1);
+            load_w(RB, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(RA, 0, ch);
+            __builtin_amdgcn_sched_barrier(0);
+            store_x(1);
+            if (ch + 1 >= nch) {
+                break;
+            }
+            __syncthreads();
+            load_x(ch + 2);
+            load_w(RA, ch + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(RB, 1, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_x(0);
+        }
+    }
+    if (!active) {
+        return;
+    }
+    const int col = nt * 16 + c;
+    if (ks > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = g * 4 + j;
+            if (row < m) {
+                partial[((size_t)blockIdx.y * m + row) * n + col] = acc[j];
+            }
+        }
+        return;
+    }
+    const float bv = bias ? (float)bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = g * 4 + j;
+        if (row < m) {
+            float v = acc[j];
+            f16   h;
+            if constexpr (INT8) {  // fused fp32 epilogue (epilogue_helpers.h:52-62)
+                v += bv;
+                if (act == 1) {
+                    v = gelu_f32(v);
+                }
+                h = (f16)v;
+            }
+            else {  // cuBLAS rounds to half; bias/gelu follow in half (activation_kernels.cu:401-426)
+                h = (f16)v;
+                if (act == 1) {
+                    h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
+                }
+                else if (bias) {
+                    h = h + bias[col];
+                }
+            }
+            C[(size_t)row * n + col] = h;
+        }
+    }
+}
+
+// split-K partials [ks][m][n] -> C with the GEMM epilogue (sum in split order: deterministic)
+template<bool INT8>
+__global__ void k_smallm_reduce(const float* __restrict__ partial, const f16* __restrict__ bias, int act,
+                                f16* __restrict__ C, int m, int n, int ks)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)m * n) {
+        return;
+    }
+    const int col = (int)(i % n);
+    float     v   = 0.f;
+    for (int s2 = 0; s2 < ks; s2++) {
+        v += partial[(size_t)s2 * m * n + i];
+    }
+    f16 h;
+    if constexpr (INT8) {
+        v += bias ? (float)bias[col] : 0.f;
+        if (act == 1) {
+            v = gelu_f32(v);
+        }
+        h = (f16)v;
+    }
+    else {
+        h = (f16)v;
+        if (act == 1) {
+            h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
+        }
+        else if (bias) {
+            h = h + bias[col];
+        }
+    }
+    C[i] = h;
+}
+
+size_t gemm_smallm_workspace_bytes(int m, int n_max)
+{
+    return (size_t)8 * m * n_max * sizeof(float);
+}
+
+void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
+                        int m, int n, int k, bool int8, int num_cu, hipStream_t s)
+{
+    FTCF_CHECK_ARG(m >= 1 && m <= 16, "small-m GEMM handles 1..16 rows");
+    FTCF_CHECK_ARG(k % GEMM_KSTEP == 0 && n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
+    const int NT = n / 16, bx = (NT + 3) / 4;
+    const int KT = k / (int8 ? TILE_K_I8 : TILE_K_F16);
+    int       ks = 1;
+    while (ks < 8 && bx * ks < 2 * num_cu && KT / (ks * 2) >= 2 * SM_U && workspace != nullptr) {
+        ks *= 2;  // enough workgroups to fill the chip, at least two chunks per K range
+    }
+    dim3 grid(bx, ks);
+    if (int8) {
+        hipLaunchKernelGGL((k_gemm_smallm<true>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace, m, n, k);
+    }
+    else {
+        hipLaunchKernelGGL((k_gemm_smallm<false>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace, m, n, k);
+    }
+    if (ks > 1) {
+        const int total = m * n;
+        if (int8) {
+            hipLaunchKernelGGL((k_smallm_reduce<true>), dim3((total + 255) / 256), dim3(256), 0, s, workspace, bias, act,
+                               C, m, n, ks);
+        }
+        else {
+            hipLaunchKernelGGL((k_smallm_reduce<false>), dim3((total + 255) / 256), dim3(256), 0, s, workspace, bias, act,
+                               C, m, n, ks);
+        }
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 // logits_f32[m, n] = A[m,k] x W[n,k]^T for m > 4 (batched decode LM head).  W rows are k-contiguous, which is the
 // B-operand order of the MFMA directly: lane (col = lane&15, kgroup = lane>>4) reads 16 B of row n0+col.
 __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ A, const f16* __restrict__ W,
@@ -212,7 +465,23 @@ __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ 
     f32x4      acc  = {0.f, 0.f, 0.f, 0.f};
     const f16* wp   = W + (size_t)wrow * k + g * 8;
     const f16* ap   = A + (size_t)arow * k + g * 8;
-    for (int k0 = 0; k0 < k; k0 += 32) {
+    int k0 = 0;
+    for (; k0 + 256 <= k; k0 += 256) {  // 8 weight fragments (8 KiB per wave) in flight: the loop is HBM-latency bound
+        f16x8 b[8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            b[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp + k0 + u * 32));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            a[u] = *reinterpret_cast<const f16x8*>(ap + k0 + u * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u], acc, 0, 0, 0);
+        }
+    }
+    for (; k0 < k; k0 += 32) {
         const f16x8 b = *reinterpret_cast<const f16x8*>(wp + k0);
         const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k0);
         acc           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_lm_head(const f16* __restrict__ x, cons
 template<bool INT8, int M>
 static void launch_ln_gemv_m(const LnGemvParams& p, hipStream_t s)
 {
-    const size_t smem = (size_t)M * p.K * 2 + 64;
+    const size_t smem = (size_t)M * (p.K + XPAD) * 2 + 64;
     const int    grid = p.blocks0 + p.blocks1;
     hipLaunchKernelGGL((k_ln_gemv<INT8, M>), dim3(grid), dim3(256), smem, s, p);
 }
@@ -303,7 +303,7 @@ void launch_ln_gemv(const LnGemvParams& p, bool int8, int M, hipStream_t s)
 template<bool INT8, int M>
 static void launch_ln_gemv_group_m(const LnGemvParams& p, int wpg, hipStream_t s)
 {
-    const size_t smem = (size_t)M * p.K * 2 + (2 * wpg + wpg * M * 16) * 4 + 64;
+    const size_t smem = (size_t)M * (p.K + XPAD) * 2 + (2 * wpg + wpg * M * 16) * 4 + 64;
     hipLaunchKernelGGL((k_ln_gemv_group<INT8, M>), dim3(p.NT0 + p.NT1), dim3(wpg * 64), smem, s, p);
 }
 
@@ -369,7 +369,7 @@ void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves)
         }
     }
     p.nwaves       = idx;
-    p.slice_halves = maxnt * TK;
+    p.slice_halves = maxnt * TK + XPAD;  // + pad: rows of a slice in different banks
     (void)M;
 }
 
@@ -413,7 +413,7 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
                     const f16* gamma, const f16* beta, float eps)
 {
     FTCF_CHECK_ARG(K % 8 == 0, "K must be a multiple of 8");
-    const size_t smem = (size_t)M * K * 2 + 64;
+    const size_t smem = (size_t)M * (K + XPAD) * 2 + 64;
     int          grid = (n_rows + 15) / 16;
     if (grid > 2048) {
         grid = 2048;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(128) void k_gemv_chunked(const ChunkParams p)
     const int a0 = min(w_lo, p.KT_a), a1 = min(w_hi, p.KT_a);
     const int b0 = max(w_lo, p.KT_a) - p.KT_a, b1 = max(w_hi, p.KT_a) - p.KT_a;
     const int ntA = a1 - a0, ntB = b1 - b0;
-    const int slice = (p.T / 2 + 2) * TK;  // halves per wave per row
+    const int slice = (p.T / 2 + 2) * TK + XPAD;  // halves per wave per row (+ pad: rows in different banks)
     f16*      xs    = reinterpret_cast<f16*>(smem) + (size_t)wid * M * slice;
     const u32x4* wpA = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.W_a)
                                                       + (((size_t)grp * p.KT_a + a0) * 64 + lane) * 16);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(128) void k_gemv_chunked(const ChunkParams p)
     }
     __syncthreads();
     const int      step = p.d_step ? *p.d_step : p.step;
-    const unsigned tag  = (unsigned)(step * 256 + p.salt) + 1u;
+    const unsigned tag  = (unsigned)(step * 1024 + p.salt) + 1u;
     u64g*          gg   = p.gran + (size_t)grp * p.Q * 2 * M * 16;
     if (threadIdx.x < 2 * M * 16) {  // index = (s*M + m)*16 + c
         const float v = part[threadIdx.x] + part[2 * M * 16 + threadIdx.x];
@@ -654,7 +654,7 @@ template<bool INT8, int M>
 static void launch_chunked_m(const ChunkParams& p, hipStream_t s)
 {
     const int    TK    = INT8 ? TILE_K_I8 : TILE_K_F16;
-    const int    slice = (p.T / 2 + 2) * TK;
+    const int    slice = (p.T / 2 + 2) * TK + XPAD;
     const size_t smem  = (size_t)2 * M * slice * 2 + (size_t)2 * 2 * M * 16 * 4;
     hipLaunchKernelGGL((k_gemv_chunked<INT8, M>), dim3((p.N / 16) * p.Q), dim3(128), smem, s, p);
 }

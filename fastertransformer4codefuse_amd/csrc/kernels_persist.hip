@@ -762,7 +762,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         r.tile0  = g * KT;
         r.sel    = seg ? 1 : 0;
         r.nt     = KT;
-        r.xoff   = seg ? M * H : 0;
+        r.xoff   = seg ? M * (H + XPAD) : 0;
         r.xsel   = 0;
         r.rid    = cg;
         r.grp    = g;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             r.tile0      = g * KT_a + t0;
             r.sel        = 1;
             r.nt         = (KT_a - t0 < RLa) ? KT_a - t0 : RLa;
-            r.xoff       = M * Il + t0 * TK;
+            r.xoff       = M * (Il + XPAD) + t0 * TK;
             r.xsel       = 1;
             r.rid        = NG * PB + idx;
             if (piece == PA - 1) {  // owner of a group's last out-proj piece merges the group
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 fb     = false;
             }
             else {
-                const int lo = r.xoff - M * Il, hi = lo + r.nt * TK;
+                const int lo = r.xoff - M * (Il + XPAD), hi = lo + r.nt * TK;
                 ctx_lo = fa ? lo : (lo < ctx_lo ? lo : ctx_lo);
                 ctx_hi = fa ? hi : (hi > ctx_hi ? hi : ctx_hi);
                 fa     = false;
@@ -852,9 +852,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
         ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
                             sg3.nrot * PS_U * PS_NBUF);
-        sg1.xs0 = sg1.xs1 = H;
-        sg3.xs0 = Il;
-        sg3.xs1 = Hl;
+        sg1.xs0 = sg1.xs1 = H + XPAD;  // LDS rows of x are padded: see XPAD
+        sg3.xs0 = Il + XPAD;
+        sg3.xs1 = Hl + XPAD;
     }
     __syncthreads();
 
@@ -1046,8 +1046,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                                 o1[e]         = (nrm * r_ln[0][k][e]) + r_ln[1][k][e];
                                 o2[e]         = (nrm * r_ln[2][k][e]) + r_ln[3][k][e];
                             }
-                            *reinterpret_cast<f16x8*>(s.xs + (size_t)m * H + v * 8)       = o1;
-                            *reinterpret_cast<f16x8*>(s.xs + (size_t)(M + m) * H + v * 8) = o2;
+                            *reinterpret_cast<f16x8*>(s.xs + (size_t)m * (H + XPAD) + v * 8)       = o1;
+                            *reinterpret_cast<f16x8*>(s.xs + (size_t)(M + m) * (H + XPAD) + v * 8) = o2;
                         }
                     }
                 }
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 for (int m = 0; m < M; m++) {
                     ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
                                  p.err, 6, [&](const int i, const unsigned v) {
-                                     reinterpret_cast<unsigned*>(s.xs + (size_t)m * Il + mid_lo)[i] = v;
+                                     reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
                                  });
                 }
             }
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 for (int m = 0; m < M; m++) {
                     ps_sweep<5>(p.gc + (((size_t)m * Hl + ctx_lo) >> 1), (ctx_hi - ctx_lo) >> 1, tid, PS_NC * 64, tag,
                                 p.err, 7, [&](const int i, const unsigned v) {
-                                    reinterpret_cast<unsigned*>(s.xs + (size_t)M * Il + (size_t)m * Hl + ctx_lo)[i] = v;
+                                    reinterpret_cast<unsigned*>(s.xs + (size_t)M * (Il + XPAD) + (size_t)m * (Hl + XPAD) + ctx_lo)[i] = v;
                                 });
                 }
                 stamp(l, 14);
@@ -1416,7 +1416,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     pl.nsplit     = nsplit;
     pl.cs1        = cs1;
     pl.cs3        = cs3;
-    pl.xs_halves  = M * std::max(2 * H, Il + Hl);
+    pl.xs_halves  = M * std::max(2 * (H + XPAD), Il + Hl + 2 * XPAD);
     if (pl.xs_halves > 0x1ffff) {
         return pl;
     }
