@@ -61,7 +61,8 @@ class ForwardStats(C.Structure):
 # every symbol include/ftcf.h declares (tests/test_capi_symbols.py checks the two lists against the header)
 EXPORTED = [
     "ftcf_last_error", "ftcf_version", "ftcf_device_count", "ftcf_symmetric_quantize_int8",
-    "ftcf_int8_rowmajor_to_tiled", "ftcf_int8_tiled_to_rowmajor", "ftcf_fp16_rowmajor_to_tiled",
+    "ftcf_int8_rowmajor_to_tiled", "ftcf_int8_tiled_to_rowmajor", "ftcf_int8_cuda_sm80_to_rowmajor",
+    "ftcf_int8_rowmajor_to_cuda_sm80", "ftcf_fp16_rowmajor_to_tiled",
     "ftcf_fpA_intB_gemm", "ftcf_fp16_gemm", "ftcf_lm_head", "ftcf_layernorm", "ftcf_add_bias_attn_ffn_residual",
     "ftcf_masked_multihead_attention", "ftcf_masked_multihead_attention_workspace", "ftcf_context_attention",
     "ftcf_comm_get_unique_id", "ftcf_comm_init", "ftcf_comm_destroy", "ftcf_comm_allreduce_sum",

@@ -135,6 +135,39 @@ def quant_and_save(in_dir, out_dir, tensor_para_size, inference_data_type="fp16"
                 os.remove(base + ".bin")
 
 
+def import_cuda_qbin(in_dir, out_dir, tensor_para_size):
+    """Re-lays the `.q.bin` files of a checkpoint that was quantised by a CUDA build of the reference (SM75..SM89 layout,
+    cutlass_preprocessors.cc:500-539) into this engine's tile layout; scales and every other file are copied unchanged.
+    The int8 values themselves are not touched: the result is what `quant` would have produced from the same weights."""
+    from . import capi
+    import ctypes as C
+    if os.path.exists(out_dir):
+        shutil.rmtree(out_dir)
+    shutil.copytree(in_dir, out_dir)
+    config = configparser.ConfigParser()
+    config.read(os.path.join(in_dir, "config.ini"))
+    sec = config["gptneox"]
+    head_num, dh, L = int(sec["head_num"]), int(sec["size_per_head"]), int(sec["num_layer"])
+    H = head_num * dh
+    hl = H // tensor_para_size
+    il = (int(sec["inter_size"]) if "inter_size" in sec else 4 * H) // tensor_para_size
+    shapes = {"attention.query_key_value.weight": (H, 3 * hl), "attention.dense.weight": (hl, H),
+              "mlp.dense_h_to_4h.weight": (H, il), "mlp.dense_4h_to_h.weight": (il, H)}
+    lib = capi.lib()
+    i8p = C.POINTER(C.c_int8)
+    for rk in range(tensor_para_size):
+        for fn, (K, N) in shapes.items():
+            for li in range(L):
+                base = os.path.join(out_dir, f"model.layers.{li}.{fn}.{rk}")
+                q = np.fromfile(base + ".q.bin", dtype=np.int8)
+                if q.size != K * N:
+                    raise ValueError(f"{base}.q.bin holds {q.size} bytes, expected {K}x{N}")
+                rm, tiled = np.empty(K * N, np.int8), np.empty(K * N, np.int8)
+                capi.check(lib.ftcf_int8_cuda_sm80_to_rowmajor(q.ctypes.data_as(i8p), K, N, rm.ctypes.data_as(i8p)))
+                capi.check(lib.ftcf_int8_rowmajor_to_tiled(rm.ctypes.data_as(i8p), K, N, tiled.ctypes.data_as(i8p)))
+                tiled.tofile(base + ".q.bin")
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -149,7 +182,14 @@ def main():
     q.add_argument("--out_dir", required=True)
     q.add_argument("--tensor_para_size", type=int, required=True)
     q.add_argument("--inference_data_type", "--data_type", choices=["fp32", "fp16"], default="fp16")
+    i = sub.add_parser("import-cuda-qbin", help="re-lay .q.bin files written by a CUDA build (SM75..SM89 layout)")
+    i.add_argument("--in_dir", required=True)
+    i.add_argument("--out_dir", required=True)
+    i.add_argument("--tensor_para_size", type=int, required=True)
     a = ap.parse_args()
+    if a.cmd == "import-cuda-qbin":
+        import_cuda_qbin(a.in_dir, a.out_dir, a.tensor_para_size)
+        return
     if a.cmd == "hf2ft":
         from transformers import GPTNeoXForCausalLM
         out = os.path.join(a.saved_dir, "%d-gpu" % a.infer_gpu_num)

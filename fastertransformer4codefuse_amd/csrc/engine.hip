@@ -160,6 +160,20 @@ extern "C" int ftcf_int8_tiled_to_rowmajor(const int8_t* q, size_t K, size_t N, 
 {
     return guarded([&] { host_int8_tiled_to_rowmajor(q, K, N, out); });
 }
+extern "C" int ftcf_int8_cuda_sm80_to_rowmajor(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(q && out && K % 64 == 0 && N % 2 == 0, "SM80 int8 layout needs K % 64 == 0 and N % 2 == 0");
+        host_int8_cuda_sm80_to_rowmajor(q, K, N, out);
+    });
+}
+extern "C" int ftcf_int8_rowmajor_to_cuda_sm80(const int8_t* q, size_t K, size_t N, int8_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(q && out && K % 64 == 0 && N % 2 == 0, "SM80 int8 layout needs K % 64 == 0 and N % 2 == 0");
+        host_int8_rowmajor_to_cuda_sm80(q, K, N, out);
+    });
+}
 extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, void* out, void* stream)
 {
     return guarded([&] {

@@ -105,4 +105,44 @@ void host_symmetric_quantize_int8(const void* weight, bool is_half, size_t E, si
     }
 }
 
+// ---- importer / exporter of the CUDA build's SM75..SM89 int8 layout ------------------------------------------------
+// Closed form of the four steps of preprocess_weights_for_mixed_gemm (cutlass_preprocessors.cc:500-539) for int8:
+// element (k, n) of the row-major matrix ends up at byte
+//   word  = (n / 2) * (K / 4) * 2  +  2 * 16 * (kp / 64)  +  16 * (n % 2)  +  (kp % 64) / 4
+//   byte  = {0, 2, 1, 3}[kp % 4]
+// with kp the row AFTER the 16-row permutation (row kp of the permuted matrix holds original row
+// 16*(kp/16) + MAP[kp%16], MAP = 0 1 8 9 2 3 10 11 4 5 12 13 6 7 14 15), and the value stored is q + 128.
+static const int kSm80RowMap[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15};
+static const int kSm80ByteSwz[4] = {0, 2, 1, 3};
+
+static inline size_t sm80_byte_index(size_t kp, size_t n, size_t K)
+{
+    const size_t word = (n / 2) * (K / 4) * 2 + 32 * (kp / 64) + 16 * (n % 2) + (kp % 64) / 4;
+    return word * 4 + (size_t)kSm80ByteSwz[kp % 4];
+}
+
+void host_int8_cuda_sm80_to_rowmajor(const int8_t* q_cuda, size_t K, size_t N, int8_t* out)
+{
+#pragma omp parallel for schedule(static)
+    for (long long kpl = 0; kpl < (long long)K; kpl++) {
+        const size_t kp = (size_t)kpl;
+        const size_t k  = 16 * (kp / 16) + (size_t)kSm80RowMap[kp % 16];
+        for (size_t n = 0; n < N; n++) {
+            out[k * N + n] = (int8_t)((int)(uint8_t)q_cuda[sm80_byte_index(kp, n, K)] - 128);
+        }
+    }
+}
+
+void host_int8_rowmajor_to_cuda_sm80(const int8_t* q, size_t K, size_t N, int8_t* out_cuda)
+{
+#pragma omp parallel for schedule(static)
+    for (long long kpl = 0; kpl < (long long)K; kpl++) {
+        const size_t kp = (size_t)kpl;
+        const size_t k  = 16 * (kp / 16) + (size_t)kSm80RowMap[kp % 16];
+        for (size_t n = 0; n < N; n++) {
+            out_cuda[sm80_byte_index(kp, n, K)] = (int8_t)(uint8_t)((int)q[k * N + n] + 128);
+        }
+    }
+}
+
 }  // namespace ftcf

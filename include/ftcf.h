@@ -55,6 +55,11 @@ int ftcf_symmetric_quantize_int8(const void* weight, ftcf_dtype dtype, size_t E,
 /* row-major int8 [K,N] (the reference's "unprocessed" tensor) <-> engine tile layout (host) */
 int ftcf_int8_rowmajor_to_tiled(const int8_t* q_rowmajor, size_t K, size_t N, int8_t* q_tiled);
 int ftcf_int8_tiled_to_rowmajor(const int8_t* q_tiled, size_t K, size_t N, int8_t* q_rowmajor);
+/* int8 [K,N] as a CUDA build of the reference stores it for SM75..SM89 -- what its `.q.bin` files hold
+ * (preprocess_weights_for_mixed_gemm, cutlass_preprocessors.cc:500-539; quant_and_save.py:20) -- <-> row major (host).
+ * K % 64 == 0, N % 2 == 0.  Importing a CUDA checkpoint = cuda_sm80_to_rowmajor followed by rowmajor_to_tiled. */
+int ftcf_int8_cuda_sm80_to_rowmajor(const int8_t* q_cuda, size_t K, size_t N, int8_t* q_rowmajor);
+int ftcf_int8_rowmajor_to_cuda_sm80(const int8_t* q_rowmajor, size_t K, size_t N, int8_t* q_cuda);
 /* device: fp16 [K,N] row major -> engine fp16 tile layout (out-of-place, K % 32 == 0, N % 16 == 0) */
 int ftcf_fp16_rowmajor_to_tiled(const void* w_rowmajor, size_t K, size_t N, void* w_tiled, void* stream);
 

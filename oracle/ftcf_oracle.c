@@ -1204,3 +1204,66 @@ int orc_generate(const orc_config* c, const orc_weights* w, const int* input_ids
     free(gather);
     return steps_run;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * CUDA (SM75..SM89) int8 weight layout: restatement of cutlass_preprocessors.cc:139-201, 207-348, 350-370, 437-498,
+ * 500-539 for QuantType::INT8_WEIGHT_ONLY (LayoutDetailsB<uint8_t, Sm75+>: ColumnMajorTileInterleave<64, 2>,
+ * mixed_gemm_B_layout.h:59-72).  Used to pin the product's importer of .q.bin files written by the CUDA build.
+ * ------------------------------------------------------------------------------------------------------------------ */
+void orc_sm80_permute_rows(const int8_t* in, int K, int N, int8_t* out)
+{
+    /* write row r of every 16-row group reads row 8*((r%4)/2) + r%2 + 2*(r/4)  (:185-187 with ELTS_PER_REG = 4) */
+    for (int base = 0; base < K; base += 16) {
+        for (int r = 0; r < 16; r++) {
+            const int rd = 8 * ((r % 4) / 2) + r % 2 + 2 * (r / 4);
+            memcpy(out + (size_t)(base + r) * N, in + (size_t)(base + rd) * N, (size_t)N);
+        }
+    }
+}
+void orc_sm80_transpose(const int8_t* in, int K, int N, int8_t* out)
+{
+    for (int k = 0; k < K; k++) {
+        for (int n = 0; n < N; n++) {
+            out[(size_t)n * K + k] = in[(size_t)k * N + n];
+        }
+    }
+}
+void orc_sm80_interleave_columns(const int8_t* in, int K, int N, int8_t* out)
+{
+    /* column-major input: column n = K bytes = K/4 32-bit words; tiles of 64 rows (16 words), 2 columns interleaved */
+    const int       vr = K / 4, per_tile = 16, il = 2;
+    const uint32_t* src = (const uint32_t*)in;
+    uint32_t*       dst = (uint32_t*)out;
+    for (int n = 0; n < N; n++) {
+        const size_t wc = (size_t)(n / il);
+        for (int base = 0; base < vr; base += per_tile) {
+            for (int v = base; v < vr && v < base + per_tile; v++) {
+                const size_t vw = (size_t)il * base + (size_t)per_tile * (n % il) + (size_t)(v % per_tile);
+                dst[wc * vr * il + vw] = src[(size_t)n * vr + v];
+            }
+        }
+    }
+}
+void orc_sm80_add_bias_interleave_int8(int8_t* t, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        t[i] = (int8_t)((int)t[i] + 128);
+    }
+    for (size_t b = 0; b + 3 < n; b += 4) { /* [e3 e2 e1 e0] -> [e3 e1 e2 e0] */
+        const int8_t x = t[b + 1];
+        t[b + 1]       = t[b + 2];
+        t[b + 2]       = x;
+    }
+}
+void orc_sm80_preprocess_int8(const int8_t* row_major, int K, int N, int8_t* out)
+{
+    int8_t* a = (int8_t*)malloc((size_t)K * N);
+    int8_t* b = (int8_t*)malloc((size_t)K * N);
+    orc_sm80_permute_rows(row_major, K, N, a);
+    orc_sm80_transpose(a, K, N, b);
+    orc_sm80_interleave_columns(b, K, N, a);
+    orc_sm80_add_bias_interleave_int8(a, (size_t)K * N);
+    memcpy(out, a, (size_t)K * N);
+    free(a);
+    free(b);
+}

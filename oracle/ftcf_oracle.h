@@ -18,6 +18,7 @@
  */
 #ifndef FTCF_ORACLE_H
 #define FTCF_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -82,6 +83,15 @@ float    orc_uniform(uint64_t seed, uint64_t row, uint64_t draw);   /* (0,1] */
 
 /* ---- quantiser (cutlass_preprocessors.cc:576-673 symmetric_quantize, INT8_WEIGHT_ONLY) ---- */
 void orc_symmetric_quantize_int8(const float* w, int K, int N, int weight_is_half, int8_t* q, float* scale);
+
+/* The CUDA build's int8 weight layout for SM75..SM89 (preprocess_weights_for_mixed_gemm, cutlass_preprocessors.cc:500-539),
+ * one function per step so that each can be pinned by the reference's own known-answer tests
+ * (tests/weight_only_quant_ops/th_weight_quant_ops_unit_tests.py).  All tensors [K rows, N cols] int8. */
+void orc_sm80_permute_rows(const int8_t* in, int K, int N, int8_t* out);          /* :139-201, map 0 1 8 9 2 3 10 11 ... */
+void orc_sm80_transpose(const int8_t* in, int K, int N, int8_t* out);             /* :207-348 -> column major [N][K] */
+void orc_sm80_interleave_columns(const int8_t* in, int K, int N, int8_t* out);    /* :437-498, 64-row tiles, 2 columns */
+void orc_sm80_add_bias_interleave_int8(int8_t* inout, size_t n);                  /* :350-370 */
+void orc_sm80_preprocess_int8(const int8_t* row_major, int K, int N, int8_t* out); /* :500-539: all four in order */
 
 /* ---- GEMMs ---- */
 /* C[m,n] = A[m,k] * W ; W given either as fp [k,n] or as (q int8 [k,n], scale [n]).

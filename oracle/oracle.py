@@ -289,3 +289,26 @@ class Model:
                                _ptr(pad_count), _ptr(masked_tokens), _ptr(finished), C.c_int(B), C.c_int(s_max),
                                C.c_int(step), _ptr(y))
         return y
+
+
+def sm80_preprocess_int8(q_rowmajor, step=None):
+    """CUDA-build layout of a row-major int8 [K,N] matrix (cutlass_preprocessors.cc:500-539); `step` selects one of the
+    four steps ("permute", "transpose", "interleave", "bias") for the reference's known-answer tests."""
+    q = np.ascontiguousarray(q_rowmajor, dtype=np.int8)
+    L = lib()
+    i8p = C.POINTER(C.c_int8)
+    if step == "bias":
+        out = q.copy().reshape(-1)
+        L.orc_sm80_add_bias_interleave_int8(out.ctypes.data_as(i8p), C.c_size_t(out.size))
+        return out.reshape(q.shape)
+    K, N = q.shape
+    out = np.empty((K, N) if step in (None, "permute") else (N, K), dtype=np.int8)
+    if step is None:
+        out = np.empty(K * N, dtype=np.int8)
+    fn = {None: L.orc_sm80_preprocess_int8, "permute": L.orc_sm80_permute_rows, "transpose": L.orc_sm80_transpose,
+          "interleave": L.orc_sm80_interleave_columns}[step]
+    if step == "interleave":  # input is already column major [N][K]
+        N, K = q.shape
+        out = np.empty(K * N, dtype=np.int8)
+    fn(q.ctypes.data_as(i8p), K, N, out.ctypes.data_as(i8p))
+    return out
