@@ -1,0 +1,85 @@
+"""-m gpu: the C++ command-line example (examples/gptneox_example.cc, counterpart of the reference's
+examples/cpp/gptneox/gptneox_example.cc) drives the same engine through include/ftcf.h without Python: a tiny checkpoint in
+the converter's file format must decode to the golden HF tokens."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  -- before libftcf.so: one HIP / OpenMP runtime per process
+
+from tests.helpers import load_tiny
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fastertransformer4codefuse_amd", "bin", "gptneox_example")
+
+NAMES = ["input_layernorm.bias", "input_layernorm.weight", "attention.query_key_value.weight.0",
+         "attention.query_key_value.bias.0", "attention.dense.weight.0", None, "mlp.dense_h_to_4h.weight.0",
+         "mlp.dense_h_to_4h.bias.0", "mlp.dense_4h_to_h.weight.0", "mlp.attention.bias.sum",
+         "post_attention_layernorm.bias", "post_attention_layernorm.weight"]
+
+
+def write_checkpoint(d, cfg, w, int8):
+    """Files as huggingface_convert.py / convert.py write them for one rank (codefuse_example.py:337-419 reads them)."""
+    from fastertransformer4codefuse_amd import capi  # noqa: F401
+    from fastertransformer4codefuse_amd.gptneox_op import symmetric_quantize_last_axis_of_batched_matrix_int8 as quant
+    import torch
+    L = cfg["num_layer"]
+    H, I = cfg["head_num"] * cfg["size_per_head"], cfg["inter_size"]
+    shapes = {2: (H, 3 * H), 4: (H, H), 6: (H, I), 8: (I, H)}
+    for g in range(12):
+        if NAMES[g] is None:
+            continue
+        for l in range(L):
+            a = np.asarray(w[g * L + l], dtype=np.float32)
+            base = os.path.join(d, f"model.layers.{l}.{NAMES[g]}")
+            if g in shapes and int8:
+                q, s = quant(torch.from_numpy(a.reshape(shapes[g])).half().contiguous())
+                q.numpy().tofile(base + ".q.bin")
+                s.float().numpy().tofile(base + ".s.bin")
+            else:
+                a.tofile(base + ".bin")
+    for i, n in enumerate(["wte", "final_layernorm.weight", "final_layernorm.bias", "lm_head.weight"]):
+        np.asarray(w[12 * L + i], dtype=np.float32).tofile(os.path.join(d, f"model.{n}.bin"))
+    with open(os.path.join(d, "config.ini"), "w") as f:
+        f.write("[gptneox]\nmodel_name=tiny\nhead_num=%d\nsize_per_head=%d\ninter_size=%d\nnum_layer=%d\nvocab_size=%d\n"
+                "rotary_embedding=%d\nstart_id=%d\nend_id=%d\nuse_gptj_residual=1\nweight_data_type=fp32\n"
+                % (cfg["head_num"], cfg["size_per_head"], I, L, cfg["vocab_size"], cfg["rotary_dim"],
+                   cfg.get("start_id", 0), cfg["end_id"]))
+
+
+@pytest.mark.parametrize("int8", [0, 1])
+def test_cli_example_decodes_the_golden_tokens(tmp_path, int8):
+    from fastertransformer4codefuse_amd import capi
+    capi.require_gpu()
+    assert os.path.exists(EXE), "build the example first: python -c 'import __graft_entry__ as g; g.build()'"
+    cfg, w, z = load_tiny()
+    mdir = tmp_path / "1-gpu"
+    mdir.mkdir()
+    write_checkpoint(str(mdir), cfg, w, int8)
+    ini = tmp_path / "gptneox_config.ini"
+    ini.write_text("[ft_instance_hyperparameter]\ndata_type=fp16\ntensor_para_size=1\npipeline_para_size=1\nint8_mode=%d\n"
+                   "model_name=tiny\nmodel_dir=%s\n\n[request]\nbeam_width=1 # beam width\ntop_k=1 ; greedy\ntop_p=0.0\n"
+                   "temperature=1.0\nrepetition_penalty=1.0\nrequest_batch_size=2\nrequest_output_len=8\n" % (int8, mdir))
+    ids = tmp_path / "start_ids.csv"
+    ids.write_text(", ".join(map(str, z["prompt"].tolist())) + "\n" + ", ".join(map(str, z["prompt_b"].tolist())) + "\n")
+    out = tmp_path / "out"
+    r = subprocess.run([EXE, str(ini), "--start_ids", str(ids), "--out", str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [list(map(int, line.split())) for line in out.read_text().strip().splitlines()]
+    assert len(rows) == 2 and len(rows[0]) == 16 + 8
+    if not int8:  # fp16 engine is token exact vs HF on this model (test_gpu_engine.py)
+        assert rows[0][16:] == z["hf_tokens"].tolist()
+        assert rows[1][:19] == z["prompt_b"].tolist() + z["hf_tokens_b"].tolist()
+    else:  # int8: same engine as the Python path -> compare with GptNeoXOp on the same quantised weights
+        from tests import gpu_helpers as gh
+        op = gh.make_op(cfg, w, int8_mode=1)
+        end_id = cfg["end_id"]
+        pid = np.full((2, 16), end_id, dtype=np.int32)
+        pid[0] = z["prompt"]
+        pid[1, :11] = z["prompt_b"]
+        ref = gh.run_op(op, pid, [16, 11], 8, cfg["vocab_size"], top_k=1, return_logits=False)
+        assert rows[0] == ref["output_ids"][0].tolist()
+        assert rows[1] == ref["output_ids"][1].tolist()
