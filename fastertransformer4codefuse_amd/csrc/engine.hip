@@ -381,6 +381,7 @@ struct ftcf_gptneox {
     // it is ordered after `user_stream` at begin() and drained before forward()/finish() return
     hipStream_t               stream = nullptr, user_stream = nullptr;
     hipEvent_t                ev_user = nullptr;
+    hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
     int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
@@ -435,6 +436,11 @@ struct ftcf_gptneox {
         }
         if (ev_user) {
             (void)hipEventDestroy(ev_user);
+        }
+        for (hipEvent_t e : tok_ev) {
+            if (e) {
+                (void)hipEventDestroy(e);
+            }
         }
         if (h_flags) {
             (void)hipHostFree(h_flags);
@@ -1074,7 +1080,8 @@ int ftcf_gptneox::step(int max_steps)
     std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
     hipEvent_t ea = get_event(), eb = get_event();
     FTCF_HIP_CHECK(hipEventRecord(ea, stream));
-    int done = 0;
+    int  done    = 0;
+    bool lagging = false;  // the host has not yet seen the flags of the token launched last
     while (done < max_steps && ses.next_step < total && !ses.all_finished) {
         const int  step         = ses.next_step;
         const bool with_decoder = !(S > 1 && step == S);
@@ -1110,7 +1117,25 @@ int ftcf_gptneox::step(int max_steps)
         ses.steps++;
         ses.next_step++;
         done++;
-        // the reference synchronises once per token here as well (stop_criteria_kernels.cu:149-156)
+        // The reference synchronises once per token here (stop_criteria_kernels.cu:149-156).  Without a streaming
+        // callback nothing on the host needs token t before token t+1 is enqueued, so the replayed graph of the next
+        // token is launched first and the host only waits for the PREVIOUS token's event: the GPU never idles for the
+        // host round trip (~25 us per token).  `finished` is sticky on the device, so the one speculative step that may
+        // run after every row has finished only rewrites end_id / leaves the lengths alone.
+        if (graph_ok && !a.callback) {
+            hipEvent_t& ev = tok_ev[done & 1];
+            if (!ev) {
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            }
+            FTCF_HIP_CHECK(hipEventRecord(ev, stream));
+            if (lagging) {
+                FTCF_HIP_CHECK(hipEventSynchronize(tok_ev[(done - 1) & 1]));
+                ses.all_finished = h_flags[0] != 0;
+            }
+            lagging = true;
+            continue;
+        }
+        lagging = false;
         FTCF_HIP_CHECK(hipStreamSynchronize(stream));
         ses.all_finished = h_flags[0] != 0;
         if (a.callback && step + 1 < total && cfg.tensor_para_rank == 0) {
@@ -1128,6 +1153,9 @@ int ftcf_gptneox::step(int max_steps)
     }
     FTCF_HIP_CHECK(hipEventRecord(eb, stream));
     FTCF_HIP_CHECK(hipEventSynchronize(eb));
+    if (lagging) {
+        ses.all_finished = h_flags[0] != 0;
+    }
     float ms = 0.f;
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
     stats.decode_ms += ms;
