@@ -42,6 +42,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-e2e", action="store_true")
     p.add_argument("--profile-steps", type=int, default=48)
+    p.add_argument("--fake-tp", type=int, default=0,
+                   help="timing aid: run rank 0's shard of a TP=N model in ONE process over a 1-rank communicator "
+                        "(no peers: outputs are meaningless, the JSON line is marked invalid)")
     return p.parse_args()
 
 
@@ -136,6 +139,11 @@ def cpu_baseline(a):
 
 def main():
     a = parse()
+    # RCCL prints a version banner through C stdio on stdout (flushed at exit, i.e. after our line): keep fd 1 clean for
+    # the ONE JSON line by sending everything else that writes to stdout to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(os.dup(2), "w")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,6 +160,11 @@ def main():
     from fastertransformer4codefuse_amd import capi
     from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
     tp = world
+    if a.fake_tp > 1:
+        assert world == 1
+        tp = a.fake_tp
+        os.environ["FTCF_FAKE_TP"] = "1"
+        group = object()  # any non-None token: the op only hands it to init_tensor_parallel_comm
     H = a.heads * a.head_dim
     weights, int8_w, scales = synth_weights(a, tp, dev)
     end_id = 2
@@ -280,12 +293,15 @@ def main():
         "path_roofline_frac": bpt * tok_s / 8e12,  # whole-token HBM roofline (8 TB/s), incl. KV + fp16 LM head
         "roofline": roof,
     }
+    if a.fake_tp > 1:
+        res["invalid"] = f"--fake-tp {a.fake_tp}: one rank of a TP={a.fake_tp} job without its peers (timing aid only)"
+        res["vs_baseline"] = None
     if world == 1 and not a.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(a)
         except Exception as e:  # the oracle is only a reported baseline
             res["cpu_baseline"] = {"error": repr(e)}
-    print(json.dumps(res))
+    os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

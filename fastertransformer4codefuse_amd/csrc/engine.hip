@@ -382,6 +382,7 @@ struct ftcf_gptneox {
     hipStream_t               stream = nullptr, user_stream = nullptr;
     hipEvent_t                ev_user = nullptr;
     hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
+    bool                      tp_graph = false;
     int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
@@ -1085,7 +1086,9 @@ int ftcf_gptneox::step(int max_steps)
     while (done < max_steps && ses.next_step < total && !ses.all_finished) {
         const int  step         = ses.next_step;
         const bool with_decoder = !(S > 1 && step == S);
-        const bool graph_ok     = use_graph && with_decoder && !profiling && tp == 1 && !a.debug_logits;
+        // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
+        // has been validated on a multi-GPU node (this round's boxes have one GPU)
+        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || tp_graph) && !a.debug_logits;
         if (graph_ok) {
             if (!ses.graph_exec) {
                 // capture ONE regular decode step (all pointers are fixed for the session, the step counter lives
@@ -1332,6 +1335,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
             e->persist_cs3 = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
+        if (const char* m = getenv("FTCF_TP_GRAPH")) {
+            e->tp_graph = atoi(m) != 0;
+        }
         if (const char* m = getenv("FTCF_USE_GRAPH")) {
             e->use_graph = atoi(m) != 0;
         }

@@ -5,6 +5,7 @@ Mirrors `th_op/gptneox/GptNeoXOp.cc:25-185` (`GptNeoXOp::GptNeoXOp`, `GptNeoXOp:
 compute goes through libftcf.so (C ABI); nothing here touches tensor contents on the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -30,6 +31,13 @@ def init_tensor_parallel_comm(group, rank, world_size, device):
     caller's process group (any backend)."""
     import torch.distributed as dist
     ids = np.zeros(capi.UNIQUE_ID_BYTES, dtype=np.uint8)
+    if os.environ.get("FTCF_FAKE_TP") == "1":
+        # timing aid (bench.py --fake-tp N): ONE process runs rank 0's shard of a TP=N model over a 1-rank communicator --
+        # the kernels and collectives of a rank are all launched, only the peers are missing (outputs are meaningless)
+        capi.check(capi.lib().ftcf_comm_get_unique_id(ids.ctypes.data_as(C.POINTER(C.c_uint8))))
+        comm = C.c_void_p()
+        capi.check(capi.lib().ftcf_comm_init(ids.ctypes.data_as(C.POINTER(C.c_uint8)), 1, 0, device, C.byref(comm)))
+        return comm
     if rank == 0:
         capi.check(capi.lib().ftcf_comm_get_unique_id(ids.ctypes.data_as(C.POINTER(C.c_uint8))))
     backend = dist.get_backend(group)
