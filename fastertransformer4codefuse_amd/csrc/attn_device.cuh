@@ -115,9 +115,6 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     const int  step = p.d_step ? *p.d_step : p.step;
     const int  pos  = (step - 1) - (p.pad_count ? p.pad_count[b] : 0);  // :1303,:1343-1344
     __builtin_amdgcn_sched_barrier(0);
-    if (p.dbg_stop == 1) {
-        return false;
-    }
     if (fin) {
         return false;  // :1176 (ctx of a finished row is never consumed); uniform for all splits of the row
     }
@@ -176,9 +173,6 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         p.v_cache[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + threadIdx.x] = s_v[threadIdx.x];
     }
 
-    if (p.dbg_stop == 2) {
-        return false;
-    }
     const float inv_sqrt_dh = rsqrtf((float)DH);  // DecoderSelfAttentionLayer.cc:118 with q_scaling 1
     const f16x8 qv  = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
     const uint8_t* mask = p.masked_tokens ? p.masked_tokens + (size_t)b * p.s_max : nullptr;
@@ -245,9 +239,6 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     }
     __syncthreads();
     const float m_loc = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    if (p.dbg_stop == 3) {
-        return false;
-    }
     // ---- phase 2: exp, local sum ----
     float lsum = 0.f;
     for (int i = threadIdx.x; i < t_end - t_beg; i += 256) {
@@ -305,9 +296,6 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
             acc[j] = fmaf(pt, (float)vv[j], acc[j]);
         }
     }
-    if (p.dbg_stop == 4) {
-        return false;
-    }
     // fold the KPI row groups of the wave, then the 4 waves
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -346,7 +334,7 @@ __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int&
     const unsigned tag  = (unsigned)(step * 1024 + p.layer) + 1u;  // salt < 1024: layer + row group * num_layer
     u64*           gall = p.gran + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
     const bool     live = mmha_partial<DH>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
-    if (!live || sp != 0 || p.dbg_stop == 5) {
+    if (!live || sp != 0) {
         return;
     }
     // ---- merger (split 0) ----

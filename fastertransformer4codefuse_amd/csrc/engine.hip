@@ -297,8 +297,7 @@ extern "C" int ftcf_masked_multihead_attention(const void* qkv, const void* qkv_
         p.ctx = (f16*)ctx;
         p.gran = (unsigned long long*)workspace;
         p.layer = 0;
-        p.dbg_stop = getenv("FTCF_MMHA_DBG") ? atoi(getenv("FTCF_MMHA_DBG")) : 0;
-        p.nsplit = getenv("FTCF_MMHA_NSPLIT") ? atoi(getenv("FTCF_MMHA_NSPLIT")) : mmha_pick_nsplit(B, nh, s_max);
+        p.nsplit = mmha_pick_nsplit(B, nh, s_max);
         FTCF_CHECK_ARG(workspace_bytes >= mmha_workspace_bytes(B, nh, dh, p.nsplit), "MMHA workspace too small");
         // the granule tags must not match anything left from an earlier call
         FTCF_HIP_CHECK(hipMemsetAsync(p.gran, 0, mmha_workspace_bytes(B, nh, dh, p.nsplit), (hipStream_t)stream));
@@ -1076,7 +1075,7 @@ int ftcf_gptneox::step(int max_steps)
     FTCF_CHECK_ARG(ses.active, "no request in flight: call ftcf_gptneox_begin first");
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
     const ftcf_forward_args& a = ses.a;
-    const int B = ses.B, S = ses.S, total = ses.total, s_max = ses.s_max;
+    const int B = ses.B, S = ses.S, total = ses.total;
     const int tp = cfg.tensor_para_size;
     std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
     hipEvent_t ea = get_event(), eb = get_event();

@@ -108,7 +108,6 @@ struct MmhaParams {
     f16*           ctx;  // [B, Hl]
     unsigned long long* gran;  // split-KV hand-off slab: [B][nh][nsplit][dh+2] {tag,value} granules (zero at request start)
     int            layer;      // tag salt: unique per launch within a token
-    int            dbg_stop;   // timing experiments only (0 = normal)
     int            nsplit;
 };
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);

@@ -20,9 +20,7 @@ __global__ __launch_bounds__(256) void k_mmha_ln_gemv(const MmhaParams ap, const
     const int      n_gemv = gp.blocks0 + gp.blocks1;
     const int      bid    = (int)blockIdx.x;
     if (bid < n_gemv) {
-        if (n_attn >= 0) {
-            ln_gemv_group_block<INT8, M>(gp, smem, bid, 2);  // 2 column groups x 2 K-halves per 4-wave workgroup
-        }
+        ln_gemv_group_block<INT8, M>(gp, smem, bid, 2);  // 2 column groups x 2 K-halves per 4-wave workgroup
     }
     else {
         const int a  = bid - n_gemv;
@@ -40,13 +38,9 @@ static void launch_m(const MmhaParams& ap, const LnGemvParams& gp, hipStream_t s
     const size_t smem_a = mmha_smem_bytes(ap.dh, ap.s_max, ap.nsplit);
     const size_t smem_g = (size_t)M * (gp.K + XPAD) * 2 + (2 * 4 + 4 * M * 16) * sizeof(float);
     const size_t smem   = std::max(smem_a, smem_g);
-    static const int dbg = getenv("FTCF_K2_DEBUG") ? atoi(getenv("FTCF_K2_DEBUG")) : 0;  // timing experiments only
-    int grid = n_attn + gp.blocks0 + gp.blocks1;
-    if (dbg == 1) {
-        grid = gp.blocks0 + gp.blocks1;  // weight stream only (attention skipped: wrong results)
-    }
+    const int grid = n_attn + gp.blocks0 + gp.blocks1;
     if (ap.dh == 128) {
-        hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 128>), dim3(grid), dim3(256), smem, s, ap, gp, dbg == 2 ? -1 : n_attn);
+        hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 128>), dim3(grid), dim3(256), smem, s, ap, gp, n_attn);
     }
     else {
         hipLaunchKernelGGL((k_mmha_ln_gemv<INT8, M, 64>), dim3(grid), dim3(256), smem, s, ap, gp, n_attn);

@@ -667,7 +667,6 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
         L += __shfl(w * ls, s2, 64);
     }
     const float inv = 1.f / (L + 1.e-6f);  // :1632
-#pragma unroll
     for (int d = tx; d < DH; d += 64) {
         float o = 0.f;
         for (int s2 = 0; s2 < ns; s2++) {
@@ -698,7 +697,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     constexpr int TK = TileK<INT8>::value;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB, bid = blockIdx.x;
-    const int     lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int     wid = threadIdx.x >> 6;
     const int     KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK;
     const int     NT0 = 3 * Hl / 16, NG = H / 16;
     const int     PA = p.plan.PA, PB = p.plan.PB, RLa = p.plan.RLa, RLb = p.plan.RLb;
