@@ -379,6 +379,17 @@ void orc_mmha_step(const float* qkv, const float* qkv_bias, float* k_cache, floa
                    const int* pad_count, const uint8_t* masked_tokens, const uint8_t* finished, int B, int nh, int dh,
                    int rot, int s_max, int step, float* ctx, int fp16)
 {
+    orc_mmha_step_beam(qkv, qkv_bias, k_cache, v_cache, seq_len, pad_count, masked_tokens, finished, B, nh, dh, rot, s_max,
+                       step, ctx, fp16, NULL, 1);
+}
+
+/* The same with beam search (HAS_BEAMS, decoder_masked_multihead_attention_template.hpp:1465-1475, 1730-1745): row b of the
+ * B = batch * beam_width rows reads the cached key / value of time t from the row of beam cache_indir[b][t] of its batch
+ * (cache_indir: [batch][beam][s_max]); the current token goes to the row's own cache. */
+void orc_mmha_step_beam(const float* qkv, const float* qkv_bias, float* k_cache, float* v_cache, const int* seq_len,
+                        const int* pad_count, const uint8_t* masked_tokens, const uint8_t* finished, int B, int nh, int dh,
+                        int rot, int s_max, int step, float* ctx, int fp16, const int* cache_indir, int beam_width)
+{
     const int   hl          = nh * dh;
     const float inv_sqrt_dh = 1.f / sqrtf((float)dh); /* DecoderSelfAttentionLayer.cc:118, q_scaling = 1 */
     const int   timestep    = step - 1;               /* :112 */
@@ -415,8 +426,13 @@ void orc_mmha_step(const float* qkv, const float* qkv_bias, float* k_cache, floa
             float  qkmax = -FLT_MAX;
             for (int t = 0; t <= tl; t++) {
                 double acc = 0;
+                const float* kt = kc;
+                if (cache_indir && t < tl) {
+                    const int src = (b / beam_width) * beam_width + cache_indir[(size_t)b * s_max + t];
+                    kt            = k_cache + ((size_t)src * nh + h) * s_max * dh;
+                }
                 for (int d = 0; d < dh; d++) {
-                    acc += (double)q[d] * (double)kc[(size_t)t * dh + d];
+                    acc += (double)q[d] * (double)kt[(size_t)t * dh + d];
                 }
                 float qk  = (float)acc * inv_sqrt_dh;
                 p[t]      = qk;
@@ -449,9 +465,14 @@ void orc_mmha_step(const float* qkv, const float* qkv_bias, float* k_cache, floa
             }
             double* part = (double*)calloc((size_t)G * dh, sizeof(double));
             for (int t = 0; t < tl; t++) {
-                int g = t % G;
+                int          g  = t % G;
+                const float* vt = vc;
+                if (cache_indir) {
+                    const int src = (b / beam_width) * beam_width + cache_indir[(size_t)b * s_max + t];
+                    vt            = v_cache + ((size_t)src * nh + h) * s_max * dh;
+                }
                 for (int d = 0; d < dh; d++) {
-                    part[(size_t)g * dh + d] += (double)p[t] * (double)vc[(size_t)t * dh + d];
+                    part[(size_t)g * dh + d] += (double)p[t] * (double)vt[(size_t)t * dh + d];
                 }
             }
             {
@@ -895,6 +916,15 @@ void orc_decoder_step(const orc_config* c, const orc_weights* w, const float* x_
                       const int* seq_len, const int* pad_count, const uint8_t* masked_tokens, const uint8_t* finished,
                       int B, int s_max, int step, float* y)
 {
+    orc_decoder_step_beam(c, w, x_in, k_cache, v_cache, seq_len, pad_count, masked_tokens, finished, B, s_max, step, y, NULL,
+                          1);
+}
+
+void orc_decoder_step_beam(const orc_config* c, const orc_weights* w, const float* x_in, float* k_cache, float* v_cache,
+                           const int* seq_len, const int* pad_count, const uint8_t* masked_tokens,
+                           const uint8_t* finished, int B, int s_max, int step, float* y, const int* cache_indir,
+                           int beam_width)
+{
     const int H = c->head_num * c->size_per_head, nhl = c->head_num / c->tp_size, hl = nhl * c->size_per_head;
     const int il   = c->inter_size / c->tp_size;
     const int L    = c->num_layer;
@@ -913,8 +943,9 @@ void orc_decoder_step(const orc_config* c, const orc_weights* w, const float* x_
         /* DecoderSelfAttentionLayer.cc:532-577 QKV GEMM (no bias: MMHA adds it), :581-614 MMHA, :635-678 out proj */
         layer_gemm(c, nrm, B, H, 3 * hl, w->qkv_w ? w->qkv_w[l] : NULL, w->qkv_q ? w->qkv_q[l] : NULL,
                    w->qkv_s ? w->qkv_s[l] : NULL, NULL, 0, qkv);
-        orc_mmha_step(qkv, w->qkv_b[l], k_cache + l * cache_l, v_cache + l * cache_l, seq_len, pad_count, masked_tokens,
-                      finished, B, nhl, c->size_per_head, c->rotary_dim, s_max, step, ctx, fp16);
+        orc_mmha_step_beam(qkv, w->qkv_b[l], k_cache + l * cache_l, v_cache + l * cache_l, seq_len, pad_count,
+                           masked_tokens, finished, B, nhl, c->size_per_head, c->rotary_dim, s_max, step, ctx, fp16,
+                           cache_indir, beam_width);
         layer_gemm(c, ctx, B, hl, H, w->out_w ? w->out_w[l] : NULL, w->out_q ? w->out_q[l] : NULL,
                    w->out_s ? w->out_s[l] : NULL, NULL, 0, att);
         if (c->use_gptj_residual) {
@@ -1266,4 +1297,380 @@ void orc_sm80_preprocess_int8(const int8_t* row_major, int K, int N, int8_t* out
     memcpy(out, a, (size_t)K * N);
     free(a);
     free(b);
+}
+
+/* ==================================================================================================================
+ * Beam search (beam_width > 1): layers/DynamicDecodeLayer.cc:309-393 -> OnlineBeamSearchLayer / BaseBeamSearchLayer
+ * without BeamHypotheses (GptNeoX.cc:948-985 passes none), kernels/online_softmax_beamsearch_kernels.cu,
+ * kernels/beam_search_penalty_kernels.cu, decoding_kernels.cu:452-583 (gatherTree with parents).
+ * Rows are bb = batch * K + beam.  output_ids / parent_ids are time-major [total][B*K].
+ * ================================================================================================================== */
+typedef struct {
+    float v;
+    int   i;
+} beam_cand;
+
+static int cmp_cand(const void* a, const void* b)
+{
+    const beam_cand* x = (const beam_cand*)a;
+    const beam_cand* y = (const beam_cand*)b;
+    if (x->v > y->v) {
+        return -1;
+    }
+    if (x->v < y->v) {
+        return 1;
+    }
+    return x->i - y->i; /* ties: lower index first (the reference's block reduce leaves this unspecified) */
+}
+
+void orc_beam_search_step(float* logits, int B, int K, int V, int step, int max_input_len, const int* input_lengths,
+                          const orc_beam_params* bp, int end_id, int* output_ids, int* parent_ids, uint8_t* finished,
+                          int* seq_len, float* cum_log_probs, const int* src_indir, int* tgt_indir, int s_max)
+{
+    const int BK = B * K;
+    /* K15: select_optional_last_tokens.cu:22-85 at the first generated step (DynamicDecodeLayer.cc:250-267) */
+    if (step == max_input_len && bp->optional_last_tokens) {
+        for (int bb = 0; bb < BK; bb++) {
+            const int b     = bb / K;
+            uint8_t*  allow = (uint8_t*)calloc((size_t)V, 1);
+            for (int j = 0; j < bp->optional_count; j++) {
+                int t = bp->optional_last_tokens[(size_t)b * bp->optional_count + j];
+                if (t >= 0 && t < V) {
+                    allow[t] = 1;
+                }
+            }
+            for (int j = 0; j < V; j++) {
+                if (!allow[j]) {
+                    logits[(size_t)bb * V + j] = -INFINITY;
+                }
+            }
+            free(allow);
+        }
+    }
+    beam_cand* cand = (beam_cand*)malloc(sizeof(beam_cand) * (size_t)K * K);
+    float*     cy   = (float*)malloc(sizeof(float) * (size_t)K * K); /* un-penalised scores */
+    int*       cx   = (int*)malloc(sizeof(int) * (size_t)K * K);     /* absolute ids: token + row * V */
+    int*       new_parent = (int*)malloc(sizeof(int) * (size_t)BK);
+    int*       new_word   = (int*)malloc(sizeof(int) * (size_t)BK);
+    float*     new_cum    = (float*)malloc(sizeof(float) * (size_t)BK);
+    for (int b = 0; b < B; b++) {
+        const float temperature = bp->temperature ? bp->temperature[b] : 1.0f;
+        const float rep         = bp->repetition_penalty ? bp->repetition_penalty[b] : 1.0f;
+        const float diversity   = bp->diversity_rate ? bp->diversity_rate[b] : 0.0f;
+        const float len_pen     = bp->len_penalty ? bp->len_penalty[b] : 0.0f;
+        const int   min_length  = bp->min_length ? bp->min_length[b] : 0;
+        for (int k = 0; k < K; k++) {
+            const int bb = b * K + k;
+            float*    l  = logits + (size_t)bb * V;
+            /* invokeAddBiasApplyPenalties (beam_search_penalty_kernels.cu:171-262) */
+            if (temperature != 1.0f) {
+                const float inv = 1.0f / (temperature + 1e-6f);
+                for (int j = 0; j < V; j++) {
+                    l[j] *= inv;
+                }
+            }
+            if (bp->repetition_penalty && step > 0 && rep != 1.0f) { /* :89-153: history along the parent chain */
+                const int in_len = input_lengths ? input_lengths[bb] : max_input_len;
+                float*    nv     = (float*)malloc(sizeof(float) * (size_t)step);
+                int*      ni     = (int*)malloc(sizeof(int) * (size_t)step);
+                int       cnt    = 0;
+                int       prev   = output_ids[(size_t)(step - 1) * BK + bb];
+                ni[cnt]          = prev;
+                nv[cnt++]        = l[prev] > 0.f ? l[prev] / rep : l[prev] * rep;
+                int parent_beam  = k;
+                for (int i = step - 2; i >= 0; i--) {
+                    if (i >= in_len && i < max_input_len) {
+                        continue;
+                    }
+                    parent_beam = parent_ids[(size_t)i * BK + b * K + parent_beam];
+                    prev        = output_ids[(size_t)i * BK + b * K + parent_beam];
+                    ni[cnt]     = prev;
+                    nv[cnt++]   = l[prev] > 0.f ? l[prev] / rep : l[prev] * rep;
+                }
+                for (int c = 0; c < cnt; c++) {
+                    l[ni[c]] = nv[c];
+                }
+                free(nv);
+                free(ni);
+            }
+            if (step - max_input_len < min_length) { /* :155-169, 252-261 */
+                if (seq_len[bb] + 1 - max_input_len < min_length) {
+                    l[end_id] = -FLT_MAX;
+                }
+            }
+            /* beam_online_softmax_topk_kernel (online_softmax_beamsearch_kernels.cu:296-365): per row, top K of
+             * log_softmax + cum_log_prob; a finished row offers its end token at cum + 0 and nothing else */
+            beam_cand* row = (beam_cand*)malloc(sizeof(beam_cand) * (size_t)V);
+            if (finished[bb]) {
+                for (int j = 0; j < V; j++) {
+                    row[j].v = (j == end_id) ? 0.0f : -INFINITY;
+                    row[j].i = j;
+                }
+            }
+            else {
+                float mx = -FLT_MAX;
+                for (int j = 0; j < V; j++) {
+                    if (l[j] > mx) {
+                        mx = l[j];
+                    }
+                }
+                float d = 0.f;
+                for (int j = 0; j < V; j++) {
+                    d += expf(l[j] - mx);
+                }
+                const float logd = logf(d);
+                for (int j = 0; j < V; j++) {
+                    row[j].v = l[j] - mx - logd;
+                    row[j].i = j;
+                }
+            }
+            qsort(row, (size_t)V, sizeof(beam_cand), cmp_cand);
+            for (int i = 0; i < K; i++) {
+                cx[k * K + i] = row[i].i + bb * V;
+                cy[k * K + i] = row[i].v + cum_log_probs[bb];
+            }
+            free(row);
+        }
+        /* batch_topk_kernel (:100-262, beam_hyps.num_beams == nullptr): K best of the K*K candidates of the batch.
+         * NB the kernel indexes finished / sequence_lengths by the BATCH id (its blockIdx), not by batch*K+beam: restated
+         * as written (only matters with len_penalty != 0, which the harness never sets). */
+        for (int e = 0; e < K * K; e++) {
+            float v = cy[e];
+            if (len_pen != 0.0f) {
+                const int length = finished[b] ? seq_len[b] : seq_len[b] + 1;
+                if (length != 1) {
+                    v = v / powf((float)length, len_pen);
+                }
+            }
+            v += diversity * (float)(e % K);
+            cand[e].v = v;
+            cand[e].i = e;
+        }
+        qsort(cand, (size_t)K * K, sizeof(beam_cand), cmp_cand);
+        for (int k = 0; k < K; k++) {
+            const int e             = cand[k].i;
+            const int z             = cx[e];
+            new_parent[b * K + k]   = (z / V) % K;
+            new_word[b * K + k]     = z % V;
+            new_cum[b * K + k]      = cy[e];
+        }
+    }
+    /* update_kernel (OnlineBeamSearchLayer.cu:25-58): lengths follow the parent beam */
+    int*     old_seq = (int*)malloc(sizeof(int) * (size_t)BK);
+    uint8_t* old_fin = (uint8_t*)malloc((size_t)BK);
+    memcpy(old_seq, seq_len, sizeof(int) * (size_t)BK);
+    memcpy(old_fin, finished, (size_t)BK);
+    for (int bb = 0; bb < BK; bb++) {
+        const int b = bb / K, pb = b * K + new_parent[bb];
+        seq_len[bb]                          = old_fin[pb] ? old_seq[pb] : old_seq[pb] + 1;
+        finished[bb]                         = new_word[bb] == end_id;
+        parent_ids[(size_t)step * BK + bb]   = new_parent[bb];
+        output_ids[(size_t)step * BK + bb]   = new_word[bb];
+        cum_log_probs[bb]                    = new_cum[bb];
+    }
+    /* update_indir_cache_kernel (BaseBeamSearchLayer.cu:30-62): rows that just finished keep their stale entries */
+    for (int bb = 0; bb < BK; bb++) {
+        if (finished[bb]) {
+            continue;
+        }
+        const int b = bb / K, k = bb % K, src_beam = new_parent[bb];
+        for (int t = 0; t <= step && t < s_max; t++) {
+            tgt_indir[(size_t)bb * s_max + t] = (t == step) ? k : src_indir[((size_t)b * K + src_beam) * s_max + t];
+        }
+    }
+    /* stop words along the parent chain (stop_criteria_kernels.cu:24-83 with parent_ids) */
+    if (bp->stop_words) {
+        for (int bb = 0; bb < BK; bb++) {
+            const int  b     = bb / K;
+            const int* words = bp->stop_words + (size_t)b * 2 * bp->stop_len;
+            const int* offs  = words + bp->stop_len;
+            for (int id = 0; id < bp->stop_len; id++) {
+                if (offs[id] < 0) {
+                    continue;
+                }
+                const int item_end = offs[id], item_start = id > 0 ? offs[id - 1] : 0, item_size = item_end - item_start;
+                int       stop = 0;
+                if (step + 1 >= item_size) {
+                    stop       = 1;
+                    int parent = bb % K;
+                    for (int t = item_size - 1; t >= 0; t--) {
+                        const int ts  = step - (item_size - 1) + t;
+                        const int tok = output_ids[(size_t)ts * BK + b * K + parent];
+                        if (tok != words[item_start + t]) {
+                            stop = 0;
+                            break;
+                        }
+                        parent = parent_ids[(size_t)ts * BK + b * K + parent];
+                    }
+                }
+                if (stop) {
+                    finished[bb] = 1;
+                }
+            }
+        }
+    }
+    free(old_seq);
+    free(old_fin);
+    free(cand);
+    free(cy);
+    free(cx);
+    free(new_parent);
+    free(new_word);
+    free(new_cum);
+}
+
+/* GptNeoX<T>::forward with beam_width = K > 1 (GptNeoX.cc:386-1052): inputs tiled K times, the context phase runs on all
+ * B*K rows, cum_log_probs of beams > 0 start at -1e20 so that the first step expands beam 0 only. */
+int orc_generate_beam(const orc_config* c, const orc_weights* w, const int* input_ids, const int* input_lengths, int B,
+                      int S, int out_len, int K, const orc_beam_params* bp, int* output_ids, int* sequence_lengths,
+                      float* cum_log_probs_out)
+{
+    const int H = c->head_num * c->size_per_head, nhl = c->head_num / c->tp_size;
+    const int V = c->vocab_size, L = c->num_layer, fp16 = c->fp16;
+    const int total = S + out_len, s_max = total, BK = B * K;
+    const size_t cache_sz = (size_t)L * BK * nhl * s_max * c->size_per_head;
+    float*   k_cache = (float*)calloc(cache_sz, sizeof(float));
+    float*   v_cache = (float*)calloc(cache_sz, sizeof(float));
+    int*     ids     = (int*)calloc((size_t)total * BK, sizeof(int));
+    int*     parents = (int*)calloc((size_t)total * BK, sizeof(int));
+    uint8_t* finished = (uint8_t*)calloc((size_t)BK, 1);
+    int*     seq_len = (int*)calloc((size_t)BK, sizeof(int));
+    int*     pad_cnt = (int*)calloc((size_t)BK, sizeof(int));
+    int*     t_len   = (int*)calloc((size_t)BK, sizeof(int));
+    uint8_t* masked  = (uint8_t*)calloc((size_t)BK * s_max, 1);
+    float*   cum     = (float*)calloc((size_t)BK, sizeof(float));
+    int*     indir[2];
+    indir[0] = (int*)calloc((size_t)BK * s_max, sizeof(int));
+    indir[1] = (int*)calloc((size_t)BK * s_max, sizeof(int));
+    float* hid     = (float*)malloc(sizeof(float) * (size_t)BK * H);
+    float* hid_out = (float*)malloc(sizeof(float) * (size_t)BK * H);
+    float* nrm     = (float*)malloc(sizeof(float) * (size_t)BK * H);
+    float* logits  = (float*)malloc(sizeof(float) * (size_t)BK * V);
+    const int max_input_length = S;
+    for (int bb = 0; bb < BK; bb++) {
+        t_len[bb]    = input_lengths[bb / K]; /* invokeTileGptInputs */
+        finished[bb] = 0;
+        seq_len[bb]  = max_input_length - 1;
+        cum[bb]      = (bb % K == 0) ? 0.f : -1e20f; /* decodingInitialize (decoding_kernels.cu:26-47) */
+    }
+    if (S > 1) {
+        float* x = (float*)malloc(sizeof(float) * (size_t)BK * S * H);
+        for (int bb = 0; bb < BK; bb++) {
+            for (int s2 = 0; s2 < S; s2++) {
+                const int id             = input_ids[(size_t)(bb / K) * S + s2];
+                ids[(size_t)s2 * BK + bb] = id;
+                memcpy(x + ((size_t)bb * S + s2) * H, w->wte + (size_t)id * H, sizeof(float) * H);
+            }
+        }
+        context_decoder(c, w, x, k_cache, v_cache, t_len, BK, S, s_max);
+        for (int bb = 0; bb < BK; bb++) {
+            memcpy(hid_out + (size_t)bb * H, x + ((size_t)bb * S + (t_len[bb] - 1)) * H, sizeof(float) * H);
+        }
+        free(x);
+    }
+    else {
+        for (int bb = 0; bb < BK; bb++) {
+            ids[bb] = input_ids[bb / K];
+        }
+    }
+    for (int bb = 0; bb < BK; bb++) {
+        for (int s2 = t_len[bb]; s2 < max_input_length; s2++) {
+            masked[(size_t)bb * s_max + s2] = 1;
+        }
+    }
+    int steps_run = 0;
+    for (int step = max_input_length; step < total; step++) {
+        const int src = (step - max_input_length) % 2, tgt = 1 - src; /* GptNeoX.cc:778-780 */
+        if (!(max_input_length > 1 && step == max_input_length)) {
+            for (int bb = 0; bb < BK; bb++) {
+                const int id = ids[(size_t)(step - 1) * BK + bb];
+                memcpy(hid + (size_t)bb * H, w->wte + (size_t)id * H, sizeof(float) * H);
+            }
+            orc_decoder_step_beam(c, w, hid, k_cache, v_cache, seq_len, pad_cnt, masked, finished, BK, s_max, step, hid_out,
+                                  indir[src], K);
+        }
+        orc_layernorm(hid_out, w->final_ln_g, w->final_ln_b, BK, H, 1e-5f, nrm, fp16);
+        orc_lm_head(nrm, BK, H, V, w->lm_head, logits);
+        orc_beam_search_step(logits, B, K, V, step, max_input_length, t_len, bp, c->end_id, ids, parents, finished, seq_len,
+                             cum, indir[src], indir[tgt], s_max);
+        int all = 1;
+        for (int bb = 0; bb < BK; bb++) {
+            all &= finished[bb];
+        }
+        steps_run++;
+        if (all) {
+            break;
+        }
+        if (step == max_input_length) {
+            for (int bb = 0; bb < BK; bb++) {
+                pad_cnt[bb] += max_input_length - t_len[bb];
+            }
+        }
+    }
+    /* gatherTree (decoding_kernels.cu:452-583) + transpose to [B][K][total] */
+    for (int b = 0; b < B; b++) {
+        int max_len = -1;
+        for (int j = 0; j < K; j++) {
+            const int tmp_len             = seq_len[b * K + j] + 1; /* max_sequence_length_final_step = 1 */
+            sequence_lengths[b * K + j]   = tmp_len;
+            if (tmp_len > max_len) {
+                max_len = tmp_len;
+            }
+        }
+        const int msl = max_len < total ? max_len : total;
+        for (int k = 0; k < K; k++) {
+            const int bb      = b * K + k;
+            int*      beams   = output_ids + (size_t)bb * total;
+            const int in_len  = t_len[bb];
+            const int pad_off = max_input_length - in_len;
+            for (int t = 0; t < total; t++) {
+                beams[t] = 0;
+            }
+            if (msl <= 0) {
+                continue;
+            }
+            beams[msl - 1 - pad_off] = ids[(size_t)(msl - 1) * BK + bb];
+            int parent               = parents[(size_t)(msl - 1) * BK + bb] % K;
+            for (int level = msl - 2; level >= 0; level--) {
+                if (level >= in_len && level < max_input_length) {
+                    continue;
+                }
+                const int tl2 = level >= max_input_length ? level - pad_off : level;
+                beams[tl2]    = ids[(size_t)level * BK + b * K + parent];
+                parent        = parents[(size_t)level * BK + b * K + parent] % K;
+            }
+            for (int index = max_len - pad_off; index < total; index++) {
+                beams[index] = c->end_id;
+            }
+            int fin = 0;
+            for (int t = max_input_length; t < msl; t++) {
+                if (fin) {
+                    beams[t] = c->end_id;
+                }
+                else if (beams[t] == c->end_id) {
+                    fin = 1;
+                }
+            }
+            if (cum_log_probs_out) {
+                cum_log_probs_out[bb] = cum[bb];
+            }
+        }
+    }
+    free(k_cache);
+    free(v_cache);
+    free(ids);
+    free(parents);
+    free(finished);
+    free(seq_len);
+    free(pad_cnt);
+    free(t_len);
+    free(masked);
+    free(cum);
+    free(indir[0]);
+    free(indir[1]);
+    free(hid);
+    free(hid_out);
+    free(nrm);
+    free(logits);
+    return steps_run;
 }

@@ -127,6 +127,35 @@ void orc_dynamic_decode(float* logits, int B, int V, int step, int max_input_len
 /* ---- whole path (GptNeoX.cc:386-1052) ---- */
 /* Returns number of executed decode-loop iterations.  dbg_logits (optional) [out_len][B][V] receives the raw
  * fp32 logits of every step before dynamic decode; dbg_hidden (optional) [B][H] the last decoder output. */
+/* ---- beam search (beam_width > 1) ---- */
+typedef struct {
+    const float* temperature;        /* [B] or NULL (1.0) */
+    const float* repetition_penalty; /* [B] or NULL (= penalty type None) */
+    const float* diversity_rate;     /* [B] or NULL (0.0) */
+    const float* len_penalty;        /* [B] or NULL (0.0) */
+    const int*   min_length;         /* [B] or NULL */
+    const int*   stop_words;         /* [B,2,stop_len] or NULL */
+    int          stop_len;
+    const int*   optional_last_tokens; /* [B,M] (-1 padded) or NULL */
+    int          optional_count;
+} orc_beam_params;
+void orc_mmha_step_beam(const float* qkv, const float* qkv_bias, float* k_cache, float* v_cache, const int* seq_len,
+                        const int* pad_count, const uint8_t* masked_tokens, const uint8_t* finished, int B, int nh, int dh,
+                        int rot, int s_max, int step, float* ctx, int fp16, const int* cache_indir, int beam_width);
+void orc_decoder_step_beam(const orc_config* c, const orc_weights* w, const float* x_in, float* k_cache, float* v_cache,
+                           const int* seq_len, const int* pad_count, const uint8_t* masked_tokens,
+                           const uint8_t* finished, int B, int s_max, int step, float* y, const int* cache_indir,
+                           int beam_width);
+/* one OnlineBeamSearchLayer step; rows bb = batch * K + beam, output_ids / parent_ids time-major [total][B*K],
+ * src / tgt cache indirection [B][K][s_max] */
+void orc_beam_search_step(float* logits, int B, int K, int V, int step, int max_input_len, const int* input_lengths,
+                          const orc_beam_params* bp, int end_id, int* output_ids, int* parent_ids, uint8_t* finished,
+                          int* seq_len, float* cum_log_probs, const int* src_indir, int* tgt_indir, int s_max);
+/* output_ids [B][K][S+out_len], sequence_lengths [B][K], cum_log_probs [B][K] */
+int orc_generate_beam(const orc_config* cfg, const orc_weights* w, const int* input_ids, const int* input_lengths, int B,
+                      int S, int out_len, int K, const orc_beam_params* bp, int* output_ids, int* sequence_lengths,
+                      float* cum_log_probs);
+
 int orc_generate(const orc_config* cfg, const orc_weights* w, const int* input_ids, const int* input_lengths, int B,
                  int S, int out_len, const orc_sampling* sp, int* output_ids, int* sequence_lengths,
                  float* cum_log_probs, float* dbg_logits, float* dbg_hidden);

@@ -63,6 +63,7 @@ def lib():
         _lib.orc_uniform.restype = C.c_float
         _lib.orc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _lib.orc_generate.restype = C.c_int
+        _lib.orc_generate_beam.restype = C.c_int
     return _lib
 
 
@@ -201,6 +202,54 @@ class Sampling:
             0 if self.optional is None else int(self.optional.shape[1]), int(return_cum_log_probs))
 
 
+class OrcBeamParams(C.Structure):
+    _fields_ = [("temperature", C.c_void_p), ("repetition_penalty", C.c_void_p), ("diversity_rate", C.c_void_p),
+                ("len_penalty", C.c_void_p), ("min_length", C.c_void_p), ("stop_words", C.c_void_p),
+                ("stop_len", C.c_int), ("optional_last_tokens", C.c_void_p), ("optional_count", C.c_int)]
+
+
+class BeamParams:
+    """Keeps the numpy buffers alive behind an orc_beam_params struct (runtime args of the beam-search layer)."""
+
+    def __init__(self, B, temperature=None, repetition_penalty=None, diversity_rate=None, len_penalty=None,
+                 min_length=None, stop_words=None, optional_last_tokens=None):
+        def bc(v, dt):
+            if v is None:
+                return None
+            a = np.asarray(v, dtype=dt).reshape(-1)
+            return np.ascontiguousarray(np.broadcast_to(a, (B,)) if a.size == 1 else a, dtype=dt)
+
+        self.temperature = bc(temperature, np.float32)
+        self.repetition_penalty = bc(repetition_penalty, np.float32)
+        self.diversity_rate = bc(diversity_rate, np.float32)
+        self.len_penalty = bc(len_penalty, np.float32)
+        self.min_length = bc(min_length, np.int32)
+        self.stop_words = None if stop_words is None else np.ascontiguousarray(stop_words, dtype=np.int32)
+        self.optional = None if optional_last_tokens is None else np.ascontiguousarray(optional_last_tokens,
+                                                                                        dtype=np.int32)
+        self.struct = OrcBeamParams(
+            _ptr(self.temperature), _ptr(self.repetition_penalty), _ptr(self.diversity_rate), _ptr(self.len_penalty),
+            _ptr(self.min_length), _ptr(self.stop_words),
+            0 if self.stop_words is None else int(self.stop_words.shape[2]), _ptr(self.optional),
+            0 if self.optional is None else int(self.optional.shape[1]))
+
+
+def beam_search_step(logits, K, step, max_input_len, input_lengths, bp, end_id, output_ids, parent_ids, finished,
+                     seq_len, cum_log_probs, src_indir, tgt_indir):
+    """One OnlineBeamSearchLayer step, in place on the state arrays.  logits [B*K, V] fp32; output_ids / parent_ids
+    time-major [total, B*K] int32; src_indir / tgt_indir [B, K, s_max] int32."""
+    BK, V = logits.shape
+    B = BK // K
+    assert logits.dtype == np.float32 and output_ids.dtype == np.int32 and parent_ids.dtype == np.int32
+    assert finished.dtype == np.uint8 and seq_len.dtype == np.int32 and cum_log_probs.dtype == np.float32
+    assert src_indir.dtype == np.int32 and tgt_indir.dtype == np.int32
+    input_lengths = np.ascontiguousarray(input_lengths, dtype=np.int32)
+    lib().orc_beam_search_step(_ptr(logits), C.c_int(B), C.c_int(K), C.c_int(V), C.c_int(step), C.c_int(max_input_len),
+                               _ptr(input_lengths), C.byref(bp.struct), C.c_int(end_id), _ptr(output_ids),
+                               _ptr(parent_ids), _ptr(finished), _ptr(seq_len), _ptr(cum_log_probs), _ptr(src_indir),
+                               _ptr(tgt_indir), C.c_int(src_indir.shape[2]))
+
+
 def dynamic_decode(logits, step, max_input_len, input_lengths, sampling, end_id, output_ids, finished, seq_len,
                    cum_log_probs, draw_counter):
     """In-place on all state arrays (numpy, C-contiguous). output_ids is time-major [total, B] int32."""
@@ -274,6 +323,21 @@ class Model:
         if return_logits:
             res["logits"] = dbg
         return res
+
+    def generate_beam(self, input_ids, input_lengths, out_len, beam_width, beam_params=None):
+        """Beam search (beam_width > 1): output_ids [B, K, S+out_len], sequence_lengths [B, K], cum_log_probs [B, K]."""
+        input_ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        B, S = input_ids.shape
+        K = int(beam_width)
+        input_lengths = np.ascontiguousarray(input_lengths, dtype=np.int32)
+        bp = beam_params or BeamParams(B)
+        out = np.zeros((B, K, S + out_len), dtype=np.int32)
+        sl = np.zeros((B, K), dtype=np.int32)
+        cum = np.zeros((B, K), dtype=np.float32)
+        n = lib().orc_generate_beam(C.byref(self.c), C.byref(self.w), _ptr(input_ids), _ptr(input_lengths), C.c_int(B),
+                                    C.c_int(S), C.c_int(out_len), C.c_int(K), C.byref(bp.struct), _ptr(out), _ptr(sl),
+                                    _ptr(cum))
+        return {"output_ids": out, "sequence_lengths": sl, "cum_log_probs": cum, "steps": n}
 
     def decoder_step(self, x, k_cache, v_cache, seq_len, pad_count, masked_tokens, finished, step):
         """k_cache/v_cache float32 [L, B, nhl, S_max, dh] in place."""

@@ -11,6 +11,8 @@ input/output vectors that pin the oracle (oracle/) and the host-side counterpart
                                       (stored as fp16: every HF parameter was made fp16-representable first).
                           - HF fp32 greedy: prompt(s), per-step logits and tokens (16-in / 8-out, and a ragged B=2 case
                             whose rows were run through HF one by one, un-padded).
+  tiny_gptneox_beam.npz   HF beam search (num_beams = K, no EOS, length_penalty 0) on the same model: prompts, the K returned
+                          continuations (best first) and their cumulative log-probs, for three (B, K, out_len) cases.
   tiny_gptneox_tp2.json   sha256 of every tensor the reference loader returns for tensor_para_size=2, rank 0 and 1.
   harness_io.json         I/O of to_word_list_format / Trie.printAutoSuggestions / is_garbage /
                           token_stream_2_str_stream_convertor / get_data_package captured from the reference.
@@ -100,6 +102,38 @@ def hf_greedy(m, ids, n_new):
     return np.stack(logits_steps), toks
 
 
+def hf_beam(m, prompts, n_new, K):
+    """HF beam search without EOS / length penalty (score == cumulative log-prob): the same search the reference's
+    OnlineBeamSearchLayer does when no beam finishes.  Returns tokens [B][K][n_new] and scores [B][K], best first."""
+    L = max(len(p) for p in prompts)
+    toks, scores = [], []
+    for p in prompts:  # row by row, un-padded
+        out = m.generate(torch.tensor([p], dtype=torch.long), num_beams=K, num_return_sequences=K, do_sample=False,
+                         max_new_tokens=n_new, min_new_tokens=n_new, eos_token_id=None, pad_token_id=0,
+                         length_penalty=0.0, early_stopping=False, output_scores=True, return_dict_in_generate=True)
+        toks.append(out.sequences[:, len(p):].numpy().astype(np.int32))
+        scores.append(out.sequences_scores.numpy().astype(np.float32))
+    return np.stack(toks), np.stack(scores)
+
+
+def beam_golden(m, cfg):
+    rng = np.random.RandomState(4242)
+    res = {}
+    for name, lens, K, n_new in (("a", [16], 3, 8), ("b", [12, 7], 4, 6), ("c", [1], 2, 10)):
+        prompts = [rng.randint(3, cfg.vocab_size, size=n).tolist() for n in lens]
+        toks, scores = hf_beam(m, prompts, n_new, K)
+        S = max(lens)
+        ids = np.zeros((len(lens), S), dtype=np.int32)
+        for i, p in enumerate(prompts):
+            ids[i, :len(p)] = p
+        res[f"ids_{name}"] = ids
+        res[f"lens_{name}"] = np.array(lens, dtype=np.int32)
+        res[f"hf_beam_tokens_{name}"] = toks
+        res[f"hf_beam_scores_{name}"] = scores
+        print("beam", name, toks.tolist(), scores.tolist())
+    np.savez_compressed(os.path.join(OUT, "tiny_gptneox_beam.npz"), **res)
+
+
 class FakeTok:
     """Deterministic stand-in tokenizer (the reference helpers only call encode/decode/get_vocab)."""
 
@@ -171,6 +205,9 @@ def harness_io():
 
 def main():
     cfg, m = build_hf()
+    beam_golden(m, cfg)
+    if "--beam-only" in sys.argv:
+        return
     rng = np.random.RandomState(42)
     prompt = rng.randint(3, cfg.vocab_size, size=16).tolist()
     logits, toks = hf_greedy(m, prompt, 8)
