@@ -112,12 +112,12 @@ def test_diversity_rate_and_temperature_change_ranking():
     s["logits"][:] = -20.0
     s["logits"][0, 3], s["logits"][0, 4] = 5.0, 4.9  # beam 0's two best beat everything of beam 1 ...
     s["logits"][1, 7] = 4.0
-    s["cum"][:] = 0
+    s["cum"][:] = [0.0, -5.0]
     a = {k: v.copy() for k, v in s.items()}
     _step(a, K, 4, orc.BeamParams(B))
     assert a["parent_ids"][4].tolist() == [0, 0] and a["output_ids"][4].tolist() == [3, 4]
     b = {k: v.copy() for k, v in s.items()}
-    _step(b, K, 4, orc.BeamParams(B, diversity_rate=-2.0))  # ... until the second candidate of a row is charged
+    _step(b, K, 4, orc.BeamParams(B, diversity_rate=-10.0))  # ... until the second candidate of a row is charged
     assert b["parent_ids"][4].tolist() == [0, 1] and b["output_ids"][4].tolist() == [3, 7]
 
 
