@@ -8,7 +8,7 @@
 //
 // ini (same keys as examples/cpp/gptneox/gptneox_config.ini):
 //   [ft_instance_hyperparameter]  model_name, model_dir, tensor_para_size (1 here: one process, one GPU), int8_mode
-//   [request]                     request_batch_size, request_output_len, beam_width (1), top_k, top_p, temperature,
+//   [request]                     request_batch_size, request_output_len, beam_width (1), beam_search_diversity_rate, len_penalty, top_k, top_p, temperature,
 //                                 repetition_penalty
 //   [<model_name>]                head_num, size_per_head, inter_size, vocab_size, decoder_layers, rotary_embedding,
 //                                 start_id, end_id, use_gptj_residual, weight_data_type (fp32 | fp16)
@@ -240,6 +240,8 @@ int main(int argc, char** argv)
         const int   top_k   = std::stoi(get(ini, "request", "top_k", "1"));
         const float top_p = std::stof(get(ini, "request", "top_p", "0")), temp = std::stof(get(ini, "request", "temperature", "1"));
         const float rep     = std::stof(get(ini, "request", "repetition_penalty", "1"));
+        const float div_rate = std::stof(get(ini, "request", "beam_search_diversity_rate", "0"));
+        const float len_pen  = std::stof(get(ini, "request", "len_penalty", "0"));
 
         // ---- prompts (gpt_example_utils.cc:27-100: one csv row per request, short rows padded with end_id, missing rows
         //      replaced by end_id rows) ----
@@ -376,6 +378,10 @@ int main(int argc, char** argv)
         fa.n_temperature = 1;
         fa.repetition_penalty = &rep;
         fa.n_repetition_penalty = 1;
+        fa.beam_search_diversity_rate = &div_rate;
+        fa.n_beam_search_diversity_rate = 1;
+        fa.len_penalty = &len_pen;
+        fa.n_len_penalty = 1;
         fa.output_ids = d_out;
         fa.sequence_lengths = d_seq;
         ftcf_check(ftcf_gptneox_forward(eng, &fa), "ftcf_gptneox_forward");  // warm up (gptneox_example.cc:395-409)

@@ -57,7 +57,10 @@ constexpr int MMHA_SPIN_LIMIT = 1 << 22;  // bounded: a protocol bug must not ha
 // Split `sp` of (row b, head h): computes the un-normalised partial (max, sum, out[DH]) over its key range and
 // publishes it as granules.  Latency chain: ONE round trip for {finished, seq_len, step, q, bias, K rows, V rows}
 // (the K/V rows of the whole fixed chunk are requested before tlength is known and masked afterwards), then math.
-template<int DH>
+// BEAMS (beam search, beam_width > 1): the key / value of time t < tlength is read from the row the cache indirection
+// names, (b / beam_width) * beam_width + cache_indir[b][t] (decoder_masked_multihead_attention_template.hpp:1290-1296,
+// :1509-1512, :1733-1736); the new key / value always goes to the row's own cache line.
+template<int DH, bool BEAMS = false>
 __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u64* gout, const unsigned tag, int h,
                                              int b, int sp)
 {
@@ -69,6 +72,23 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     const int t_beg = sp * chunk;
     const f16* kc = p.k_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
     const f16* vc = p.v_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
+    const int*      indir   = nullptr;
+    const ptrdiff_t row_kv  = (ptrdiff_t)p.nh * p.s_max * DH;
+    int             b_first = 0;
+    if constexpr (BEAMS) {
+        const int step0 = p.d_step ? *p.d_step : p.step;
+        // source plane of this step: (step - max_input_len) % 2 (GptNeoX.cc:778-780)
+        indir   = p.cache_indir + (size_t)((step0 - p.max_input_len) & 1) * p.indir_plane + (size_t)b * p.s_max;
+        b_first = b / p.beam_width * p.beam_width;
+    }
+    auto row_of = [&](const f16* own, const int t) -> const f16* {
+        if constexpr (BEAMS) {
+            return own + (ptrdiff_t)(b_first + indir[t] - b) * row_kv + (size_t)t * DH;
+        }
+        else {
+            return own + (size_t)t * DH;
+        }
+    };
     constexpr int UK   = 8;
     const bool    fast = (chunk <= 4 * KPI * UK);
     u32x4         kreg[UK], vreg[UK];
@@ -77,13 +97,13 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * 4 * KPI + wid * KPI + grp;
             t       = t < p.s_max ? t : p.s_max - 1;  // always inside the cache; rows >= tlength are masked below
-            kreg[u] = *reinterpret_cast<const u32x4*>(kc + (size_t)t * DH + sub * 8);
+            kreg[u] = *reinterpret_cast<const u32x4*>(row_of(kc, t) + sub * 8);
         }
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * 4 * KPI + wid * KPI + grp;
             t       = t < p.s_max ? t : p.s_max - 1;
-            vreg[u] = *reinterpret_cast<const u32x4*>(vc + (size_t)t * DH + sub * 8);
+            vreg[u] = *reinterpret_cast<const u32x4*>(row_of(vc, t) + sub * 8);
         }
     }
     const int  hl = p.nh * DH;
@@ -209,7 +229,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
             for (int u = 0; u < U; u++) {
                 int t = t0 + u * 4 * KPI + grp;
                 t     = t < t_cached_end ? t : t_cached_end - 1;
-                kr[u] = *reinterpret_cast<const u32x4*>(kc + (size_t)t * DH + sub * 8);
+                kr[u] = *reinterpret_cast<const u32x4*>(row_of(kc, t) + sub * 8);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -280,7 +300,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
             for (int u = 0; u < U; u++) {
                 int t = t0 + u * 4 * KPI + grp;
                 t     = t < t_cached_end ? t : t_cached_end - 1;
-                vr[u] = *reinterpret_cast<const u32x4*>(vc + (size_t)t * DH + sub * 8);
+                vr[u] = *reinterpret_cast<const u32x4*>(row_of(vc, t) + sub * 8);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -326,14 +346,14 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
 // polls the nsplit partials (all loads of one pass in flight together), merges them in split order (deterministic)
 // and writes ctx.  Only split 0 ever waits, producers never do: no deadlock under any dispatch order as long as the
 // producers get scheduled, and every spin is bounded.
-template<int DH>
+template<int DH, bool BEAMS = false>
 __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int& s_last, const int h, const int b, const int sp)
 {
     (void)s_last;
     const int      step = p.d_step ? *p.d_step : p.step;
     const unsigned tag  = (unsigned)(step * 1024 + p.layer) + 1u;  // salt < 1024: layer + row group * num_layer
     u64*           gall = p.gran + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
-    const bool     live = mmha_partial<DH>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
+    const bool     live = mmha_partial<DH, BEAMS>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
     if (!live || sp != 0) {
         return;
     }

@@ -404,6 +404,10 @@ struct ftcf_gptneox {
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials of the batched decode GEMM (5..16 rows)
+    // beam search (beam_width K > 1; rows = batch * K everywhere above)
+    int *  tiled_ids = nullptr, *tiled_len = nullptr, *parent_ids = nullptr, *cache_indir = nullptr;
+    void*  beam_ws = nullptr;
+    float *d_div = nullptr, *d_lenpen = nullptr;
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
@@ -491,7 +495,8 @@ struct ftcf_gptneox {
     }
 
     // ---- arena planning: everything a request of shape (B, S, total) needs, carved once ----
-    void plan(int B, int S, int total)
+    // B = rows of the request (batch * beam_width)
+    void plan(int B, int S, int total, int K)
     {
         const int s_max = total;
         nsplit          = mmha_pick_nsplit(B, nhl, s_max);
@@ -517,7 +522,7 @@ struct ftcf_gptneox {
             // With tensor parallelism there is a collective between the layers: the persistent kernel would run one
             // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
             // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
-            if (persist && B <= 2 && (cfg.tensor_para_size == 1 || persist_per_layer)) {
+            if (persist && K == 1 && B <= 2 && (cfg.tensor_para_size == 1 || persist_per_layer)) {
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
             }
             if (pplan.ok) {
@@ -550,6 +555,15 @@ struct ftcf_gptneox {
             d_rep              = c.take<float>(B);
             draws              = c.take<uint64_t>(B);
             d_seed             = c.take<uint64_t>(B);
+            if (K > 1) {
+                tiled_ids   = c.take<int>((size_t)B * S);
+                tiled_len   = c.take<int>(B);
+                parent_ids  = c.take<int>((size_t)total * B);
+                cache_indir = c.take<int>((size_t)2 * B * s_max);
+                beam_ws     = c.take<char>(beam_workspace_bytes(B / K, K));
+                d_div       = c.take<float>(B);
+                d_lenpen    = c.take<float>(B);
+            }
             if (S > 1) {
                 const size_t M = (size_t)B * S;
                 px             = c.take<f16>(M * H);
@@ -641,7 +655,8 @@ struct ftcf_gptneox {
     void decoder(int B, int s_max)
     {
         const double wbytes  = int8 ? 1.0 : 2.0;
-        stats.decode_path = pplan.ok ? 1 : (B <= STAGE_MAX_ROWS ? 0 : 2);
+        const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1;  // beam search reads K/V through the cache indirection
+        stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
             // there is no collective between the layers
@@ -668,7 +683,7 @@ struct ftcf_gptneox {
             const LayerWeights& w = layers[l];
             // layer_input/output alias for 0 < l < L-1 in the reference (:249-250) -> which residual form it runs
             const int inplace = (l > 0 && l < L - 1) ? 1 : 0;
-            if (B <= STAGE_MAX_ROWS) {
+            if (staged) {
                 // Per-stage launches over row groups of <= 4 rows (the GEMV kernels' register budget).  STAGE_MAX_ROWS > 4
                 // would replay every stage per group; measured no faster than the batched GEMM path (the m = 4 forms
                 // of these kernels stream at half the m = 1 rate), so larger batches take the small-m GEMM below.
@@ -682,6 +697,12 @@ struct ftcf_gptneox {
             }
             else {
                 MmhaParams mp = mmha_params(l, w, B, s_max, 0, B, l);
+                if (ses.K > 1) {
+                    mp.cache_indir   = cache_indir;
+                    mp.beam_width    = ses.K;
+                    mp.max_input_len = ses.S;
+                    mp.indir_plane   = (size_t)B * s_max;
+                }
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
                 gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
                 launch_mmha(mp, stream);
@@ -838,7 +859,9 @@ struct ftcf_gptneox {
         bool              active = false;
         ftcf_forward_args a{};
         SamplingParams    sp{};
-        int               B = 0, S = 0, total = 0, s_max = 0;
+        BeamParams        bp{};
+        int               B = 0, S = 0, total = 0, s_max = 0;  // B = rows (batch * beam_width)
+        int               K = 1, batch = 0;
         int               next_step = 0;  // host mirror of state->step
         int               steps = 0;
         bool              all_finished = false;
@@ -886,31 +909,35 @@ static std::vector<T> broadcast_arg(const T* p, int n, int B, T dflt, const char
 
 void ftcf_gptneox::begin(const ftcf_forward_args& a)
 {
-    const int B = a.batch_size, S = a.max_input_len, out_len = a.output_len;
-    FTCF_CHECK_ARG(B >= 1 && S >= 1 && out_len >= 1, "batch_size, max_input_len and output_len must be >= 1");
+    const int B = a.batch_size * (a.beam_width > 0 ? a.beam_width : 1);  // rows
+    const int S = a.max_input_len, out_len = a.output_len;
+    FTCF_CHECK_ARG(a.batch_size >= 1 && S >= 1 && out_len >= 1, "batch_size, max_input_len and output_len must be >= 1");
     FTCF_CHECK_ARG(a.input_ids && a.input_lengths && a.output_ids && a.sequence_lengths, "NULL tensor");
-    if (a.beam_width != 1) {
-        throw Error(FTCF_ERR_UNSUPPORTED, "beam_width > 1 (beam search) is not implemented yet");
-    }
+    const int K = a.beam_width, batch = a.batch_size;
+    FTCF_CHECK_ARG(K >= 1 && K <= BEAM_MAX_K, "beam_width must be in [1, 64]");
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
     // everything the caller enqueued on its stream (input tensors) happens-before the engine's work
     FTCF_HIP_CHECK(hipEventRecord(ev_user, user_stream));
     FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_user, 0));
     const int total = S + out_len;  // max_output_seq_len == max_seq_len == max_cache_seq_len (GptNeoX.cc:520-523)
     const int s_max = total;
-    plan(B, S, total);
+    ses.K = K;  // (decoder path selection reads it)
+    plan(B, S, total, K);
 
     // ---- runtime args: routing of TopKSamplingLayer.cu:27-77 / TopPSamplingLayer.cu:30-110 ----
-    auto top_k = broadcast_arg<int>(a.top_k, a.n_top_k, B, 0, "top_k");
-    auto top_p = broadcast_arg<float>(a.top_p, a.n_top_p, B, 0.f, "top_p");
-    auto temp  = broadcast_arg<float>(a.temperature, a.n_temperature, B, 1.f, "temperature");
-    auto rep   = broadcast_arg<float>(a.repetition_penalty, a.n_repetition_penalty, B, 1.f, "repetition_penalty");
-    auto seed  = broadcast_arg<uint64_t>(a.random_seed, a.n_random_seed, B, 0, "random_seed");
-    auto minl  = broadcast_arg<int>(a.min_length, a.n_min_length, B, 0, "min_length");
-    std::vector<int>   k_eff(B);
-    std::vector<float> p_topk(B), p_topp(B);
+    auto top_k = broadcast_arg<int>(a.top_k, a.n_top_k, batch, 0, "top_k");
+    auto top_p = broadcast_arg<float>(a.top_p, a.n_top_p, batch, 0.f, "top_p");
+    auto temp  = broadcast_arg<float>(a.temperature, a.n_temperature, batch, 1.f, "temperature");
+    auto rep   = broadcast_arg<float>(a.repetition_penalty, a.n_repetition_penalty, batch, 1.f, "repetition_penalty");
+    auto seed  = broadcast_arg<uint64_t>(a.random_seed, a.n_random_seed, batch, 0, "random_seed");
+    auto minl  = broadcast_arg<int>(a.min_length, a.n_min_length, batch, 0, "min_length");
+    auto divr  = broadcast_arg<float>(a.beam_search_diversity_rate, a.n_beam_search_diversity_rate, batch, 0.f,
+                                      "beam_search_diversity_rate");
+    auto lenp  = broadcast_arg<float>(a.len_penalty, a.n_len_penalty, batch, 0.f, "len_penalty");
+    std::vector<int>   k_eff(batch);
+    std::vector<float> p_topk(batch), p_topp(batch);
     bool               temp_all_one = true, rep_all_default = true, any_min = false;
-    for (int b = 0; b < B; b++) {
+    for (int b = 0; b < batch; b++) {
         int   k = top_k[b];
         float p = top_p[b];
         FTCF_CHECK_ARG(k >= 0, "top_k must be >= 0");
@@ -928,13 +955,17 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         rep_all_default &= (rep[b] == 1.0f);
         any_min |= (minl[b] > 0);
     }
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_top_k, k_eff.data(), B * 4, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topk, p_topk.data(), B * 4, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topp, p_topp.data(), B * 4, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_temp, temp.data(), B * 4, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_rep, rep.data(), B * 4, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_seed, seed.data(), B * 8, hipMemcpyHostToDevice, stream));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_min_length, minl.data(), B * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_top_k, k_eff.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topk, p_topk.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_p_topp, p_topp.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_temp, temp.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_rep, rep.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_seed, seed.data(), batch * 8, hipMemcpyHostToDevice, stream));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_min_length, minl.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    if (K > 1) {
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_div, divr.data(), batch * 4, hipMemcpyHostToDevice, stream));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_lenpen, lenp.data(), batch * 4, hipMemcpyHostToDevice, stream));
+    }
     FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // the host vectors die at scope exit
 
     hipEvent_t e0 = get_event(), e1 = get_event();
@@ -969,14 +1000,24 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
         FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // `pl` dies at scope exit
     }
-    launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, a.input_lengths, state, B, S, s_max, stream);
+    // beam search: inputs tiled K times, the context phase runs on all batch * K rows (GptNeoX.cc:560-574, 640-735)
+    const int* in_ids = a.input_ids;
+    const int* in_len = a.input_lengths;
+    if (K > 1) {
+        launch_tile_inputs(tiled_ids, tiled_len, a.input_ids, a.input_lengths, batch, K, S, stream);
+        FTCF_HIP_CHECK(hipMemsetAsync(cache_indir, 0, (size_t)2 * B * s_max * 4, stream));
+        FTCF_HIP_CHECK(hipMemsetAsync(parent_ids, 0, (size_t)total * B * 4, stream));
+        in_ids = tiled_ids;
+        in_len = tiled_len;
+    }
+    launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, in_len, state, B, S, s_max, stream, K);
     if (S > 1) {
-        launch_prompt_embedding(px, step_ids, wte, a.input_ids, B, S, H, stream);
-        context_decoder(B, S, a.input_lengths, s_max);
-        launch_gather_last_token(x, px, a.input_lengths, B, S, H, stream);
+        launch_prompt_embedding(px, step_ids, wte, in_ids, B, S, H, stream);
+        context_decoder(B, S, in_len, s_max);
+        launch_gather_last_token(x, px, in_len, B, S, H, stream);
     }
     else {
-        FTCF_HIP_CHECK(hipMemcpyAsync(step_ids, a.input_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
+        FTCF_HIP_CHECK(hipMemcpyAsync(step_ids, in_ids, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
     }
     FTCF_HIP_CHECK(hipEventRecord(e1, stream));
 
@@ -987,7 +1028,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     sp.max_input_len = S;
     sp.total_len = total;
     sp.end_id = cfg.end_id;
-    sp.input_lengths = a.input_lengths;
+    sp.input_lengths = in_len;
     sp.top_k = d_top_k;
     sp.top_p_topk = d_p_topk;
     sp.top_p_topp = d_p_topp;
@@ -998,7 +1039,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     sp.draw_counter = draws;
     sp.apply_temperature = temp_all_one ? 0 : 1;
     sp.apply_repetition = (a.n_repetition_penalty > 0 && !rep_all_default) ? 1 : 0;
-    sp.stop_words = a.stop_words_list;
+    sp.stop_words = K > 1 ? nullptr : a.stop_words_list;  // (the beam kernel checks them along the parent chain)
     sp.stop_len = a.stop_words_len;
     sp.optional_last_tokens = a.optional_last_tokens;
     sp.optional_count = a.optional_last_tokens_count;
@@ -1012,9 +1053,42 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     sp.h_flags = h_flags;
     sp.ws = samp_ws;
 
+    BeamParams bp{};
+    if (K > 1) {
+        bp.logits = logits;
+        bp.B = batch;
+        bp.K = K;
+        bp.V = V;
+        bp.max_input_len = S;
+        bp.total_len = total;
+        bp.end_id = cfg.end_id;
+        bp.s_max = s_max;
+        bp.input_lengths = in_len;
+        bp.temperature = d_temp;
+        bp.repetition_penalty = a.n_repetition_penalty > 0 ? d_rep : nullptr;  // penalty type None otherwise
+        bp.diversity_rate = d_div;
+        bp.len_penalty = d_lenpen;
+        bp.min_length = any_min ? d_min_length : nullptr;
+        bp.stop_words = a.stop_words_list;
+        bp.stop_len = a.stop_words_len;
+        bp.optional_last_tokens = a.optional_last_tokens;
+        bp.optional_count = a.optional_last_tokens_count;
+        bp.output_ids = step_ids;
+        bp.parent_ids = parent_ids;
+        bp.finished = finished;
+        bp.seq_len = seq_len;
+        bp.cum_log_probs = cum;
+        bp.cache_indir = cache_indir;
+        bp.state = state;
+        bp.ws = beam_ws;
+    }
+
     ses.active = true;
     ses.a = a;
     ses.sp = sp;
+    ses.bp = bp;
+    ses.K = K;
+    ses.batch = batch;
     ses.B = B;
     ses.S = S;
     ses.total = total;
@@ -1066,7 +1140,13 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
             FTCF_HIP_CHECK(hipMemcpyAsync(a.debug_logits + (size_t)(ses.next_step - S) * B * V, logits,
                                           (size_t)B * V * 4, hipMemcpyDeviceToDevice, stream));
         }
-    launch_dynamic_decode(ses.sp, stream);
+    if (ses.K > 1) {
+        launch_beam_search(ses.bp, stream);
+        launch_decode_finish(ses.sp, stream);
+    }
+    else {
+        launch_dynamic_decode(ses.sp, stream);
+    }
 }
 
 // the token loop of GptNeoX<T>::forward (GptNeoX.cc:776-1048); returns the number of iterations executed
@@ -1150,7 +1230,7 @@ int ftcf_gptneox::step(int max_steps)
                     h_tokens[b] = cfg.end_id;
                 }
             }
-            a.callback(h_tokens.data(), h_idx.data(), B, 1, a.callback_user);
+            a.callback(h_tokens.data(), h_idx.data(), ses.batch, ses.K, a.callback_user);
         }
     }
     FTCF_HIP_CHECK(hipEventRecord(eb, stream));
@@ -1171,8 +1251,14 @@ void ftcf_gptneox::finish()
     FTCF_CHECK_ARG(ses.active, "no request in flight");
     const ftcf_forward_args& a = ses.a;
     // setOutputTensors (GptNeoX.cc:1090-1181)
-    launch_gather_tree(a.output_ids, a.sequence_lengths, step_ids, seq_len, a.input_lengths, ses.B, ses.S, ses.total,
-                       cfg.end_id, stream);
+    if (ses.K > 1) {
+        launch_gather_tree_beam(a.output_ids, a.sequence_lengths, step_ids, parent_ids, seq_len, tiled_len, ses.batch,
+                                ses.K, ses.S, ses.total, cfg.end_id, stream);
+    }
+    else {
+        launch_gather_tree(a.output_ids, a.sequence_lengths, step_ids, seq_len, a.input_lengths, ses.B, ses.S,
+                           ses.total, cfg.end_id, stream);
+    }
     if (a.cum_log_probs) {
         FTCF_HIP_CHECK(hipMemcpyAsync(a.cum_log_probs, cum, (size_t)ses.B * 4, hipMemcpyDeviceToDevice, stream));
     }

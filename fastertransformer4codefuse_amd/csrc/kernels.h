@@ -109,6 +109,10 @@ struct MmhaParams {
     unsigned long long* gran;  // split-KV hand-off slab: [B][nh][nsplit][dh+2] {tag,value} granules (zero at request start)
     int            layer;      // tag salt: unique per launch within a token
     int            nsplit;
+    // beam search (standalone launch_mmha only): [2][B][s_max] ping-pong planes of the cache indirection, B = batch * beam
+    const int*     cache_indir;
+    int            beam_width, max_input_len;
+    size_t         indir_plane;  // elements per plane
 };
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);
 int    mmha_pick_nsplit(int B, int nh, int s_max);
@@ -204,11 +208,43 @@ struct SamplingParams {
     int*            h_flags;  // pinned host mirror: [0] = all_finished, [1] = step that produced it
     void*           ws;       // workspace (see sampling_workspace_bytes)
 };
+// beam search (beam_width > 1): OnlineBeamSearchLayer semantics, rows bb = batch * K + beam
+constexpr int BEAM_MAX_K = 64;  // online_softmax_beamsearch_kernels.cu:691-695
+struct BeamParams {
+    float*       logits;  // [B*K, V] fp32 (modified in place)
+    int          B, K, V;
+    int          max_input_len, total_len, end_id, s_max;
+    const int*   input_lengths;       // device [B*K] (tiled)
+    const float* temperature;         // device [B]
+    const float* repetition_penalty;  // device [B] or NULL
+    const float* diversity_rate;      // device [B]
+    const float* len_penalty;         // device [B]
+    const int*   min_length;          // device [B] or NULL
+    const int*   stop_words;          // device [B,2,stop_len] or NULL
+    int          stop_len;
+    const int*   optional_last_tokens;  // device [B,M] or NULL
+    int          optional_count;
+    int *        output_ids, *parent_ids;  // time-major [total, B*K]
+    uint8_t*     finished;
+    int*         seq_len;
+    float*       cum_log_probs;
+    int*         cache_indir;  // [2][B*K][s_max]: plane (step - max_input_len) % 2 is read, the other one written
+    DecodeState* state;
+    void*        ws;  // beam_workspace_bytes
+};
+size_t beam_workspace_bytes(int B, int K);
+void   launch_beam_search(const BeamParams& p, hipStream_t s);  // rows + batch kernels (not the finish step)
+void   launch_decode_finish(const SamplingParams& p, hipStream_t s);
+void   launch_tile_inputs(int* tiled_ids, int* tiled_len, const int* ids, const int* len, int B, int K, int S,
+                          hipStream_t s);
+void   launch_gather_tree_beam(int* output_ids, int* sequence_lengths, const int* step_ids, const int* parent_ids,
+                               const int* seq_len, const int* input_lengths, int B, int K, int max_input_len, int total,
+                               int end_id, hipStream_t s);
 size_t sampling_workspace_bytes(int B, int V);
 void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s);
 void   launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
                           uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
-                          int s_max, hipStream_t s);
+                          int s_max, hipStream_t s, int beam_width = 1);
 void   launch_gather_tree(int* output_ids, int* sequence_lengths, const int* step_ids, const int* seq_len,
                           const int* input_lengths, int B, int max_input_len, int total, int end_id, hipStream_t s);
 

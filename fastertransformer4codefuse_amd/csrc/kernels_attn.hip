@@ -18,12 +18,12 @@
 
 namespace ftcf {
 
-template<int DH>
+template<int DH, bool BEAMS>
 __global__ __launch_bounds__(256) void k_mmha_split(const MmhaParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_last;
-    mmha_block<DH>(p, smem, s_last, blockIdx.x, blockIdx.y, blockIdx.z);
+    mmha_block<DH, BEAMS>(p, smem, s_last, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit)
@@ -75,11 +75,20 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
     const size_t smem = mmha_smem_bytes(p.dh, p.s_max, p.nsplit);
     dim3         grid(p.nh, p.B, p.nsplit);
     FTCF_CHECK_ARG(p.nsplit >= 1 && p.nsplit <= 16 && p.gran != nullptr, "bad split-KV configuration");
-    if (p.dh == 128) {
-        hipLaunchKernelGGL(k_mmha_split<128>, grid, dim3(256), smem, s, p);
+    if (p.cache_indir) {  // beam search
+        FTCF_CHECK_ARG(p.beam_width > 1 && p.B % p.beam_width == 0, "cache indirection needs rows = batch * beam_width");
+        if (p.dh == 128) {
+            hipLaunchKernelGGL((k_mmha_split<128, true>), grid, dim3(256), smem, s, p);
+        }
+        else {
+            hipLaunchKernelGGL((k_mmha_split<64, true>), grid, dim3(256), smem, s, p);
+        }
+    }
+    else if (p.dh == 128) {
+        hipLaunchKernelGGL((k_mmha_split<128, false>), grid, dim3(256), smem, s, p);
     }
     else {
-        hipLaunchKernelGGL(k_mmha_split<64>, grid, dim3(256), smem, s, p);
+        hipLaunchKernelGGL((k_mmha_split<64, false>), grid, dim3(256), smem, s, p);
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }

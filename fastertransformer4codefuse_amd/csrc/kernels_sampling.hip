@@ -442,6 +442,12 @@ __global__ void k_decode_finish(const SamplingParams p)
     }
 }
 
+void launch_decode_finish(const SamplingParams& p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 size_t sampling_workspace_bytes(int B, int V)
 {
     (void)V;
@@ -472,13 +478,13 @@ void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
 // invokeDecodingInitialize (decoding_kernels.cu:26-65) + invokeMaskPaddingTokens (gpt_kernels.cu:1035-1082)
 __global__ void k_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count,
                               uint8_t* masked_tokens, uint64_t* draw_counter, const int* input_lengths, DecodeState* st,
-                              int B, int max_input_len, int s_max)
+                              int B, int max_input_len, int s_max, int beam_width)
 {
     const int b = blockIdx.x;
     if (threadIdx.x == 0) {
         finished[b]      = 0;
         seq_len[b]       = max_input_len - 1;
-        cum_log_probs[b] = 0.f;
+        cum_log_probs[b] = (b % beam_width == 0) ? 0.f : -1e20f;  // beams > 0 start behind (decoding_kernels.cu:40-43)
         pad_count[b]     = 0;
         draw_counter[b]  = 0;
         if (b == 0) {
@@ -495,10 +501,10 @@ __global__ void k_decode_init(uint8_t* finished, int* seq_len, float* cum_log_pr
 
 void launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
                         uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
-                        int s_max, hipStream_t s)
+                        int s_max, hipStream_t s, int beam_width)
 {
     hipLaunchKernelGGL(k_decode_init, dim3(B), dim3(256), 0, s, finished, seq_len, cum_log_probs, pad_count,
-                       masked_tokens, draw_counter, input_lengths, st, B, max_input_len, s_max);
+                       masked_tokens, draw_counter, input_lengths, st, B, max_input_len, s_max, beam_width);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
@@ -550,6 +556,368 @@ void launch_gather_tree(int* output_ids, int* sequence_lengths, const int* step_
 {
     hipLaunchKernelGGL(k_gather_tree, dim3(B), dim3(64), 0, s, output_ids, sequence_lengths, step_ids, seq_len,
                        input_lengths, B, max_input_len, total, end_id);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+
+// ================================================================================================================
+// beam search (beam_width K > 1): OnlineBeamSearchLayer without BeamHypotheses
+//   layers/beam_search_layers/BaseBeamSearchLayer.cu:30-62,191-280, OnlineBeamSearchLayer.cu:25-166,
+//   kernels/beam_search_penalty_kernels.cu:89-262, kernels/online_softmax_beamsearch_kernels.cu:100-365,650-701.
+// Rows bb = batch * K + beam.  Three launches per token: rows (penalties + per-row top K of log-softmax + cum), batch
+// (K best of the K*K candidates, state / parents / cache-indirection update, stop words), then k_decode_finish.
+// ================================================================================================================
+__global__ __launch_bounds__(1024) void k_beam_rows(const BeamParams p, float* cand_v, int* cand_i, int* snap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[64];
+    __shared__ int   redi[64];
+    __shared__ int   s_chosen[BEAM_MAX_K];
+    __shared__ int   s_cnt;
+    const int        bb = blockIdx.x, K = p.K, V = p.V;
+    const int        b = bb / K, k = bb % K, BK = p.B * K;
+    float*           l    = p.logits + (size_t)bb * V;
+    const int        step = p.state->step;
+    const int        tid = threadIdx.x, nt = blockDim.x;
+
+    if (p.optional_last_tokens && step == p.max_input_len) {  // select_optional_last_tokens.cu:22-85
+        uint32_t* bits  = reinterpret_cast<uint32_t*>(smem);
+        const int words = (V + 31) / 32;
+        for (int i = tid; i < words; i += nt) {
+            bits[i] = 0u;
+        }
+        __syncthreads();
+        for (int j = tid; j < p.optional_count; j += nt) {
+            const int t = p.optional_last_tokens[(size_t)b * p.optional_count + j];
+            if (t >= 0 && t < V) {
+                atomicOr(&bits[t >> 5], 1u << (t & 31));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < V; i += nt) {
+            if (!((bits[i >> 5] >> (i & 31)) & 1u)) {
+                l[i] = -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+    const float temperature = p.temperature[b];
+    if (temperature != 1.0f) {  // beam_search_penalty_kernels.cu:171-262
+        const float inv = 1.0f / (temperature + 1e-6f);
+        for (int i = tid; i < V; i += nt) {
+            l[i] *= inv;
+        }
+        __syncthreads();
+    }
+    if (p.repetition_penalty && step > 0 && p.repetition_penalty[b] != 1.0f) {  // :89-153: history of THIS beam
+        float*      newv = reinterpret_cast<float*>(smem);
+        int*        idx  = reinterpret_cast<int*>(newv + p.total_len);
+        const float pen  = p.repetition_penalty[b];
+        if (tid == 0) {  // the walk along the parent chain is serial
+            const int in_len = p.input_lengths[bb];
+            int       cnt    = 0;
+            idx[cnt++]       = p.output_ids[(size_t)(step - 1) * BK + bb];
+            int parent       = k;
+            for (int i = step - 2; i >= 0; i--) {
+                if (i >= in_len && i < p.max_input_len) {
+                    continue;
+                }
+                parent     = p.parent_ids[(size_t)i * BK + b * K + parent];
+                idx[cnt++] = p.output_ids[(size_t)i * BK + b * K + parent];
+            }
+            s_cnt = cnt;
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        for (int c = tid; c < cnt; c += nt) {
+            const float lg = l[idx[c]];
+            newv[c]        = lg > 0.0f ? lg / pen : lg * pen;
+        }
+        __syncthreads();
+        for (int c = tid; c < cnt; c += nt) {
+            l[idx[c]] = newv[c];
+        }
+        __syncthreads();
+    }
+    if (p.min_length && tid == 0) {  // :155-169
+        if (step - p.max_input_len < p.min_length[b] && p.seq_len[bb] + 1 - p.max_input_len < p.min_length[b]) {
+            l[p.end_id] = -FLT_MAX;
+        }
+    }
+    __syncthreads();
+    float* cv  = cand_v + (size_t)bb * K;
+    int*   ci  = cand_i + (size_t)bb * K;
+    const float cum = p.cum_log_probs[bb];
+    if (tid == 0) {  // pre-update length / finished of every row for the batch kernel (its workgroups overwrite them)
+        snap[bb]      = p.seq_len[bb];
+        snap[BK + bb] = p.finished[bb];
+    }
+    if (p.finished[bb]) {  // a finished beam offers its end token at cum + 0 and nothing else (:296-365)
+        for (int i = tid; i < K; i += nt) {
+            const int j = (i == 0) ? p.end_id : (i - 1 < p.end_id ? i - 1 : i);
+            cv[i]       = (i == 0) ? cum : -INFINITY;
+            ci[i]       = j + bb * V;
+        }
+        return;
+    }
+    float mx = -FLT_MAX;
+    for (int i = tid; i < V; i += nt) {
+        mx = fmaxf(mx, l[i]);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = mx;
+    }
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < (nt >> 6); w++) {
+        mx = fmaxf(mx, red[w]);
+    }
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < V; i += nt) {
+        sum += expf(l[i] - mx);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = sum;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    for (int w = 0; w < (nt >> 6); w++) {
+        tot += red[w];
+    }
+    __syncthreads();
+    const float logd = logf(tot);
+    // K rounds of block arg-best (ties: lower token id), skipping the tokens already taken
+    for (int r = 0; r < K; r++) {
+        VI best{-INFINITY, 0x7fffffff};
+        for (int i = tid; i < V; i += nt) {
+            const float v = l[i];
+            if (better(v, i, best.v, best.i)) {
+                bool taken = false;
+                for (int c = 0; c < r; c++) {
+                    taken |= (s_chosen[c] == i);
+                }
+                if (!taken) {
+                    best.v = v;
+                    best.i = i;
+                }
+            }
+        }
+        best = block_best(best, red, redi);
+        if (tid == 0) {
+            s_chosen[r] = best.i;
+            cv[r]       = (best.v - mx - logd) + cum;
+            ci[r]       = best.i + bb * V;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_beam_batch(const BeamParams p, const float* cand_v, const int* cand_i,
+                                                    const int* snap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[8];
+    __shared__ int   redi[8];
+    __shared__ int   s_parent[BEAM_MAX_K], s_word[BEAM_MAX_K], s_seq[BEAM_MAX_K], s_fin[BEAM_MAX_K];
+    __shared__ float s_cum[BEAM_MAX_K];
+    const int        b = blockIdx.x, K = p.K, V = p.V, BK = p.B * K, KK = K * K;
+    const int        tid = threadIdx.x, nt = blockDim.x;
+    const int        step = p.state->step;
+    float*           sv   = reinterpret_cast<float*>(smem);  // [K*K] penalised scores
+    uint8_t*         tk   = reinterpret_cast<uint8_t*>(sv + KK);  // [K*K] taken
+    const float*     cy   = cand_v + (size_t)b * KK;
+    const int*       cx   = cand_i + (size_t)b * KK;
+    const float      len_pen = p.len_penalty[b], diversity = p.diversity_rate[b];
+    // batch_topk_kernel (online_softmax_beamsearch_kernels.cu:100-262, no beam hypotheses).  NB it indexes finished /
+    // sequence_lengths by the BATCH id, restated as written (only matters with len_penalty != 0).
+    const int* old_seq = snap;
+    const int* old_fin = snap + BK;
+    const int  length  = old_fin[b] ? old_seq[b] : old_seq[b] + 1;
+    for (int e = tid; e < KK; e += nt) {
+        float v = cy[e];
+        if (len_pen != 0.0f && length != 1) {
+            v = v / powf((float)length, len_pen);
+        }
+        v += diversity * (float)(e % K);
+        sv[e] = v;
+        tk[e] = 0;
+    }
+    __syncthreads();
+    for (int r = 0; r < K; r++) {
+        VI best{-INFINITY, 0x7fffffff};
+        for (int e = tid; e < KK; e += nt) {
+            if (!tk[e] && better(sv[e], e, best.v, best.i)) {
+                best.v = sv[e];
+                best.i = e;
+            }
+        }
+        best = block_best(best, red, redi);
+        if (tid == 0) {
+            const int e  = best.i;
+            tk[e]        = 1;
+            const int z  = cx[e];
+            const int pk = (z / V) % K;
+            s_parent[r]  = pk;
+            s_word[r]    = z % V;
+            s_cum[r]     = cy[e];
+            // update_kernel (OnlineBeamSearchLayer.cu:25-58): lengths follow the parent beam
+            const int pb = b * K + pk;
+            s_seq[r]     = old_fin[pb] ? old_seq[pb] : old_seq[pb] + 1;
+            s_fin[r]     = (z % V) == p.end_id;
+        }
+        __syncthreads();
+    }
+    if (tid < K) {
+        const int bb                         = b * K + tid;
+        p.seq_len[bb]                        = s_seq[tid];
+        p.finished[bb]                       = (uint8_t)s_fin[tid];
+        p.parent_ids[(size_t)step * BK + bb] = s_parent[tid];
+        p.output_ids[(size_t)step * BK + bb] = s_word[tid];
+        p.cum_log_probs[bb]                  = s_cum[tid];
+    }
+    // update_indir_cache_kernel (BaseBeamSearchLayer.cu:30-62): rows that just finished keep their stale entries
+    const size_t plane = (size_t)BK * p.s_max;
+    const int*   src   = p.cache_indir + (size_t)((step - p.max_input_len) & 1) * plane;
+    int*         tgt   = p.cache_indir + (size_t)(1 - ((step - p.max_input_len) & 1)) * plane;
+    const int    nts   = step + 1 < p.s_max ? step + 1 : p.s_max;
+    for (int i = tid; i < K * nts; i += nt) {
+        const int kk = i / nts, t = i % nts;
+        if (!s_fin[kk]) {
+            tgt[((size_t)b * K + kk) * p.s_max + t] = (t == step) ? kk : src[((size_t)b * K + s_parent[kk]) * p.s_max + t];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (p.stop_words && tid < K) {  // stop_criteria_kernels.cu:24-83 along the parent chain
+        const int  bb    = b * K + tid;
+        const int* words = p.stop_words + (size_t)b * 2 * p.stop_len;
+        const int* offs  = words + p.stop_len;
+        for (int id = 0; id < p.stop_len; id++) {
+            if (offs[id] < 0) {
+                continue;
+            }
+            const int item_end = offs[id], item_start = id > 0 ? offs[id - 1] : 0, item_size = item_end - item_start;
+            bool      stop = false;
+            if (step + 1 >= item_size) {
+                stop       = true;
+                int parent = tid;
+                for (int t = item_size - 1; t >= 0; t--) {
+                    const int ts  = step - (item_size - 1) + t;
+                    const int tok = p.output_ids[(size_t)ts * BK + b * K + parent];
+                    if (tok != words[item_start + t]) {
+                        stop = false;
+                        break;
+                    }
+                    parent = p.parent_ids[(size_t)ts * BK + b * K + parent];
+                }
+            }
+            if (stop) {
+                p.finished[bb] = 1;
+            }
+        }
+    }
+}
+
+size_t beam_workspace_bytes(int B, int K)
+{
+    return (size_t)B * K * K * (sizeof(float) + sizeof(int)) + (size_t)B * K * 2 * sizeof(int);
+}
+
+void launch_beam_search(const BeamParams& p, hipStream_t s)
+{
+    FTCF_CHECK_ARG(p.K >= 2 && p.K <= BEAM_MAX_K, "beam_width must be in [2, 64]");
+    float* cand_v = reinterpret_cast<float*>(p.ws);
+    int*   cand_i = reinterpret_cast<int*>(cand_v + (size_t)p.B * p.K * p.K);
+    int*   snap   = cand_i + (size_t)p.B * p.K * p.K;
+    size_t smem   = 0;
+    if (p.optional_last_tokens) {
+        smem = std::max(smem, (size_t)((p.V + 31) / 32) * 4);
+    }
+    if (p.repetition_penalty) {
+        smem = std::max(smem, (size_t)p.total_len * 8);
+    }
+    FTCF_CHECK_ARG(smem <= 60 * 1024, "sequence too long for the repetition-penalty staging buffer");
+    hipLaunchKernelGGL(k_beam_rows, dim3(p.B * p.K), dim3(1024), smem, s, p, cand_v, cand_i, snap);
+    hipLaunchKernelGGL(k_beam_batch, dim3(p.B), dim3(256), (size_t)p.K * p.K * 5, s, p, cand_v, cand_i, snap);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// invokeTileGptInputs (gpt_kernels.cu:632-667)
+__global__ void k_tile_inputs(int* tiled_ids, int* tiled_len, const int* ids, const int* len, int K, int S)
+{
+    const int bb = blockIdx.x, b = bb / K;
+    if (threadIdx.x == 0) {
+        tiled_len[bb] = len[b];
+    }
+    for (int s2 = threadIdx.x; s2 < S; s2 += blockDim.x) {
+        tiled_ids[(size_t)bb * S + s2] = ids[(size_t)b * S + s2];
+    }
+}
+
+void launch_tile_inputs(int* tiled_ids, int* tiled_len, const int* ids, const int* len, int B, int K, int S, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile_inputs, dim3(B * K), dim3(256), 0, s, tiled_ids, tiled_len, ids, len, K, S);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// gatherTree with parents (decoding_kernels.cu:452-583) + the [time, batch*beam] -> [batch, beam, time] transpose
+__global__ void k_gather_tree_beam(int* output_ids, int* sequence_lengths, const int* step_ids, const int* parent_ids,
+                                   const int* seq_len, const int* input_lengths, int B, int K, int max_input_len,
+                                   int total, int end_id)
+{
+    const int bb = blockIdx.x, b = bb / K, BK = B * K;
+    if (threadIdx.x != 0) {
+        return;
+    }
+    int max_len = -1;
+    for (int j = 0; j < K; j++) {
+        const int tmp_len = seq_len[b * K + j] + 1;  // max_sequence_length_final_step = 1
+        max_len           = tmp_len > max_len ? tmp_len : max_len;
+    }
+    sequence_lengths[bb] = seq_len[bb] + 1;
+    const int msl        = max_len < total ? max_len : total;
+    int*      beams      = output_ids + (size_t)bb * total;
+    for (int t = 0; t < total; t++) {
+        beams[t] = 0;
+    }
+    if (msl <= 0) {
+        return;
+    }
+    const int in_len  = input_lengths[bb];
+    const int pad_off = max_input_len - in_len;
+    beams[msl - 1 - pad_off] = step_ids[(size_t)(msl - 1) * BK + bb];
+    int parent               = parent_ids[(size_t)(msl - 1) * BK + bb] % K;
+    for (int level = msl - 2; level >= 0; level--) {
+        if (level >= in_len && level < max_input_len) {
+            continue;
+        }
+        const int tgt = level >= max_input_len ? level - pad_off : level;
+        beams[tgt]    = step_ids[(size_t)level * BK + b * K + parent];
+        parent        = parent_ids[(size_t)level * BK + b * K + parent] % K;
+    }
+    for (int index = max_len - pad_off; index < total; index++) {
+        beams[index] = end_id;
+    }
+    bool fin = false;
+    for (int t = max_input_len; t < msl; t++) {
+        if (fin) {
+            beams[t] = end_id;
+        }
+        else if (beams[t] == end_id) {
+            fin = true;
+        }
+    }
+}
+
+void launch_gather_tree_beam(int* output_ids, int* sequence_lengths, const int* step_ids, const int* parent_ids,
+                             const int* seq_len, const int* input_lengths, int B, int K, int max_input_len, int total,
+                             int end_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gather_tree_beam, dim3(B * K), dim3(64), 0, s, output_ids, sequence_lengths, step_ids, parent_ids,
+                       seq_len, input_lengths, B, K, max_input_len, total, end_id);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 

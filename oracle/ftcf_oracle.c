@@ -1519,6 +1519,58 @@ void orc_beam_search_step(float* logits, int B, int K, int V, int step, int max_
     free(new_cum);
 }
 
+/* gatherTree (decoding_kernels.cu:452-583) + the transpose to [B][K][total]; ids / parents time-major [total][B*K] */
+void orc_gather_tree_beam(const int* ids, const int* parents, const int* seq_len, const int* t_len, int B, int K,
+                          int max_input_len, int total, int end_id, int* output_ids, int* sequence_lengths)
+{
+    const int BK = B * K;
+    for (int b = 0; b < B; b++) {
+        int max_len = -1;
+        for (int j = 0; j < K; j++) {
+            const int tmp_len             = seq_len[b * K + j] + 1; /* max_sequence_length_final_step = 1 */
+            sequence_lengths[b * K + j]   = tmp_len;
+            if (tmp_len > max_len) {
+                max_len = tmp_len;
+            }
+        }
+        const int msl = max_len < total ? max_len : total;
+        for (int k = 0; k < K; k++) {
+            const int bb      = b * K + k;
+            int*      beams   = output_ids + (size_t)bb * total;
+            const int in_len  = t_len[bb];
+            const int pad_off = max_input_len - in_len;
+            for (int t = 0; t < total; t++) {
+                beams[t] = 0;
+            }
+            if (msl <= 0) {
+                continue;
+            }
+            beams[msl - 1 - pad_off] = ids[(size_t)(msl - 1) * BK + bb];
+            int parent               = parents[(size_t)(msl - 1) * BK + bb] % K;
+            for (int level = msl - 2; level >= 0; level--) {
+                if (level >= in_len && level < max_input_len) {
+                    continue;
+                }
+                const int tl2 = level >= max_input_len ? level - pad_off : level;
+                beams[tl2]    = ids[(size_t)level * BK + b * K + parent];
+                parent        = parents[(size_t)level * BK + b * K + parent] % K;
+            }
+            for (int index = max_len - pad_off; index < total; index++) {
+                beams[index] = end_id;
+            }
+            int fin = 0;
+            for (int t = max_input_len; t < msl; t++) {
+                if (fin) {
+                    beams[t] = end_id;
+                }
+                else if (beams[t] == end_id) {
+                    fin = 1;
+                }
+            }
+        }
+    }
+}
+
 /* GptNeoX<T>::forward with beam_width = K > 1 (GptNeoX.cc:386-1052): inputs tiled K times, the context phase runs on all
  * B*K rows, cum_log_probs of beams > 0 start at -1e20 so that the first step expands beam 0 only. */
 int orc_generate_beam(const orc_config* c, const orc_weights* w, const int* input_ids, const int* input_lengths, int B,
@@ -1607,54 +1659,10 @@ int orc_generate_beam(const orc_config* c, const orc_weights* w, const int* inpu
             }
         }
     }
-    /* gatherTree (decoding_kernels.cu:452-583) + transpose to [B][K][total] */
-    for (int b = 0; b < B; b++) {
-        int max_len = -1;
-        for (int j = 0; j < K; j++) {
-            const int tmp_len             = seq_len[b * K + j] + 1; /* max_sequence_length_final_step = 1 */
-            sequence_lengths[b * K + j]   = tmp_len;
-            if (tmp_len > max_len) {
-                max_len = tmp_len;
-            }
-        }
-        const int msl = max_len < total ? max_len : total;
-        for (int k = 0; k < K; k++) {
-            const int bb      = b * K + k;
-            int*      beams   = output_ids + (size_t)bb * total;
-            const int in_len  = t_len[bb];
-            const int pad_off = max_input_length - in_len;
-            for (int t = 0; t < total; t++) {
-                beams[t] = 0;
-            }
-            if (msl <= 0) {
-                continue;
-            }
-            beams[msl - 1 - pad_off] = ids[(size_t)(msl - 1) * BK + bb];
-            int parent               = parents[(size_t)(msl - 1) * BK + bb] % K;
-            for (int level = msl - 2; level >= 0; level--) {
-                if (level >= in_len && level < max_input_length) {
-                    continue;
-                }
-                const int tl2 = level >= max_input_length ? level - pad_off : level;
-                beams[tl2]    = ids[(size_t)level * BK + b * K + parent];
-                parent        = parents[(size_t)level * BK + b * K + parent] % K;
-            }
-            for (int index = max_len - pad_off; index < total; index++) {
-                beams[index] = c->end_id;
-            }
-            int fin = 0;
-            for (int t = max_input_length; t < msl; t++) {
-                if (fin) {
-                    beams[t] = c->end_id;
-                }
-                else if (beams[t] == c->end_id) {
-                    fin = 1;
-                }
-            }
-            if (cum_log_probs_out) {
-                cum_log_probs_out[bb] = cum[bb];
-            }
-        }
+    orc_gather_tree_beam(ids, parents, seq_len, t_len, B, K, max_input_length, total, c->end_id, output_ids,
+                         sequence_lengths);
+    if (cum_log_probs_out) {
+        memcpy(cum_log_probs_out, cum, sizeof(float) * (size_t)BK);
     }
     free(k_cache);
     free(v_cache);

@@ -151,6 +151,8 @@ void orc_decoder_step_beam(const orc_config* c, const orc_weights* w, const floa
 void orc_beam_search_step(float* logits, int B, int K, int V, int step, int max_input_len, const int* input_lengths,
                           const orc_beam_params* bp, int end_id, int* output_ids, int* parent_ids, uint8_t* finished,
                           int* seq_len, float* cum_log_probs, const int* src_indir, int* tgt_indir, int s_max);
+void orc_gather_tree_beam(const int* ids, const int* parents, const int* seq_len, const int* t_len, int B, int K,
+                          int max_input_len, int total, int end_id, int* output_ids, int* sequence_lengths);
 /* output_ids [B][K][S+out_len], sequence_lengths [B][K], cum_log_probs [B][K] */
 int orc_generate_beam(const orc_config* cfg, const orc_weights* w, const int* input_ids, const int* input_lengths, int B,
                       int S, int out_len, int K, const orc_beam_params* bp, int* output_ids, int* sequence_lengths,

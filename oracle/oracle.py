@@ -250,6 +250,21 @@ def beam_search_step(logits, K, step, max_input_len, input_lengths, bp, end_id, 
                                _ptr(tgt_indir), C.c_int(src_indir.shape[2]))
 
 
+def gather_tree_beam(ids, parents, seq_len, tiled_lengths, K, max_input_len, end_id):
+    """ids / parents time-major [total, B*K] -> (output_ids [B, K, total], sequence_lengths [B, K])."""
+    total, BK = ids.shape
+    B = BK // K
+    out = np.zeros((B, K, total), dtype=np.int32)
+    sl = np.zeros((B, K), dtype=np.int32)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    parents = np.ascontiguousarray(parents, dtype=np.int32)
+    seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+    tiled_lengths = np.ascontiguousarray(tiled_lengths, dtype=np.int32)
+    lib().orc_gather_tree_beam(_ptr(ids), _ptr(parents), _ptr(seq_len), _ptr(tiled_lengths), C.c_int(B), C.c_int(K),
+                               C.c_int(max_input_len), C.c_int(total), C.c_int(end_id), _ptr(out), _ptr(sl))
+    return out, sl
+
+
 def dynamic_decode(logits, step, max_input_len, input_lengths, sampling, end_id, output_ids, finished, seq_len,
                    cum_log_probs, draw_counter):
     """In-place on all state arrays (numpy, C-contiguous). output_ids is time-major [total, B] int32."""

@@ -64,5 +64,28 @@ def run_op(op, input_ids, input_lengths, out_len, V, return_logits=True, **kw):
     return res
 
 
+def run_op_beam(op, input_ids, input_lengths, out_len, V, K, return_logits=False, **kw):
+    """Beam search through GptNeoXOp.forward: output_ids [B, K, total], sequence_lengths / cum_log_probs [B, K]."""
+    ids = torch.from_numpy(np.ascontiguousarray(input_ids, dtype=np.int32)).cuda()
+    lens = torch.from_numpy(np.ascontiguousarray(input_lengths, dtype=np.int32)).cuda()
+    B = ids.shape[0]
+    dbg = torch.zeros((out_len, B * K, V), dtype=torch.float32, device="cuda") if return_logits else None
+    t = lambda v, dt: None if v is None else torch.tensor(v if isinstance(v, (list, tuple)) else [v], dtype=dt)
+    outs = op.forward(ids, lens, out_len, K, None, None, t(kw.get("beam_search_diversity_rate"), torch.float32),
+                      t(kw.get("temperature"), torch.float32), t(kw.get("len_penalty"), torch.float32),
+                      t(kw.get("repetition_penalty"), torch.float32), None,
+                      None if kw.get("stop_words") is None else torch.from_numpy(
+                          np.ascontiguousarray(kw["stop_words"], dtype=np.int32)).cuda(),
+                      None if kw.get("optional_last_tokens") is None else torch.from_numpy(
+                          np.ascontiguousarray(kw["optional_last_tokens"], dtype=np.int32)).cuda(),
+                      1, kw.get("callback"), _debug_logits=dbg)
+    torch.cuda.synchronize()
+    res = {"output_ids": outs[0].cpu().numpy(), "sequence_lengths": outs[1].cpu().numpy(),
+           "cum_log_probs": outs[2].cpu().numpy()}
+    if return_logits:
+        res["logits"] = dbg.cpu().numpy()
+    return res
+
+
 def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
