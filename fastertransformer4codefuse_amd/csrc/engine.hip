@@ -389,7 +389,7 @@ struct ftcf_gptneox {
 
     DeviceBuffer arena;
     // decode / state views (valid after plan())
-    f16 *x = nullptr, *nrm = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
+    f16 *x = nullptr, *nrm = nullptr, *nrm2 = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
     f16 *k_cache = nullptr, *v_cache = nullptr;
     f16 *px = nullptr, *pnrm = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
         *pffn = nullptr;
@@ -507,6 +507,7 @@ struct ftcf_gptneox {
             v_cache            = c.take<f16>(cache);
             x                  = c.take<f16>((size_t)B * H);
             nrm                = c.take<f16>((size_t)B * H);
+            nrm2               = c.take<f16>((size_t)B * H);
             qkv                = c.take<f16>((size_t)B * 3 * hl);
             ctx                = c.take<f16>((size_t)B * hl);
             att                = c.take<f16>((size_t)B * H);
@@ -696,6 +697,8 @@ struct ftcf_gptneox {
                 }
             }
             else {
+                // general path: both LayerNorms of the layer come from one pass over x, fused with the previous layer's
+                // residual when there is no collective in between
                 MmhaParams mp = mmha_params(l, w, B, s_max, 0, B, l);
                 if (ses.K > 1) {
                     mp.cache_indir   = cache_indir;
@@ -703,15 +706,31 @@ struct ftcf_gptneox {
                     mp.max_input_len = ses.S;
                     mp.indir_plane   = (size_t)B * s_max;
                 }
-                launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
+                const bool dual = residual_dual_ln_supported(H);
+                const bool tp1  = cfg.tensor_para_size == 1;
+                if (!dual) {
+                    launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
+                    launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, stream);
+                }
+                else if (l == 0 || !tp1) {
+                    launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
+                                            nrm2, B, H, 1e-5f, stream);
+                }
                 gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
                 launch_mmha(mp, stream);
                 gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
-                launch_layernorm(x, w.ln2_g, w.ln2_b, nrm, B, H, 1e-5f, true, stream);
-                gemm(nrm, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
+                gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
                 gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
-                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, cfg.tensor_para_size, inplace,
-                                                  true, stream);
+                if (dual && tp1) {
+                    const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
+                    launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, inplace, nx ? nx->ln1_g : nullptr,
+                                            nx ? nx->ln1_b : nullptr, nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr,
+                                            nrm, nrm2, B, H, 1e-5f, stream);
+                }
+                else {
+                    launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, cfg.tensor_para_size, inplace,
+                                                      true, stream);
+                }
             }
             allreduce(x, (size_t)B * H);
         }

@@ -79,6 +79,12 @@ void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n
 // ---- misc : kernels_misc.hip ----
 void launch_layernorm(const void* x, const void* gamma, const void* beta, void* out, int m, int n, float eps,
                       bool fp16, hipStream_t s);
+// [x += residual of the previous layer;] out1 = LN(x; g1, b1), out2 = LN(x; g2, b2) in one pass (ffn == NULL: no
+// residual; g1 == NULL: residual only)
+bool residual_dual_ln_supported(int n);
+void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16* bias, int tp, int inplace_variant,
+                             const f16* g1, const f16* b1, const f16* g2, const f16* b2, f16* out1, f16* out2, int m,
+                             int n, float eps, hipStream_t s);
 void launch_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* attn, const void* in, const void* bias,
                                        int m, int n, int tp, int inplace_variant, bool fp16, hipStream_t s);
 void launch_embedding(f16* out, const f16* table, const int* ids, int n_ids, int H, hipStream_t s);

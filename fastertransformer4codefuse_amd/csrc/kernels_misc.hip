@@ -37,6 +37,26 @@ __global__ __launch_bounds__(256) void k_layernorm_f16(const f16* __restrict__ x
     const float mean = s[0] / (float)n;
     const float rstd = rsqrtf(s[1] / (float)n - mean * mean + eps);
     const f16   mh = (f16)mean, rh = (f16)rstd;
+    if (vec) {
+        for (int i = threadIdx.x * 8; i < n; i += 256 * 8) {
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(xr + i);
+            const f16x8 gv = *reinterpret_cast<const f16x8*>(gamma + i);
+            f16x8       ov;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                ov[j] = ((xv[j] - mh) * rh) * gv[j];
+            }
+            if (beta) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(beta + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    ov[j] = ov[j] + bv[j];
+                }
+            }
+            *reinterpret_cast<f16x8*>(o + i) = ov;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += 256) {
         f16 v = ((xr[i] - mh) * rh) * gamma[i];
         if (beta) {
@@ -44,6 +64,108 @@ __global__ __launch_bounds__(256) void k_layernorm_f16(const f16* __restrict__ x
         }
         o[i] = v;
     }
+}
+
+// Batched decode layers (general path): the two LayerNorms of a parallel-residual layer read the same x, so one pass
+// computes the statistics once and writes both normalised copies; with RESID the layer-closing
+// invokeAddBiasAttentionFfnResidual of the PREVIOUS layer (add_residual_kernels.cu:116-178) runs first in the same
+// pass (x is updated in place).  Same arithmetic as k_layernorm_f16 / k_add_bias_attn_ffn_residual (same per-thread
+// element sets and summation order); the row stays in registers.  n % 8 == 0, n <= 8192.
+constexpr int DLN_NV = 4;
+template<bool RESID>
+__global__ __launch_bounds__(256) void k_residual_dual_ln(f16* __restrict__ x, const f16* __restrict__ ffn,
+                                                          const f16* __restrict__ attn, const f16* __restrict__ bias,
+                                                          int tp, int inplace_variant, const f16* __restrict__ g1,
+                                                          const f16* __restrict__ b1, const f16* __restrict__ g2,
+                                                          const f16* __restrict__ b2, f16* __restrict__ out1,
+                                                          f16* __restrict__ out2, int n, float eps)
+{
+    __shared__ float red[8];
+    const size_t     row = (size_t)blockIdx.x * n;
+    f16x8            v[DLN_NV];
+    float            s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < DLN_NV; it++) {
+        const int i = threadIdx.x * 8 + it * 2048;
+        if (i < n) {
+            f16x8 xv = *reinterpret_cast<const f16x8*>(x + row + i);
+            if constexpr (RESID) {
+                const f16x8 fv = *reinterpret_cast<const f16x8*>(ffn + row + i);
+                const f16x8 av = *reinterpret_cast<const f16x8*>(attn + row + i);
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(bias + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const f16 xin = (f16)((float)xv[j] / (float)tp);
+                    if (inplace_variant) {
+                        xv[j] = (f16)((float)xin + (float)fv[j] + (float)av[j] + (float)bv[j]);
+                    }
+                    else {
+                        xv[j] = ((fv[j] + av[j]) + bv[j]) + xin;
+                    }
+                }
+                *reinterpret_cast<f16x8*>(x + row + i) = xv;
+            }
+            v[it] = xv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float f = (float)xv[j];
+                s[0] += f;
+                s[1] += f * f;
+            }
+        }
+    }
+    if (g1 == nullptr) {  // last layer: residual only
+        return;
+    }
+    block_sum<2>(s, red);
+    const float mean = s[0] / (float)n;
+    const float rstd = rsqrtf(s[1] / (float)n - mean * mean + eps);
+    const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+    for (int it = 0; it < DLN_NV; it++) {
+        const int i = threadIdx.x * 8 + it * 2048;
+        if (i < n) {
+            const f16x8 ga = *reinterpret_cast<const f16x8*>(g1 + i), gb = *reinterpret_cast<const f16x8*>(g2 + i);
+            const f16x8 ba = *reinterpret_cast<const f16x8*>(b1 + i), bb = *reinterpret_cast<const f16x8*>(b2 + i);
+            f16x8       oa, ob;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const f16 c = (v[it][j] - mh) * rh;
+                f16       a = c * ga[j];
+                a           = a + ba[j];
+                f16 b       = c * gb[j];
+                b           = b + bb[j];
+                oa[j]       = a;
+                ob[j]       = b;
+            }
+            *reinterpret_cast<f16x8*>(out1 + row + i) = oa;
+            *reinterpret_cast<f16x8*>(out2 + row + i) = ob;
+        }
+    }
+}
+
+bool residual_dual_ln_supported(int n)
+{
+    return n % 8 == 0 && n <= 2048 * DLN_NV;
+}
+
+void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16* bias, int tp, int inplace_variant,
+                             const f16* g1, const f16* b1, const f16* g2, const f16* b2, f16* out1, f16* out2, int m,
+                             int n, float eps, hipStream_t s)
+{
+    FTCF_CHECK_ARG(residual_dual_ln_supported(n), "fused residual + LayerNorm needs n % 8 == 0 and n <= 8192");
+    if (m == 0) {
+        return;
+    }
+    if (ffn) {
+        hipLaunchKernelGGL((k_residual_dual_ln<true>), dim3(m), dim3(256), 0, s, x, ffn, attn, bias, tp, inplace_variant,
+                           g1, b1, g2, b2, out1, out2, n, eps);
+    }
+    else {
+        hipLaunchKernelGGL((k_residual_dual_ln<false>), dim3(m), dim3(256), 0, s, x, ffn, attn, bias, tp,
+                           inplace_variant, g1, b1, g2, b2, out1, out2, n, eps);
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
 }
 
 // fp32 engine variant: two-pass generalLayerNorm (kernels/layernorm_kernels.cu:1565-1650)
