@@ -199,7 +199,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
 
     // ---- phase 1: qk for the cached keys (fp32 accumulate, MMHA_USE_FP32_ACUM_FOR_FMA) ----
     float lmax = -INFINITY;
-    constexpr int U = 4;
+    constexpr int U = 8;  // rows per lane and round of the looped form (long key ranges): 8 KiB per wave in flight
     auto qk_one = [&](const u32x4 raw, const int t, const int u_fast) {
         const f16x8 kv = __builtin_bit_cast(f16x8, raw);
         float       a  = 0.f;

@@ -186,7 +186,8 @@ extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, vo
 // kernel-level entry points
 // ---------------------------------------------------------------------------------------------------------------
 static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m,
-                          int n, int k, bool int8, hipStream_t s, float* smallm_ws = nullptr, int num_cu = 256)
+                          int n, int k, bool int8, hipStream_t s, float* smallm_ws = nullptr, size_t smallm_partial = 0,
+                          int num_cu = 256)
 {
     if (m <= 4) {
         SplitKParams p{};
@@ -205,7 +206,7 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
         launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
     }
     else if (m <= 16) {
-        launch_gemm_smallm(A, W, scale, bias, act, C, smallm_ws, m, n, k, int8, num_cu, s);
+        launch_gemm_smallm(A, W, scale, bias, act, C, smallm_ws, smallm_partial, m, n, k, int8, num_cu, s);
     }
     else {
         launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s);
@@ -403,7 +404,8 @@ struct ftcf_gptneox {
         *d_min_length = nullptr;
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
-    float*    smallm_ws = nullptr;  // split-K partials of the batched decode GEMM (5..16 rows)
+    float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
+    size_t    smallm_partial = 0;
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
     int *  tiled_ids = nullptr, *tiled_len = nullptr, *parent_ids = nullptr, *cache_indir = nullptr;
     void*  beam_ws = nullptr;
@@ -539,8 +541,10 @@ struct ftcf_gptneox {
                 d_players   = c.take<PersistLayer>(L);
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
-            smallm_ws = (B > 4 && B <= 16) ? c.take<float>(gemm_smallm_workspace_bytes(B, std::max(std::max(3 * hl, il), H)) / 4)
-                                           : nullptr;
+            smallm_partial = std::max(
+                std::max(gemm_smallm_workspace_bytes(B, 3 * hl, H, int8), gemm_smallm_workspace_bytes(B, H, hl, int8)),
+                std::max(gemm_smallm_workspace_bytes(B, il, H, int8), gemm_smallm_workspace_bytes(B, H, il, int8)));
+            smallm_ws = (B > 4 && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -584,7 +588,7 @@ struct ftcf_gptneox {
     // ---- FfnLayer / attention projections over M rows (general path) ----
     void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
     {
-        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, smallm_ws, num_cu);
+        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, smallm_ws, smallm_partial, num_cu);
     }
 
     void allreduce(f16* buf, size_t count)
@@ -991,6 +995,10 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
     FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, std::min(B, 4), 8), stream));
+    if (smallm_ws) {
+        FTCF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(smallm_ws) + smallm_partial, 0, gemm_smallm_ticket_bytes(),
+                                      stream));
+    }
     if (pplan.ok) {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         std::vector<PersistLayer> pl(L);

@@ -69,10 +69,14 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
 // C[m,n] = A[m,k] x W(tiled)  (+bias, gelu) ; int8: fused fp32 epilogue ; fp16: half epilogue
 void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
                        int k, bool int8, hipStream_t s);
-// batched decode GEMM for m <= 16 rows (HBM bound form); `workspace` (gemm_smallm_workspace_bytes) enables split-K
-size_t gemm_smallm_workspace_bytes(int m, int n_max);
+// batched decode GEMM for m <= 16 rows (HBM bound forms); with a `workspace` (>= gemm_smallm_workspace_bytes of this
+// GEMM) the burst form runs: K slices of 20 tiles, every wave requests its whole slice at once
+// at once; `workspace` = [partial_bytes of split-K partial sums][gemm_smallm_ticket_bytes(), zeroed once before the first
+// launch]: the reduction runs in the workgroup that takes the last ticket of a column block (no second launch)
+size_t gemm_smallm_workspace_bytes(int m, int n, int k, bool int8);
+size_t gemm_smallm_ticket_bytes();
 void   launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
-                          int m, int n, int k, bool int8, int num_cu, hipStream_t s);
+                          size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s);
 // logits_f32[m, n] = A[m,k] x W[n,k]^T (row major fp16 weights, m > 4)
 void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s);
 

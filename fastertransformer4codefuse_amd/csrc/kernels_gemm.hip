@@ -377,29 +377,28 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, 
     }
 }
 
-// split-K partials [ks][m][n] -> C with the GEMM epilogue (sum in split order: deterministic)
+// ---------------------------------------------------------------------------------------------------------------
+// "Burst" form of the batched decode GEMM (used whenever a split-K workspace is available).  The chunked kernel above is
+// latency bound: a workgroup lives for three dependent memory round trips to move 20 KiB per wave.  Here K is cut into
+// slices of <= SMB_T tiles and every wave requests its WHOLE slice (20 KiB, 80 VGPRs) in one go, together with the
+// workgroup's x slice (16 rows x slice_k, through LDS once): one round trip per workgroup, the whole matrix is in flight
+// at once and the launch lasts about bytes / HBM rate.  Partial sums [ks][m][n] are reduced inside the launch (tickets).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SMB_T       = 20;    // tiles per wave and slice
+constexpr int SMB_TICKETS = 4096;  // column blocks; zero before the first launch
+
 template<bool INT8>
-__global__ void k_smallm_reduce(const float* __restrict__ partial, const f16* __restrict__ bias, int act,
-                                f16* __restrict__ C, int m, int n, int ks)
+__device__ __forceinline__ f16 smallm_epilogue(float v, const f16* __restrict__ bias, const int col, const int act)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)m * n) {
-        return;
-    }
-    const int col = (int)(i % n);
-    float     v   = 0.f;
-    for (int s2 = 0; s2 < ks; s2++) {
-        v += partial[(size_t)s2 * m * n + i];
-    }
     f16 h;
-    if constexpr (INT8) {
+    if constexpr (INT8) {  // fused fp32 epilogue (epilogue_helpers.h:52-62)
         v += bias ? (float)bias[col] : 0.f;
         if (act == 1) {
             v = gelu_f32(v);
         }
         h = (f16)v;
     }
-    else {
+    else {  // cuBLAS rounds to half; bias/gelu follow in half (activation_kernels.cu:401-426)
         h = (f16)v;
         if (act == 1) {
             h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
@@ -408,42 +407,194 @@ __global__ void k_smallm_reduce(const float* __restrict__ partial, const f16* __
             h = h + bias[col];
         }
     }
-    C[i] = h;
+    return h;
 }
 
-size_t gemm_smallm_workspace_bytes(int m, int n_max)
+template<bool INT8>
+__global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict__ A, const void* __restrict__ W,
+                                                           const f16* __restrict__ scale, const f16* __restrict__ bias,
+                                                           int act, f16* __restrict__ C, float* __restrict__ partial,
+                                                           unsigned* __restrict__ tickets, int m, int n, int k)
 {
-    return (size_t)8 * m * n_max * sizeof(float);
+    constexpr int TK   = INT8 ? TILE_K_I8 : TILE_K_F16;
+    constexpr int KMAX = SMB_T * TK;  // k per slice
+    __shared__ int s_last;
+    constexpr int LDA  = KMAX + 8;    // halves per LDS row: rows start in different banks
+    constexpr int XP   = 16 * KMAX / 8 / 256;  // 16-byte pieces of x per thread: 10 (int8) / 5 (fp16)
+    __shared__ __attribute__((aligned(16))) f16 As[16 * LDA];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int NT = n / 16, KT = k / TK, ks = gridDim.y;
+    const int nt = blockIdx.x * 4 + wid;
+    const bool active = nt < NT;
+    const int t0 = (int)((long)KT * blockIdx.y / ks), t1 = (int)((long)KT * (blockIdx.y + 1) / ks);
+    const int nts = t1 - t0;  // <= SMB_T
+
+    f16x2 scale2 = {(f16)1.f, (f16)1.f};
+    if constexpr (INT8) {
+        const f16 sc = scale[(active ? nt : 0) * 16 + c];
+        scale2       = f16x2{sc, sc};
+    }
+    const u32x4* wp = reinterpret_cast<const u32x4*>(W) + ((size_t)(active ? nt : 0) * KT + t0) * 64 + lane;
+    u32x4        wr[SMB_T];
+#pragma unroll
+    for (int u = 0; u < SMB_T; u++) {
+        const int t = u < nts ? u : nts - 1;  // clamped, never conditional
+        wr[u]       = __builtin_nontemporal_load(wp + (size_t)t * 64);
+    }
+    u32x4     xr[XP];
+    const int ppr = nts * TK / 8;  // pieces per row of this slice
+#pragma unroll
+    for (int i = 0; i < XP; i++) {
+        const int pc  = threadIdx.x + i * 256;
+        int       row = pc / (KMAX / 8), p8 = pc % (KMAX / 8);
+        row           = row < m ? row : m - 1;
+        p8            = p8 < ppr ? p8 : ppr - 1;
+        xr[i]         = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)t0 * TK + p8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < XP; i++) {
+        const int pc = threadIdx.x + i * 256;
+        *reinterpret_cast<u32x4*>(&As[(pc / (KMAX / 8)) * LDA + (pc % (KMAX / 8)) * 8]) = xr[i];
+    }
+    __syncthreads();
+    f32x4      acc = {0.f, 0.f, 0.f, 0.f};
+    const f16* xs  = &As[c * LDA + g * (INT8 ? 16 : 8)];
+#pragma unroll
+    for (int u = 0; u < SMB_T; u++) {
+        if (u < nts) {
+            consume_tile_raw<INT8>(wr[u], xs + u * TK, scale2, acc);
+        }
+    }
+    const int col = nt * 16 + c;
+    if (ks > 1) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = g * 4 + j;
+                if (row < m) {
+                    __hip_atomic_store(&partial[((size_t)blockIdx.y * m + row) * n + col], acc[j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // The slice workgroup of this column block that takes the last ticket adds the partials in slice order
+        // (deterministic) and applies the epilogue: no reduction launch (a dependent launch costs more than it computes
+        // here).  The partials are write-through (agent scope) stores read back with agent-scope loads, so ordering them
+        // before the ticket only needs the stores to have completed (vmcnt); an agent-scope release fence would write back
+        // the whole L2 (measured: 20 -> 140 us per launch).  The ticket resets itself for the next launch on the stream.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last           = (t == (unsigned)ks - 1u);
+            if (s_last) {
+                __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (!s_last) {
+            return;
+        }
+        // 64 columns x m rows: 4 outputs per thread, RS slices of each requested together (an agent-scope load is a memory
+        // round trip)
+        constexpr int RS = 4;
+        const int     cc = blockIdx.x * 64 + (threadIdx.x & 63);
+        float         v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cc < n) {
+            for (int s0 = 0; s0 < ks; s0 += RS) {
+                float pv[4][RS];
+#pragma unroll
+                for (int j = 0; j < RS; j++) {
+                    const int s2 = s0 + j < ks ? s0 + j : ks - 1;
+#pragma unroll
+                    for (int o = 0; o < 4; o++) {
+                        int row  = (threadIdx.x >> 6) + o * 4;
+                        row      = row < m ? row : m - 1;
+                        pv[o][j] = __hip_atomic_load(&partial[((size_t)s2 * m + row) * n + cc], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RS; j++) {
+                    if (s0 + j < ks) {
+#pragma unroll
+                        for (int o = 0; o < 4; o++) {
+                            v[o] += pv[o][j];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                const int row = (threadIdx.x >> 6) + o * 4;
+                if (row < m) {
+                    C[(size_t)row * n + cc] = smallm_epilogue<INT8>(v[o], bias, cc, act);
+                }
+            }
+        }
+        return;
+    }
+    if (!active) {
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = g * 4 + j;
+        if (row < m) {
+            C[(size_t)row * n + col] = smallm_epilogue<INT8>(acc[j], bias, col, act);
+        }
+    }
+}
+
+static int smallm_burst_slices(int k, bool int8)
+{
+    const int KT = k / (int8 ? TILE_K_I8 : TILE_K_F16);
+    return (KT + SMB_T - 1) / SMB_T;
+}
+
+// split-K partials [slices][m][n] of ONE GEMM; take the maximum over the GEMMs that share the workspace
+size_t gemm_smallm_workspace_bytes(int m, int n, int k, bool int8)
+{
+    return (size_t)std::max(8, smallm_burst_slices(k, int8)) * m * n * sizeof(float);
+}
+size_t gemm_smallm_ticket_bytes()
+{
+    return SMB_TICKETS * sizeof(unsigned);
 }
 
 void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
-                        int m, int n, int k, bool int8, int num_cu, hipStream_t s)
+                        size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s)
 {
     FTCF_CHECK_ARG(m >= 1 && m <= 16, "small-m GEMM handles 1..16 rows");
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0 && n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
     const int NT = n / 16, bx = (NT + 3) / 4;
     const int KT = k / (int8 ? TILE_K_I8 : TILE_K_F16);
-    int       ks = 1;
-    while (ks < 8 && bx * ks < 2 * num_cu && KT / (ks * 2) >= 2 * SM_U && workspace != nullptr) {
-        ks *= 2;  // enough workgroups to fill the chip, at least two chunks per K range
+    if (workspace != nullptr) {  // burst form; the ticket table sits behind `partial_bytes` of partial sums
+        const int ks = smallm_burst_slices(k, int8);
+        FTCF_CHECK_ARG(bx <= SMB_TICKETS && gemm_smallm_workspace_bytes(m, n, k, int8) <= partial_bytes,
+                       "small-m GEMM: split-K workspace too small");
+        unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + partial_bytes);
+        dim3      grid(bx, ks);
+        if (int8) {
+            hipLaunchKernelGGL((k_gemm_smallm_burst<true>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace,
+                               tickets, m, n, k);
+        }
+        else {
+            hipLaunchKernelGGL((k_gemm_smallm_burst<false>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace,
+                               tickets, m, n, k);
+        }
+        FTCF_HIP_CHECK(hipGetLastError());
+        return;
     }
-    dim3 grid(bx, ks);
+    // no workspace (kernel-level entry points): the chunked form over the whole K extent
+    dim3 grid(bx, 1);
     if (int8) {
         hipLaunchKernelGGL((k_gemm_smallm<true>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace, m, n, k);
     }
     else {
         hipLaunchKernelGGL((k_gemm_smallm<false>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace, m, n, k);
-    }
-    if (ks > 1) {
-        const int total = m * n;
-        if (int8) {
-            hipLaunchKernelGGL((k_smallm_reduce<true>), dim3((total + 255) / 256), dim3(256), 0, s, workspace, bias, act,
-                               C, m, n, ks);
-        }
-        else {
-            hipLaunchKernelGGL((k_smallm_reduce<false>), dim3((total + 255) / 256), dim3(256), 0, s, workspace, bias, act,
-                               C, m, n, ks);
-        }
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }
