@@ -83,3 +83,30 @@ def test_cli_example_decodes_the_golden_tokens(tmp_path, int8):
         ref = gh.run_op(op, pid, [16, 11], 8, cfg["vocab_size"], top_k=1, return_logits=False)
         assert rows[0] == ref["output_ids"][0].tolist()
         assert rows[1] == ref["output_ids"][1].tolist()
+
+
+def test_cli_example_beam_search_matches_the_hf_beams(tmp_path):
+    """beam_width > 1 through the command-line example: one output row per (request, beam), best beam first."""
+    from fastertransformer4codefuse_amd import capi
+    capi.require_gpu()
+    cfg, w, _ = load_tiny()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_gptneox_beam.npz"))
+    mdir = tmp_path / "1-gpu"
+    mdir.mkdir()
+    write_checkpoint(str(mdir), cfg, w, 0)
+    ini = tmp_path / "gptneox_config.ini"
+    ini.write_text("[ft_instance_hyperparameter]\ndata_type=fp16\ntensor_para_size=1\npipeline_para_size=1\nint8_mode=0\n"
+                   "model_name=tiny\nmodel_dir=%s\n\n[request]\nbeam_width=3\nbeam_search_diversity_rate=0.0\n"
+                   "len_penalty=0.0\ntop_k=0\ntop_p=0.0\ntemperature=1.0\nrepetition_penalty=1.0\nrequest_batch_size=1\n"
+                   "request_output_len=8\n" % mdir)
+    ids = tmp_path / "start_ids.csv"
+    ids.write_text(", ".join(map(str, g["ids_a"][0].tolist())) + "\n")
+    out = tmp_path / "out"
+    r = subprocess.run([EXE, str(ini), "--start_ids", str(ids), "--out", str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [list(map(int, line.split())) for line in out.read_text().strip().splitlines()]
+    assert len(rows) == 3 and all(len(x) == 16 + 8 for x in rows)
+    for k in range(3):
+        assert rows[k][:16] == g["ids_a"][0].tolist()
+        assert rows[k][16:] == g["hf_beam_tokens_a"][0, k].tolist()
