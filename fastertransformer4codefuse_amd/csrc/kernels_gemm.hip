@@ -42,7 +42,10 @@ __device__ __forceinline__ void consume_tile_raw(const u32x4 w, const f16* xr, c
 }
 constexpr int GEMM_LDA   = GEMM_KSTEP + 8;  // halves per LDS row (16 B pad)
 
-template<bool INT8, int RG>
+// RG row groups (16 rows each) x NG column groups (16 columns each) per wave: an A fragment read from LDS feeds NG MFMAs
+// and a dequantised B fragment RG of them.  NG = 1 reads 1 KiB of LDS per MFMA and is LDS-bandwidth bound (22 % of the
+// MFMA peak at m = 1024); NG = 4 cuts that to a quarter (prefill).  Block tile: (RG*16) x (4 waves * NG * 16).
+template<bool INT8, int RG, int NG>
 __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
                                                     int act, f16* __restrict__ C, int m, int n, int k)
@@ -53,20 +56,22 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, c
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * BM;
-    const int nt = blockIdx.x * 4 + wid;  // column group of this wave
+    const int nt0 = (blockIdx.x * 4 + wid) * NG;  // first column group of this wave
     const int NT = n / 16;
-    const bool active = nt < NT;
     const int  ksteps = k / GEMM_KSTEP;
 
-    // B stream pointers
-    const int    KT    = INT8 ? k / TILE_K_I8 : k / TILE_K_F16;
-    const u32x4* wp    = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(W)
-                                                     + ((size_t)(active ? nt : 0) * KT * 64 + lane) * 16);
-    f16x2        scale2 = {(f16)1.f, (f16)1.f};
-    if constexpr (INT8) {
-        if (active) {
+    // B stream pointers (column groups past the end re-read the last one; their results are dropped)
+    const int    KT = INT8 ? k / TILE_K_I8 : k / TILE_K_F16;
+    const u32x4* wp[NG];
+    f16x2        scale2[NG];
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        const int nt = nt0 + j < NT ? nt0 + j : NT - 1;
+        wp[j]        = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(W) + ((size_t)nt * KT * 64 + lane) * 16);
+        scale2[j]    = f16x2{(f16)1.f, (f16)1.f};
+        if constexpr (INT8) {
             const f16 sc = scale[nt * 16 + c];
-            scale2       = f16x2{sc, sc};
+            scale2[j]    = f16x2{sc, sc};
         }
     }
 
@@ -95,95 +100,105 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, c
         }
     };
 
-    f32x4 acc[RG];
+    f32x4 acc[RG][NG];
 #pragma unroll
     for (int r = 0; r < RG; r++) {
-        acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 
-    u32x4 breg[2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
+    u32x4 breg[NG][2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
     auto load_b = [&](int ks) {
-        if constexpr (INT8) {
-            breg[0] = __builtin_nontemporal_load(wp + (size_t)ks * 64);
-        }
-        else {
-            breg[0] = __builtin_nontemporal_load(wp + (size_t)(2 * ks) * 64);
-            breg[1] = __builtin_nontemporal_load(wp + (size_t)(2 * ks + 1) * 64);
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            if constexpr (INT8) {
+                breg[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)ks * 64);
+            }
+            else {
+                breg[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks) * 64);
+                breg[j][1] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks + 1) * 64);
+            }
         }
     };
 
     load_a(0);
-    if (active) {
-        load_b(0);
-    }
+    load_b(0);
     for (int ks = 0; ks < ksteps; ks++) {
         __syncthreads();  // previous step's fragment reads are done
         store_a();
-        f16x8 bf[2];
-        if constexpr (INT8) {
-            f16x2 d[8];
-            dequant4(breg[0].x, scale2, d[0], d[1]);
-            dequant4(breg[0].y, scale2, d[2], d[3]);
-            dequant4(breg[0].z, scale2, d[4], d[5]);
-            dequant4(breg[0].w, scale2, d[6], d[7]);
-            bf[0] = f16x8{d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
-            bf[1] = f16x8{d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
-        }
-        else {
-            bf[0] = __builtin_bit_cast(f16x8, breg[0]);
-            bf[1] = __builtin_bit_cast(f16x8, breg[1]);
+        f16x8 bf[NG][2];
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            if constexpr (INT8) {
+                f16x2 d[8];
+                dequant4(breg[j][0].x, scale2[j], d[0], d[1]);
+                dequant4(breg[j][0].y, scale2[j], d[2], d[3]);
+                dequant4(breg[j][0].z, scale2[j], d[4], d[5]);
+                dequant4(breg[j][0].w, scale2[j], d[6], d[7]);
+                bf[j][0] = f16x8{d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
+                bf[j][1] = f16x8{d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
+            }
+            else {
+                bf[j][0] = __builtin_bit_cast(f16x8, breg[j][0]);
+                bf[j][1] = __builtin_bit_cast(f16x8, breg[j][1]);
+            }
         }
         __syncthreads();
-        if (ks + 1 < ksteps) {  // prefetch the next stage into registers while this one is consumed
-            load_a(ks + 1);
-            if (active) {
-                load_b(ks + 1);
-            }
+        {  // prefetch the next stage into registers while this one is consumed (clamped on the last step)
+            const int nx = ks + 1 < ksteps ? ks + 1 : ks;
+            load_a(nx);
+            load_b(nx);
         }
-        if (active) {
-            // A fragment k offsets must follow the B fragment's k order (see file header)
-            const int koff0 = INT8 ? g * 16 : g * 8;
-            const int koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
+        // A fragment k offsets must follow the B fragment's k order (see file header)
+        const int koff0 = INT8 ? g * 16 : g * 8;
+        const int koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
 #pragma unroll
-            for (int r = 0; r < RG; r++) {
-                const f16x8 a0 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff0]);
-                const f16x8 a1 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff1]);
-                acc[r]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[0], acc[r], 0, 0, 0);
-                acc[r]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[1], acc[r], 0, 0, 0);
+        for (int r = 0; r < RG; r++) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff0]);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff1]);
+#pragma unroll
+            for (int j = 0; j < NG; j++) {
+                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[j][0], acc[r][j], 0, 0, 0);
+                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j][1], acc[r][j], 0, 0, 0);
             }
         }
-    }
-    if (!active) {
-        return;
     }
     // C/D layout of mfma 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
-    const int   col = nt * 16 + c;
-    const float bv  = bias ? (float)bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < RG; r++) {
+    for (int j = 0; j < NG; j++) {
+        if (nt0 + j >= NT) {
+            continue;
+        }
+        const int   col = (nt0 + j) * 16 + c;
+        const float bv  = bias ? (float)bias[col] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = m0 + r * 16 + g * 4 + j;
-            if (row < m) {
-                float v = acc[r][j];
-                f16   h;
-                if constexpr (INT8) {  // fused fp32 epilogue (epilogue_helpers.h:52-62)
-                    v += bv;
-                    if (act == 1) {
-                        v = gelu_f32(v);
+        for (int r = 0; r < RG; r++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = m0 + r * 16 + g * 4 + q;
+                if (row < m) {
+                    float v = acc[r][j][q];
+                    f16   h;
+                    if constexpr (INT8) {  // fused fp32 epilogue (epilogue_helpers.h:52-62)
+                        v += bv;
+                        if (act == 1) {
+                            v = gelu_f32(v);
+                        }
+                        h = (f16)v;
                     }
-                    h = (f16)v;
+                    else {  // cuBLAS rounds to half; bias/gelu follow in half (activation_kernels.cu:401-426)
+                        h = (f16)v;
+                        if (act == 1) {
+                            h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
+                        }
+                        else if (bias) {
+                            h = h + bias[col];
+                        }
+                    }
+                    C[(size_t)row * n + col] = h;
                 }
-                else {  // cuBLAS rounds to half; bias/gelu follow in half (activation_kernels.cu:401-426)
-                    h = (f16)v;
-                    if (act == 1) {
-                        h = gelu_f16(bias ? (f16)(h + bias[col]) : h);
-                    }
-                    else if (bias) {
-                        h = h + bias[col];
-                    }
-                }
-                C[(size_t)row * n + col] = h;
             }
         }
     }
@@ -201,19 +216,22 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     if (m <= 32) {
         dim3 grid((NT + 3) / 4, (m + 31) / 32);
         if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 2>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<true, 2, 1>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 2>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<false, 2, 1>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
     }
     else {
-        dim3 grid((NT + 3) / 4, (m + 127) / 128);
+        // (RG, NG) = (8, 2) measured best on the 13B prefill: 50.7 ms vs 57.8 (8, 1), 61.0 (8, 4: one wave per SIMD),
+        // 53.4 (4, 4), 53.8 (4, 2)
+        constexpr int NG = 2;
+        dim3          grid((NT + 4 * NG - 1) / (4 * NG), (m + 127) / 128);
         if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 8>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 8>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());
@@ -570,7 +588,6 @@ void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16
     FTCF_CHECK_ARG(m >= 1 && m <= 16, "small-m GEMM handles 1..16 rows");
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0 && n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
     const int NT = n / 16, bx = (NT + 3) / 4;
-    const int KT = k / (int8 ? TILE_K_I8 : TILE_K_F16);
     if (workspace != nullptr) {  // burst form; the ticket table sits behind `partial_bytes` of partial sums
         const int ks = smallm_burst_slices(k, int8);
         FTCF_CHECK_ARG(bx <= SMB_TICKETS && gemm_smallm_workspace_bytes(m, n, k, int8) <= partial_bytes,
