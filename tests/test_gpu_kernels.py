@@ -157,10 +157,11 @@ def test_layernorm_and_residual_match_oracle_rounding_points():
 
 
 @pytest.mark.parametrize("dh,nh,rot", [(128, 5, 32), (64, 4, 16)])
-@pytest.mark.parametrize("tl", [0, 1, 31, 100, 700])
-def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl):
+@pytest.mark.parametrize("tl,s_max", [(0, 1024), (1, 1024), (31, 1024), (100, 1024), (700, 1024), (5000, 6000), (4099, 4100)])
+def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl, s_max):
+    """s_max 1024: every KV split fits the all-in-registers form; 6000 / 4100: the looped form (384 / 272 keys per split)."""
     rng = np.random.RandomState(tl + dh)
-    B, s_max = 3, 1024
+    B = 3
     hl = nh * dh
     kc = orc.round_half(rng.randn(B, nh, s_max, dh).astype(np.float32))
     vc = orc.round_half(rng.randn(B, nh, s_max, dh).astype(np.float32))
