@@ -10,7 +10,8 @@
 //  * k_qkv_bias_rotary_cache + k_context_attention : prefill, the counterpart of add_fusedQKV_bias_transpose_kernel
 //      (kernels/unfused_attention_kernels.cu:1326-1484), transpose_4d_batch_major_{k,v}_cache (:1673-1749), the
 //      batched QK^T / P.V GEMMs and softmax_kernel (:255-332) of GptContextAttentionLayer.cc:142-345, fused into a
-//      causal online-softmax kernel (no S x S score buffers).
+//      causal online-softmax kernel (no S x S score buffers); k_context_attention_mfma is the form in use (QK^T and PV
+//      on MFMA tiles), k_context_attention the first VALU form (FTCF_CTX_ATTN_VALU=1, A/B runs).
 //
 // Cache layout (engine private): K and V both [B, nh, s_max, dh] fp16, dh contiguous: one wave-load = 1 KiB of
 // consecutive keys.  Roofline: HBM (decode: 4*t*dh*nh bytes per layer per row).
@@ -256,6 +257,160 @@ __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict
     }
 }
 
+// MFMA form of the causal prefill attention: one workgroup = 64 query rows of one (row, head), a wave = 16 of them.
+// Per 64-key tile: S = Q K^T on mfma_f32_16x16x32_f16 (K rows are d-contiguous = the B-operand order), online softmax in
+// the accumulator layout (a row lives in 16 lanes x 4 key groups), P rounded to half (the reference's softmax output
+// type) and turned into the A operand through a wave-private LDS tile, O += P V with V staged TRANSPOSED in LDS (the B
+// operand wants 8 consecutive keys of one output dim per lane).  Tiles above the diagonal of a wave are skipped.
+template<int DH>
+__global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __restrict__ qkv,
+                                                                const int* __restrict__ input_lengths,
+                                                                const f16* __restrict__ k_cache,
+                                                                const f16* __restrict__ v_cache, int S, int nh, int s_max,
+                                                                f16* __restrict__ ctx, float qk_scale)
+{
+    constexpr int KT  = 64;        // keys per tile
+    constexpr int LDK = DH + 8;    // sK row (halves): rows start in different banks
+    constexpr int LDV = KT + 8;    // sVt row: Vt[d][key]
+    constexpr int LDP = KT + 8;    // sP row: P[row][key]
+    constexpr int ND  = DH / 32;   // d steps of Q K^T
+    constexpr int NO  = DH / 16;   // output column groups
+    __shared__ __attribute__((aligned(16))) f16 sK[KT * LDK];
+    __shared__ __attribute__((aligned(16))) f16 sVt[DH * LDV];
+    __shared__ __attribute__((aligned(16))) f16 sP[4][16 * LDP];
+
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int hl  = nh * DH;
+    const int len = input_lengths[b];
+    if (q0 >= len) {
+        return;  // padded query rows are discarded by the reference
+    }
+    // Q fragments (A operand): row c of this wave's 16, d = s*32 + g*8 .. +8 (already bias + rotary'd in the qkv buffer)
+    f16x8 qf[ND];
+    {
+        int qrow = q0 + wid * 16 + c;
+        qrow     = qrow < S ? qrow : S - 1;
+        const f16* qp = qkv + ((size_t)b * S + qrow) * 3 * hl + h * DH + g * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < ND; s2++) {
+            qf[s2] = *reinterpret_cast<const f16x8*>(qp + s2 * 32);
+        }
+    }
+    const f16* kc = k_cache + ((size_t)b * nh + h) * s_max * DH;
+    const f16* vc = v_cache + ((size_t)b * nh + h) * s_max * DH;
+    f32x4      o[NO];
+    float      m_run[4], l_run[4];
+#pragma unroll
+    for (int n = 0; n < NO; n++) {
+        o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        m_run[j] = -INFINITY;
+        l_run[j] = 0.f;
+    }
+    const int q_last   = min(q0 + 63, len - 1);
+    const int w_last   = q0 + wid * 16 + 15;  // last query row of this wave
+    f16*      sPw      = sP[wid];
+    for (int k0 = 0; k0 <= q_last; k0 += KT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < KT * DH / 8; i += 256) {  // K tile, row major
+            const int r = i / (DH / 8), ch = i % (DH / 8);
+            int       kk = k0 + r;
+            kk           = kk < S ? kk : S - 1;
+            *reinterpret_cast<u32x4*>(&sK[r * LDK + ch * 8]) = *reinterpret_cast<const u32x4*>(kc + (size_t)kk * DH + ch * 8);
+        }
+        for (int i = threadIdx.x; i < (KT / 2) * (DH / 8); i += 256) {  // V tile, transposed: a thread moves 2 keys x 8 dims
+            const int rp = i % (KT / 2), ch = i / (KT / 2);            // (lanes of a wave spread over the banks)
+            int       k1 = k0 + 2 * rp, k2 = k0 + 2 * rp + 1;
+            k1           = k1 < S ? k1 : S - 1;
+            k2           = k2 < S ? k2 : S - 1;
+            const f16x8 v1 = *reinterpret_cast<const f16x8*>(vc + (size_t)k1 * DH + ch * 8);
+            const f16x8 v2 = *reinterpret_cast<const f16x8*>(vc + (size_t)k2 * DH + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                *reinterpret_cast<f16x2*>(&sVt[(ch * 8 + e) * LDV + 2 * rp]) = f16x2{v1[e], v2[e]};
+            }
+        }
+        __syncthreads();
+        if (k0 > w_last) {
+            continue;  // above this wave's diagonal (the barriers above are still taken by every wave)
+        }
+        // ---- S = Q K^T : sc[kg][j] = score of row g*4+j and key k0 + kg*16 + c ----
+        f32x4 sc[4];
+#pragma unroll
+        for (int kg = 0; kg < 4; kg++) {
+            sc[kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < ND; s2++) {
+                const f16x8 kb = *reinterpret_cast<const f16x8*>(&sK[(kg * 16 + c) * LDK + s2 * 32 + g * 8]);
+                sc[kg]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[s2], kb, sc[kg], 0, 0, 0);
+            }
+        }
+        // ---- online softmax per row (mask of gpt_kernels.cu:359-402), P -> LDS as half ----
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int qi = q0 + wid * 16 + g * 4 + j;
+            float     sv[4];
+            float     mt = -INFINITY;
+#pragma unroll
+            for (int kg = 0; kg < 4; kg++) {
+                const int  key   = k0 + kg * 16 + c;
+                const bool valid = (key <= qi) && (qi < len);
+                sv[kg]           = valid ? qk_scale * sc[kg][j] : -INFINITY;
+                mt               = fmaxf(mt, sv[kg]);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+            }
+            const float mn = fmaxf(m_run[j], mt);
+            const float al = (m_run[j] == -INFINITY) ? 0.f : __expf(m_run[j] - mn);
+            float       ls = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 4; kg++) {
+                const float e = (sv[kg] == -INFINITY || mn == -INFINITY) ? 0.f : __expf(sv[kg] - mn);
+                ls += e;
+                sPw[(g * 4 + j) * LDP + kg * 16 + c] = (f16)e;
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                ls += __shfl_xor(ls, off, 64);
+            }
+            l_run[j] = l_run[j] * al + ls;
+            m_run[j] = mn;
+#pragma unroll
+            for (int n = 0; n < NO; n++) {
+                o[n][j] *= al;
+            }
+        }
+        // sP[wid] is written and read by this wave only: LDS operations of a wave are ordered, no barrier needed
+        // ---- O += P V ----
+#pragma unroll
+        for (int ks = 0; ks < KT / 32; ks++) {
+            const f16x8 pa = *reinterpret_cast<const f16x8*>(&sPw[c * LDP + ks * 32 + g * 8]);
+#pragma unroll
+            for (int n = 0; n < NO; n++) {
+                const f16x8 vb = *reinterpret_cast<const f16x8*>(&sVt[(n * 16 + c) * LDV + ks * 32 + g * 8]);
+                o[n]           = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa, vb, o[n], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int qi = q0 + wid * 16 + g * 4 + j;
+        if (qi < len && qi < S) {
+            const float inv = 1.f / (l_run[j] + 1e-6f);  // unfused_attention_kernels.cu:322
+#pragma unroll
+            for (int n = 0; n < NO; n++) {
+                ctx[((size_t)b * S + qi) * hl + h * DH + n * 16 + c] = (f16)(o[n][j] * inv);
+            }
+        }
+    }
+}
+
 void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                               f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx, hipStream_t s)
 {
@@ -265,14 +420,28 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
                        qkv_bias, input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max);
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
-    dim3        grid((S + 15) / 16, nh, B);
-    if (dh == 128) {
-        hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                           s_max, ctx, qk_scale);
+    static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
+    if (valu_form) {
+        dim3 grid((S + 15) / 16, nh, B);
+        if (dh == 128) {
+            hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
+                               s_max, ctx, qk_scale);
+        }
+        else {
+            hipLaunchKernelGGL(k_context_attention<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
+                               s_max, ctx, qk_scale);
+        }
     }
     else {
-        hipLaunchKernelGGL(k_context_attention<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                           s_max, ctx, qk_scale);
+        dim3 grid((S + 63) / 64, nh, B);
+        if (dh == 128) {
+            hipLaunchKernelGGL(k_context_attention_mfma<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
+                               nh, s_max, ctx, qk_scale);
+        }
+        else {
+            hipLaunchKernelGGL(k_context_attention_mfma<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
+                               nh, s_max, ctx, qk_scale);
+        }
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }
