@@ -44,19 +44,22 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 8;  // halves per LDS row (16 B pad)
 
 // RG row groups (16 rows each) x NG column groups (16 columns each) per wave: an A fragment read from LDS feeds NG MFMAs
 // and a dequantised B fragment RG of them.  NG = 1 reads 1 KiB of LDS per MFMA and is LDS-bandwidth bound (22 % of the
-// MFMA peak at m = 1024); NG = 4 cuts that to a quarter (prefill).  Block tile: (RG*16) x (4 waves * NG * 16).
-template<bool INT8, int RG, int NG>
-__global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
+// MFMA peak at m = 1024); NG = 2 halves that.  Block tile: (RG*16) x (WAVES * NG * 16); the waves of a workgroup share the A
+// tile in LDS, so WAVES = 8 halves the number of workgroups re-reading A from L2 (prefill is L2-traffic bound: at m = 1024
+// a 128 x 128 tile moves 1.2 GB of A and 0.6 GB of weights through the L2 for the QKV GEMM).
+template<bool INT8, int RG, int NG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
                                                     int act, f16* __restrict__ C, int m, int n, int k)
 {
-    constexpr int BM = RG * 16;
-    __shared__ __attribute__((aligned(16))) f16 As[BM * GEMM_LDA];
+    constexpr int BM   = RG * 16;
+    constexpr int NTHR = 64 * WAVES;
+    __shared__ __attribute__((aligned(16))) f16 As[2][BM * GEMM_LDA];  // double buffered: one barrier per k-step
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * BM;
-    const int nt0 = (blockIdx.x * 4 + wid) * NG;  // first column group of this wave
+    const int nt0 = (blockIdx.x * WAVES + wid) * NG;  // first column group of this wave
     const int NT = n / 16;
     const int  ksteps = k / GEMM_KSTEP;
 
@@ -77,12 +80,12 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, c
 
     // A staging: BM x 64 halves, 8 halves (16 B) per thread-chunk
     constexpr int CHUNKS = BM * GEMM_KSTEP / 8;             // 16-byte chunks per stage
-    constexpr int CPT    = (CHUNKS + 255) / 256;            // chunks per thread
+    constexpr int CPT    = (CHUNKS + NTHR - 1) / NTHR;            // chunks per thread
     u32x4         areg[CPT];
     auto load_a = [&](int ks) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int ch = threadIdx.x + i * 256;
+            const int ch = threadIdx.x + i * NTHR;
             if (ch < CHUNKS) {
                 int row = m0 + ch / 8;
                 row     = row < m ? row : m - 1;
@@ -90,12 +93,12 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, c
             }
         }
     };
-    auto store_a = [&]() {
+    auto store_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const int ch = threadIdx.x + i * 256;
+            const int ch = threadIdx.x + i * NTHR;
             if (ch < CHUNKS) {
-                *reinterpret_cast<u32x4*>(&As[(ch / 8) * GEMM_LDA + (ch % 8) * 8]) = areg[i];
+                *reinterpret_cast<u32x4*>(&As[buf][(ch / 8) * GEMM_LDA + (ch % 8) * 8]) = areg[i];
             }
         }
     };
@@ -109,61 +112,79 @@ __global__ __launch_bounds__(256) void k_gemm_tiled(const f16* __restrict__ A, c
         }
     }
 
-    u32x4 breg[NG][2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
-    auto load_b = [&](int ks) {
+    // weight tiles: three k-steps in flight per wave (the first reader of a tile misses to HBM: ~900+ cycles, more than
+    // one k-step lasts); requests are clamped, never conditional
+    typedef u32x4 BTile[NG][2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
+    BTile         B0, B1, B2;
+    auto load_b = [&](BTile& br, int ks) {
+        ks = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if constexpr (INT8) {
-                breg[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)ks * 64);
+                br[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)ks * 64);
             }
             else {
-                breg[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks) * 64);
-                breg[j][1] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks + 1) * 64);
+                br[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks) * 64);
+                br[j][1] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks + 1) * 64);
             }
         }
     };
-
-    load_a(0);
-    load_b(0);
-    for (int ks = 0; ks < ksteps; ks++) {
-        __syncthreads();  // previous step's fragment reads are done
-        store_a();
+    // at entry As[ks & 1] holds stage ks (its barrier has been passed) and areg stage ks + 1
+    auto step = [&](const BTile& br, int ks) {
         f16x8 bf[NG][2];
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if constexpr (INT8) {
                 f16x2 d[8];
-                dequant4(breg[j][0].x, scale2[j], d[0], d[1]);
-                dequant4(breg[j][0].y, scale2[j], d[2], d[3]);
-                dequant4(breg[j][0].z, scale2[j], d[4], d[5]);
-                dequant4(breg[j][0].w, scale2[j], d[6], d[7]);
+                dequant4(br[j][0].x, scale2[j], d[0], d[1]);
+                dequant4(br[j][0].y, scale2[j], d[2], d[3]);
+                dequant4(br[j][0].z, scale2[j], d[4], d[5]);
+                dequant4(br[j][0].w, scale2[j], d[6], d[7]);
                 bf[j][0] = f16x8{d[0][0], d[0][1], d[1][0], d[1][1], d[2][0], d[2][1], d[3][0], d[3][1]};
                 bf[j][1] = f16x8{d[4][0], d[4][1], d[5][0], d[5][1], d[6][0], d[6][1], d[7][0], d[7][1]};
             }
             else {
-                bf[j][0] = __builtin_bit_cast(f16x8, breg[j][0]);
-                bf[j][1] = __builtin_bit_cast(f16x8, breg[j][1]);
+                bf[j][0] = __builtin_bit_cast(f16x8, br[j][0]);
+                bf[j][1] = __builtin_bit_cast(f16x8, br[j][1]);
             }
         }
-        __syncthreads();
-        {  // prefetch the next stage into registers while this one is consumed (clamped on the last step)
-            const int nx = ks + 1 < ksteps ? ks + 1 : ks;
-            load_a(nx);
-            load_b(nx);
-        }
         // A fragment k offsets must follow the B fragment's k order (see file header)
-        const int koff0 = INT8 ? g * 16 : g * 8;
-        const int koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
+        const int  koff0 = INT8 ? g * 16 : g * 8;
+        const int  koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
+        const f16* as    = As[ks & 1];
 #pragma unroll
         for (int r = 0; r < RG; r++) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff0]);
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(&As[(r * 16 + c) * GEMM_LDA + koff1]);
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff0]);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff1]);
 #pragma unroll
             for (int j = 0; j < NG; j++) {
                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[j][0], acc[r][j], 0, 0, 0);
                 acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j][1], acc[r][j], 0, 0, 0);
             }
         }
+        store_a((ks + 1) & 1);  // the other buffer: its readers (stage ks - 1) finished before the previous barrier
+        load_a(ks + 2 < ksteps ? ks + 2 : ksteps - 1);
+        __syncthreads();
+    };
+
+    load_a(0);
+    load_b(B0, 0);
+    load_b(B1, 1);
+    load_b(B2, 2);
+    store_a(0);
+    load_a(1 < ksteps ? 1 : 0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ks += 3) {
+        step(B0, ks);
+        load_b(B0, ks + 3);
+        if (ks + 1 < ksteps) {
+            step(B1, ks + 1);
+        }
+        load_b(B1, ks + 4);
+        if (ks + 2 < ksteps) {
+            step(B2, ks + 2);
+        }
+        load_b(B2, ks + 5);
     }
     // C/D layout of mfma 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -216,22 +237,34 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     if (m <= 32) {
         dim3 grid((NT + 3) / 4, (m + 31) / 32);
         if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 2, 1>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<true, 2, 1, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 2, 1>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<false, 2, 1, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
     }
     else {
         // (RG, NG) = (8, 2) measured best on the 13B prefill: 50.7 ms vs 57.8 (8, 1), 61.0 (8, 4: one wave per SIMD),
         // 53.4 (4, 4), 53.8 (4, 2)
         constexpr int NG = 2;
+        static const int waves = getenv("FTCF_GEMM_WAVES") ? atoi(getenv("FTCF_GEMM_WAVES")) : 8;
+        if (waves == 8) {
+            dim3 grid((NT + 8 * NG - 1) / (8 * NG), (m + 127) / 128);
+            if (int8) {
+                hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 8>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k);
+            }
+            else {
+                hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 8>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k);
+            }
+            FTCF_HIP_CHECK(hipGetLastError());
+            return;
+        }
         dim3          grid((NT + 4 * NG - 1) / (4 * NG), (m + 127) / 128);
         if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());
