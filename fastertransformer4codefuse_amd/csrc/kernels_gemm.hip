@@ -40,7 +40,11 @@ __device__ __forceinline__ void consume_tile_raw(const u32x4 w, const f16* xr, c
         acc            = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
     }
 }
-constexpr int GEMM_LDA   = GEMM_KSTEP + 8;  // halves per LDS row (16 B pad)
+// A tile row in LDS: 64 k + 32 B pad, and the eight 16-byte k chunks of a row stored in the order the MFMA A fragments are
+// read -- chunk position p holds k chunk (p & 3) * 2 + (p >> 2) for int8 weights (the B tile interleaves k in 16s), p for
+// fp16 -- so that lane (c, g) reads positions g and 4 + g: with this row stride the 16 lanes of every ds_read_b128 phase
+// fall on 64 distinct banks (a plain [k] order with 16 B pad was 2-way conflicted: SQ_LDS_BANK_CONFLICT 44 %).
+constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 
 // RG row groups (16 rows each) x NG column groups (16 columns each) per wave: an A fragment read from LDS feeds NG MFMAs
 // and a dequantised B fragment RG of them.  NG = 1 reads 1 KiB of LDS per MFMA and is LDS-bandwidth bound (22 % of the
@@ -98,7 +102,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
         for (int i = 0; i < CPT; i++) {
             const int ch = threadIdx.x + i * NTHR;
             if (ch < CHUNKS) {
-                *reinterpret_cast<u32x4*>(&As[buf][(ch / 8) * GEMM_LDA + (ch % 8) * 8]) = areg[i];
+                const int kc = ch % 8;                                             // k chunk of this piece
+                const int pc = INT8 ? (((kc & 1) << 2) | (kc >> 1)) : kc;          // its position in the row
+                *reinterpret_cast<u32x4*>(&As[buf][(ch / 8) * GEMM_LDA + pc * 8]) = areg[i];
             }
         }
     };
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
             }
         }
         // A fragment k offsets must follow the B fragment's k order (see file header)
-        const int  koff0 = INT8 ? g * 16 : g * 8;
-        const int  koff1 = INT8 ? g * 16 + 8 : 32 + g * 8;
+        const int  koff0 = g * 8;
+        const int  koff1 = 32 + g * 8;
         const f16* as    = As[ks & 1];
 #pragma unroll
         for (int r = 0; r < RG; r++) {
