@@ -413,7 +413,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
-    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 12;
+    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
