@@ -542,8 +542,8 @@ struct ftcf_gptneox {
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
             smallm_partial = std::max(
-                std::max(gemm_smallm_workspace_bytes(B, 3 * hl, H, int8), gemm_smallm_workspace_bytes(B, H, hl, int8)),
-                std::max(gemm_smallm_workspace_bytes(B, il, H, int8), gemm_smallm_workspace_bytes(B, H, il, int8)));
+                gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8),
+                gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8));
             smallm_ws = (B > 4 && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
@@ -720,11 +720,24 @@ struct ftcf_gptneox {
                     launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
                                             nrm2, B, H, 1e-5f, stream);
                 }
-                gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
-                launch_mmha(mp, stream);
-                gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
-                gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
-                gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                if (B > 4 && B <= 16 && smallm_ws) {
+                    // independent GEMMs share a launch (a dependent launch costs ~8 us of dispatch latency, most of a layer
+                    // at tensor-parallel shard sizes): [QKV, FFN1] -> MMHA -> [out-proj, FFN2]
+                    const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
+                                              {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
+                    launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, stream);
+                    launch_mmha(mp, stream);
+                    const SmallmDesc p3[2] = {{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl},
+                                              {mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}};
+                    launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream);
+                }
+                else {
+                    gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
+                    launch_mmha(mp, stream);
+                    gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
+                    gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
+                    gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                }
                 if (dual && tp1) {
                     const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
                     launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, inplace, nx ? nx->ln1_g : nullptr,

@@ -75,6 +75,18 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
 // launch]: the reduction runs in the workgroup that takes the last ticket of a column block (no second launch)
 size_t gemm_smallm_workspace_bytes(int m, int n, int k, bool int8);
 size_t gemm_smallm_ticket_bytes();
+struct SmallmDesc {  // C[m, n] = epilogue(A[m, k] x W[k, n]); act 1 = bias + gelu
+    const f16*  A;
+    const void* W;
+    const f16*  scale;
+    const f16*  bias;
+    int         act;
+    f16*        C;
+    int         n, k;
+};
+// one launch for up to two independent GEMMs with the same m (partial_bytes >= the SUM of their workspace bytes)
+void   launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
+                                hipStream_t s);
 void   launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
                           size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s);
 // logits_f32[m, n] = A[m,k] x W[n,k]^T (row major fp16 weights, m > 4)

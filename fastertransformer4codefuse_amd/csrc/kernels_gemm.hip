@@ -467,12 +467,45 @@ __device__ __forceinline__ f16 smallm_epilogue(float v, const f16* __restrict__ 
     return h;
 }
 
+// One launch runs up to two independent GEMMs with the same m ("group": QKV with FFN1, out-proj with FFN2): a dependent
+// launch costs ~8 us of dispatch latency however little it computes, which is most of a layer at tensor-parallel shard
+// sizes.  blockIdx.x selects the problem, blockIdx.y the K slice (workgroups beyond a problem's slice count exit).
+struct SmallmProblem {
+    const f16*  A;
+    const void* W;
+    const f16*  scale;
+    const f16*  bias;
+    f16*        C;
+    float*      partial;  // [ks][m][n]
+    unsigned*   tickets;  // [bx]
+    int         act, n, k, ks, bx;
+};
+struct SmallmGroup {
+    SmallmProblem p[2];
+    int           np, m;
+};
+// (pointers that come out of the argument struct are global: the explicit address space keeps the accesses from
+// becoming FLAT, which would also count on lgkmcnt and serialise with the LDS waits)
+#define SMB_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
+
 template<bool INT8>
-__global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict__ A, const void* __restrict__ W,
-                                                           const f16* __restrict__ scale, const f16* __restrict__ bias,
-                                                           int act, f16* __restrict__ C, float* __restrict__ partial,
-                                                           unsigned* __restrict__ tickets, int m, int n, int k)
+__global__ __launch_bounds__(256) void k_gemm_smallm_burst(const SmallmGroup G)
 {
+    int bxl = blockIdx.x, pi = 0;
+    if (G.np > 1 && bxl >= G.p[0].bx) {
+        pi = 1;
+        bxl -= G.p[0].bx;
+    }
+    const SmallmProblem& P = G.p[pi];
+    if ((int)blockIdx.y >= P.ks) {
+        return;
+    }
+    const int      m = G.m, n = P.n, k = P.k, act = P.act;
+    const f16*     A = P.A;
+    const f16*     bias = P.bias;
+    f16*           C = P.C;
+    float*         partial = P.partial;
+    unsigned*      tickets = P.tickets;
     constexpr int TK   = INT8 ? TILE_K_I8 : TILE_K_F16;
     constexpr int KMAX = SMB_T * TK;  // k per slice
     __shared__ int s_last;
@@ -482,23 +515,23 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int NT = n / 16, KT = k / TK, ks = gridDim.y;
-    const int nt = blockIdx.x * 4 + wid;
+    const int NT = n / 16, KT = k / TK, ks = P.ks;
+    const int nt = bxl * 4 + wid;
     const bool active = nt < NT;
     const int t0 = (int)((long)KT * blockIdx.y / ks), t1 = (int)((long)KT * (blockIdx.y + 1) / ks);
     const int nts = t1 - t0;  // <= SMB_T
 
     f16x2 scale2 = {(f16)1.f, (f16)1.f};
     if constexpr (INT8) {
-        const f16 sc = scale[(active ? nt : 0) * 16 + c];
+        const f16 sc = *SMB_G(f16, P.scale + (active ? nt : 0) * 16 + c);
         scale2       = f16x2{sc, sc};
     }
-    const u32x4* wp = reinterpret_cast<const u32x4*>(W) + ((size_t)(active ? nt : 0) * KT + t0) * 64 + lane;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(P.W) + ((size_t)(active ? nt : 0) * KT + t0) * 64 + lane;
     u32x4        wr[SMB_T];
 #pragma unroll
     for (int u = 0; u < SMB_T; u++) {
         const int t = u < nts ? u : nts - 1;  // clamped, never conditional
-        wr[u]       = __builtin_nontemporal_load(wp + (size_t)t * 64);
+        wr[u]       = __builtin_nontemporal_load(SMB_G(u32x4, wp + (size_t)t * 64));
     }
     u32x4     xr[XP];
     const int ppr = nts * TK / 8;  // pieces per row of this slice
@@ -508,7 +541,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict
         int       row = pc / (KMAX / 8), p8 = pc % (KMAX / 8);
         row           = row < m ? row : m - 1;
         p8            = p8 < ppr ? p8 : ppr - 1;
-        xr[i]         = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)t0 * TK + p8 * 8);
+        xr[i]         = *SMB_G(u32x4, reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)t0 * TK + p8 * 8));
     }
 #pragma unroll
     for (int i = 0; i < XP; i++) {
@@ -544,10 +577,10 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned t = __hip_atomic_fetch_add(&tickets[bxl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last           = (t == (unsigned)ks - 1u);
             if (s_last) {
-                __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&tickets[bxl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -557,7 +590,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const f16* __restrict
         // 64 columns x m rows: 4 outputs per thread, RS slices of each requested together (an agent-scope load is a memory
         // round trip)
         constexpr int RS = 4;
-        const int     cc = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int     cc = bxl * 64 + (threadIdx.x & 63);
         float         v[4] = {0.f, 0.f, 0.f, 0.f};
         if (cc < n) {
             for (int s0 = 0; s0 < ks; s0 += RS) {
@@ -621,27 +654,58 @@ size_t gemm_smallm_ticket_bytes()
     return SMB_TICKETS * sizeof(unsigned);
 }
 
+// burst form of one or two GEMMs in one launch; `workspace` = [partial_bytes of partial sums][ticket table]
+void launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
+                              hipStream_t s)
+{
+    FTCF_CHECK_ARG(np >= 1 && np <= 2 && m >= 1 && m <= 16 && workspace != nullptr, "small-m GEMM group: bad arguments");
+    SmallmGroup G{};
+    G.np = np;
+    G.m  = m;
+    size_t    poff = 0;
+    int       toff = 0, ks_max = 1, bx_sum = 0;
+    unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + partial_bytes);
+    for (int i = 0; i < np; i++) {
+        FTCF_CHECK_ARG(d[i].k % GEMM_KSTEP == 0 && d[i].n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
+        SmallmProblem& P = G.p[i];
+        P.A = d[i].A;
+        P.W = d[i].W;
+        P.scale = d[i].scale;
+        P.bias = d[i].bias;
+        P.C = d[i].C;
+        P.act = d[i].act;
+        P.n = d[i].n;
+        P.k = d[i].k;
+        P.ks = smallm_burst_slices(d[i].k, int8);
+        P.bx = (d[i].n / 16 + 3) / 4;
+        P.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + poff);
+        P.tickets = tickets + toff;
+        poff += gemm_smallm_workspace_bytes(m, d[i].n, d[i].k, int8);
+        toff += P.bx;
+        bx_sum += P.bx;
+        ks_max = std::max(ks_max, P.ks);
+    }
+    FTCF_CHECK_ARG(poff <= partial_bytes && toff <= SMB_TICKETS, "small-m GEMM: split-K workspace too small");
+    dim3 grid(bx_sum, ks_max);
+    if (int8) {
+        hipLaunchKernelGGL((k_gemm_smallm_burst<true>), grid, dim3(256), 0, s, G);
+    }
+    else {
+        hipLaunchKernelGGL((k_gemm_smallm_burst<false>), grid, dim3(256), 0, s, G);
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
                         size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s)
 {
     FTCF_CHECK_ARG(m >= 1 && m <= 16, "small-m GEMM handles 1..16 rows");
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0 && n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
     const int NT = n / 16, bx = (NT + 3) / 4;
-    if (workspace != nullptr) {  // burst form; the ticket table sits behind `partial_bytes` of partial sums
-        const int ks = smallm_burst_slices(k, int8);
-        FTCF_CHECK_ARG(bx <= SMB_TICKETS && gemm_smallm_workspace_bytes(m, n, k, int8) <= partial_bytes,
-                       "small-m GEMM: split-K workspace too small");
-        unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + partial_bytes);
-        dim3      grid(bx, ks);
-        if (int8) {
-            hipLaunchKernelGGL((k_gemm_smallm_burst<true>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace,
-                               tickets, m, n, k);
-        }
-        else {
-            hipLaunchKernelGGL((k_gemm_smallm_burst<false>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, workspace,
-                               tickets, m, n, k);
-        }
-        FTCF_HIP_CHECK(hipGetLastError());
+    (void)num_cu;
+    if (workspace != nullptr) {
+        const SmallmDesc d{A, W, scale, bias, act, C, n, k};
+        launch_gemm_smallm_group(&d, 1, workspace, partial_bytes, m, int8, s);
         return;
     }
     // no workspace (kernel-level entry points): the chunked form over the whole K extent
