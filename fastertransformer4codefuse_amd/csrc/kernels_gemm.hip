@@ -721,27 +721,31 @@ void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16
 
 // logits_f32[m, n] = A[m,k] x W[n,k]^T for m > 4 (batched decode LM head).  W rows are k-contiguous, which is the
 // B-operand order of the MFMA directly: lane (col = lane&15, kgroup = lane>>4) reads 16 B of row n0+col.
+// Each wave takes TWO groups of 16 vocabulary rows: an A fragment (from L2) feeds two weight fragments (from HBM).
 __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ A, const f16* __restrict__ W,
                                                         float* __restrict__ C, int m, int n, int k, int ldc)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = (blockIdx.x * 4 + wid) * 16;
+    const int n0 = (blockIdx.x * 4 + wid) * 32;
     const int m0 = blockIdx.y * 16;
     if (n0 >= n) {
         return;
     }
-    const int  wrow = (n0 + c < n) ? n0 + c : n - 1;
-    const int  arow = (m0 + c < m) ? m0 + c : m - 1;
-    f32x4      acc  = {0.f, 0.f, 0.f, 0.f};
-    const f16* wp   = W + (size_t)wrow * k + g * 8;
-    const f16* ap   = A + (size_t)arow * k + g * 8;
+    const int  wrow0 = (n0 + c < n) ? n0 + c : n - 1;
+    const int  wrow1 = (n0 + 16 + c < n) ? n0 + 16 + c : n - 1;
+    const int  arow  = (m0 + c < m) ? m0 + c : m - 1;
+    f32x4      acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f16* wp0 = W + (size_t)wrow0 * k + g * 8;
+    const f16* wp1 = W + (size_t)wrow1 * k + g * 8;
+    const f16* ap  = A + (size_t)arow * k + g * 8;
     int k0 = 0;
-    for (; k0 + 256 <= k; k0 += 256) {  // 8 weight fragments (8 KiB per wave) in flight: the loop is HBM-latency bound
-        f16x8 b[8], a[8];
+    for (; k0 + 256 <= k; k0 += 256) {  // 16 weight fragments (16 KiB per wave) in flight: the loop is HBM-latency bound
+        f16x8 b0[8], b1[8], a[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            b[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp + k0 + u * 32));
+            b0[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp0 + k0 + u * 32));
+            b1[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp1 + k0 + u * 32));
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -749,19 +753,27 @@ __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ 
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u], acc, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b1[u], acc1, 0, 0, 0);
         }
     }
     for (; k0 < k; k0 += 32) {
-        const f16x8 b = *reinterpret_cast<const f16x8*>(wp + k0);
-        const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k0);
-        acc           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+        const f16x8 b0 = *reinterpret_cast<const f16x8*>(wp0 + k0);
+        const f16x8 b1 = *reinterpret_cast<const f16x8*>(wp1 + k0);
+        const f16x8 a  = *reinterpret_cast<const f16x8*>(ap + k0);
+        acc0           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc0, 0, 0, 0);
+        acc1           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int row = m0 + g * 4 + j;
-        if (row < m && n0 + c < n) {
-            C[(size_t)row * ldc + n0 + c] = acc[j];
+        if (row < m) {
+            if (n0 + c < n) {
+                C[(size_t)row * ldc + n0 + c] = acc0[j];
+            }
+            if (n0 + 16 + c < n) {
+                C[(size_t)row * ldc + n0 + 16 + c] = acc1[j];
+            }
         }
     }
 }
@@ -769,7 +781,7 @@ __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ 
 void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s)
 {
     FTCF_CHECK_ARG(k % 32 == 0, "k must be a multiple of 32");
-    dim3 grid((n + 63) / 64, (m + 15) / 16);
+    dim3 grid((n + 127) / 128, (m + 15) / 16);
     hipLaunchKernelGGL(k_gemm_nk_f32out, grid, dim3(256), 0, s, A, W_nk, C, m, n, k, ldc);
     FTCF_HIP_CHECK(hipGetLastError());
 }
