@@ -199,7 +199,46 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
 
     // ---- phase 1: qk for the cached keys (fp32 accumulate, MMHA_USE_FP32_ACUM_FOR_FMA) ----
     float lmax = -INFINITY;
-    constexpr int U = 8;  // rows per lane and round of the looped form (long key ranges): 8 KiB per wave in flight
+    // looped form (key ranges beyond the all-in-registers one): rounds of U rows per lane, two rounds in flight (the loads
+    // of round i + 1 are requested before round i is consumed; clamped, never conditional)
+    constexpr int U = 8;
+    auto stream_rows = [&](const f16* base, auto&& consume) {
+        constexpr int STEP = 4 * KPI * U;
+        int           t0   = t_beg + wid * KPI;
+        if (t0 >= t_cached_end) {
+            return;
+        }
+        u32x4 ra[U], rb[U];
+        auto  ld = [&](u32x4 (&r)[U], const int tt) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                int t = tt + u * 4 * KPI + grp;
+                t     = t < t_cached_end ? t : t_cached_end - 1;
+                r[u]  = *reinterpret_cast<const u32x4*>(row_of(base, t) + sub * 8);
+            }
+        };
+        ld(ra, t0);
+        for (;;) {
+            ld(rb, t0 + STEP);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                consume(ra[u], t0 + u * 4 * KPI + grp);
+            }
+            t0 += STEP;
+            if (t0 >= t_cached_end) {
+                break;
+            }
+            ld(ra, t0 + STEP);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                consume(rb[u], t0 + u * 4 * KPI + grp);
+            }
+            t0 += STEP;
+            if (t0 >= t_cached_end) {
+                break;
+            }
+        }
+    };
     auto qk_one = [&](const u32x4 raw, const int t, const int u_fast) {
         const f16x8 kv = __builtin_bit_cast(f16x8, raw);
         float       a  = 0.f;
@@ -223,19 +262,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         }
     }
     else {
-        for (int t0 = t_beg + wid * KPI; t0 < t_cached_end; t0 += 4 * KPI * U) {
-            u32x4 kr[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                int t = t0 + u * 4 * KPI + grp;
-                t     = t < t_cached_end ? t : t_cached_end - 1;
-                kr[u] = *reinterpret_cast<const u32x4*>(row_of(kc, t) + sub * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                qk_one(kr[u], t0 + u * 4 * KPI + grp, -1);
-            }
-        }
+        stream_rows(kc, [&](const u32x4 raw, const int t) { qk_one(raw, t, -1); });
     }
     if (owns_cur && wid == 0) {  // current token from LDS (:1407-1437)
         float a = 0.f;
@@ -294,19 +321,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         }
     }
     else {
-        for (int t0 = t_beg + wid * KPI; t0 < t_cached_end; t0 += 4 * KPI * U) {
-            u32x4 vr[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                int t = t0 + u * 4 * KPI + grp;
-                t     = t < t_cached_end ? t : t_cached_end - 1;
-                vr[u] = *reinterpret_cast<const u32x4*>(row_of(vc, t) + sub * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                pv_one(vr[u], t0 + u * 4 * KPI + grp);
-            }
-        }
+        stream_rows(vc, [&](const u32x4 raw, const int t) { pv_one(raw, t); });
     }
     if (owns_cur && wid == 0 && grp == 0) {
         const float pt = s_p[tl - t_beg];
@@ -331,6 +346,19 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         }
     }
     __syncthreads();
+    if (p.nsplit == 1) {
+        // a single split: nothing to merge -- normalise and write ctx here (the same arithmetic as the merger with one
+        // partial of weight exp(0) = 1) instead of publishing granules and polling them back (a memory round trip)
+        if (threadIdx.x < DH) {
+            const int   d   = threadIdx.x;
+            const float o   = (s_o[d] + s_o[DH + d]) + (s_o[2 * DH + d] + s_o[3 * DH + d]);
+            const float L   = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            const float w   = (m_loc == -INFINITY) ? 0.f : 1.f;
+            const float inv = 1.f / (w * L + 1.e-6f);  // :1632
+            p.ctx[(size_t)b * p.nh * DH + h * DH + d] = (f16)((w * o) * inv);
+        }
+        return false;
+    }
     if (threadIdx.x < DH) {
         const int d = threadIdx.x;
         st_granule(&gout[d], tag, (s_o[d] + s_o[DH + d]) + (s_o[2 * DH + d] + s_o[3 * DH + d]));
