@@ -525,7 +525,7 @@ struct ftcf_gptneox {
             // With tensor parallelism there is a collective between the layers: the persistent kernel would run one
             // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
             // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
-            if (persist && K == 1 && B <= 2 && (cfg.tensor_para_size == 1 || persist_per_layer)) {
+            if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (cfg.tensor_para_size == 1 || persist_per_layer)) {
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
             }
             if (pplan.ok) {
@@ -611,6 +611,18 @@ struct ftcf_gptneox {
             launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B,
                                      S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream);
             gemm(pctx, w.attn_out, nullptr, 0, patt, M, H, hl);
+            if (!cfg.use_gptj_residual) {
+                // sequential residual (GptNeoXContextDecoder.cc:401-418,463-470): the TensorParallel layers reduce their
+                // own outputs; h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h
+                allreduce(patt, (size_t)M * H);
+                launch_add_bias_residual(patt, px, patt, w.attn_out.bias, M, H, stream);
+                launch_layernorm(patt, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
+                gemm(pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
+                gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
+                allreduce(pffn, (size_t)M * H);
+                launch_add_bias_residual(px, pffn, patt, w.ffn2.bias, M, H, stream);
+                continue;
+            }
             launch_layernorm(px, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
             gemm(pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
             gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
@@ -660,7 +672,8 @@ struct ftcf_gptneox {
     void decoder(int B, int s_max)
     {
         const double wbytes  = int8 ? 1.0 : 2.0;
-        const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1;  // beam search reads K/V through the cache indirection
+        // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
+        const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual;
         stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
@@ -709,6 +722,21 @@ struct ftcf_gptneox {
                     mp.beam_width    = ses.K;
                     mp.max_input_len = ses.S;
                     mp.indir_plane   = (size_t)B * s_max;
+                }
+                if (!cfg.use_gptj_residual) {
+                    // sequential residual (GptNeoXDecoder.cc:313-331,362-367): h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h
+                    launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
+                    gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
+                    launch_mmha(mp, stream);
+                    gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
+                    allreduce(att, (size_t)B * H);
+                    launch_add_bias_residual(att, x, att, w.attn_out.bias, B, H, stream);
+                    launch_layernorm(att, w.ln2_g, w.ln2_b, nrm, B, H, 1e-5f, true, stream);
+                    gemm(nrm, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
+                    gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                    allreduce(ffn, (size_t)B * H);
+                    launch_add_bias_residual(x, ffn, att, w.ffn2.bias, B, H, stream);
+                    continue;
                 }
                 const bool dual = residual_dual_ln_supported(H);
                 const bool tp1  = cfg.tensor_para_size == 1;
@@ -1344,9 +1372,6 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (cfg->dtype != FTCF_FP16) {
             throw Error(FTCF_ERR_UNSUPPORTED, "the GPU engine runs fp16 weights/activations only");
         }
-        if (!cfg->use_gptj_residual) {
-            throw Error(FTCF_ERR_UNSUPPORTED, "use_gptj_residual == 0 (sequential residual) is not implemented");
-        }
         FTCF_CHECK_ARG(cfg->int8_mode == 0 || cfg->int8_mode == 1, "int8_mode must be 0 or 1");
         const int tp = cfg->tensor_para_size;
         FTCF_CHECK_ARG(tp >= 1 && cfg->head_num % tp == 0 && cfg->inter_size % tp == 0 && cfg->vocab_size % tp == 0,
@@ -1390,6 +1415,8 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
             lw.ln2_g = (const f16*)W(11, l);
             FTCF_CHECK_ARG(lw.ln1_b && lw.ln1_g && lw.ln2_b && lw.ln2_g && lw.qkv.bias && lw.ffn1.bias && lw.ffn2.bias,
                            "missing layernorm / bias tensor");
+            FTCF_CHECK_ARG(cfg->use_gptj_residual || lw.attn_out.bias,
+                           "use_gptj_residual == 0 needs the attention output bias (weights[5*L + l])");
             if (e->int8) {
                 lw.qkv.kernel = w->int8_weights[0 * L + l];
                 lw.attn_out.kernel = w->int8_weights[1 * L + l];

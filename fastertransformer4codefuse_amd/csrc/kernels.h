@@ -101,6 +101,8 @@ bool residual_dual_ln_supported(int n);
 void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16* bias, int tp, int inplace_variant,
                              const f16* g1, const f16* b1, const f16* g2, const f16* b2, f16* out1, f16* out2, int m,
                              int n, float eps, hipStream_t s);
+// out = (bias + a) + b in fp32, rounded once (sequential-residual layers)
+void launch_add_bias_residual(f16* out, const f16* a, const f16* b, const f16* bias, int m, int n, hipStream_t s);
 void launch_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* attn, const void* in, const void* bias,
                                        int m, int n, int tp, int inplace_variant, bool fp16, hipStream_t s);
 void launch_embedding(f16* out, const f16* table, const int* ids, int n_ids, int H, hipStream_t s);

@@ -250,6 +250,28 @@ void launch_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* a
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
+// sequential-residual layers (use_gptj_residual == 0): out = a + b + bias in fp32, rounded once -- the element-wise part of
+// invokeGeneralAddBiasResidualPreLayerNorm (layernorm_kernels.cu:158-260, the LayerNorm follows as its own launch) and
+// invokeAddBiasResidual (add_residual_kernels.cu:22-60) as GptNeoXDecoder.cc:313-331,362-367 use them
+__global__ void k_add_bias_residual(f16* out, const f16* a, const f16* b, const f16* bias, size_t total, int n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float bv = bias ? (float)bias[i % n] : 0.f;
+        out[i]         = (f16)((bv + (float)a[i]) + (float)b[i]);
+    }
+}
+
+void launch_add_bias_residual(f16* out, const f16* a, const f16* b, const f16* bias, int m, int n, hipStream_t s)
+{
+    const size_t total = (size_t)m * n;
+    if (total == 0) {
+        return;
+    }
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_add_bias_residual, dim3(grid), dim3(256), 0, s, out, a, b, bias, total, n);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 // kernels/gpt_kernels.cu:31-104 start_id_embedding_position_lookups_kernel (no position table for NeoX)
 __global__ void k_prompt_embedding(f16* out, int* output_ids, const f16* table, const int* ids, int B, int S, int H)
 {

@@ -13,6 +13,8 @@ input/output vectors that pin the oracle (oracle/) and the host-side counterpart
                             whose rows were run through HF one by one, un-padded).
   tiny_gptneox_beam.npz   HF beam search (num_beams = K, no EOS, length_penalty 0) on the same model: prompts, the K returned
                           continuations (best first) and their cumulative log-probs, for three (B, K, out_len) cases.
+  tiny_gptneox_seq.npz    the same parameters with use_parallel_residual=False (FT use_gptj_residual = 0): the separate
+                          attention / FFN output biases and HF's greedy logits + tokens on `prompt`.
   tiny_gptneox_tp2.json   sha256 of every tensor the reference loader returns for tensor_para_size=2, rank 0 and 1.
   harness_io.json         I/O of to_word_list_format / Trie.printAutoSuggestions / is_garbage /
                           token_stream_2_str_stream_convertor / get_data_package captured from the reference.
@@ -38,9 +40,9 @@ CFG = dict(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermed
            max_position_embeddings=64, tie_word_embeddings=False, bos_token_id=0, eos_token_id=2, attention_bias=True)
 
 
-def build_hf():
+def build_hf(**overrides):
     from transformers import GPTNeoXConfig, GPTNeoXForCausalLM
-    cfg = GPTNeoXConfig(**CFG)
+    cfg = GPTNeoXConfig(**dict(CFG, **overrides))
     torch.manual_seed(1234)
     m = GPTNeoXForCausalLM(cfg).eval()
     g = torch.Generator().manual_seed(4321)
@@ -134,6 +136,21 @@ def beam_golden(m, cfg):
     np.savez_compressed(os.path.join(OUT, "tiny_gptneox_beam.npz"), **res)
 
 
+def sequential_golden(prompt):
+    """The same parameters with use_parallel_residual=False (FT: use_gptj_residual = 0): the two biases the parallel form
+    only stores as a sum, and HF's greedy logits / tokens."""
+    cfg, m = build_hf(use_parallel_residual=False)
+    L = cfg.num_hidden_layers
+    sd = dict(m.named_parameters())
+    out_b = np.stack([sd[f"gpt_neox.layers.{l}.attention.dense.bias"].detach().numpy() for l in range(L)])
+    ffn2_b = np.stack([sd[f"gpt_neox.layers.{l}.mlp.dense_4h_to_h.bias"].detach().numpy() for l in range(L)])
+    logits, toks = hf_greedy(m, prompt, 8)
+    np.savez_compressed(os.path.join(OUT, "tiny_gptneox_seq.npz"), out_b=out_b.astype(np.float16),
+                        ffn2_b=ffn2_b.astype(np.float16), hf_logits=logits.astype(np.float32),
+                        hf_tokens=np.array(toks, np.int32))
+    print("sequential", toks)
+
+
 class FakeTok:
     """Deterministic stand-in tokenizer (the reference helpers only call encode/decode/get_vocab)."""
 
@@ -208,9 +225,14 @@ def main():
     beam_golden(m, cfg)
     if "--beam-only" in sys.argv:
         return
+    if "--seq-only" in sys.argv:
+        rng0 = np.random.RandomState(42)
+        sequential_golden(rng0.randint(3, cfg.vocab_size, size=16).tolist())
+        return
     rng = np.random.RandomState(42)
     prompt = rng.randint(3, cfg.vocab_size, size=16).tolist()
     logits, toks = hf_greedy(m, prompt, 8)
+    sequential_golden(prompt)
     # ragged batch: rows of length 16 and 11, each run through HF separately (no padding semantics involved)
     prompt_b = rng.randint(3, cfg.vocab_size, size=11).tolist()
     logits_b, toks_b = hf_greedy(m, prompt_b, 8)

@@ -12,7 +12,7 @@ def dev(a, dtype=torch.float16):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None):
+def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True):
     """cfg: dict like tests.helpers ; w: reference-order list of float32 numpy arrays (full, TP=1 layout)."""
     L = cfg["num_layer"]
     H = cfg["head_num"] * cfg["size_per_head"]
@@ -37,7 +37,7 @@ def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None):
     if not int8_mode:
         int8_w, scales = [], []
     op = GptNeoXOp(comm, rank, cfg["head_num"], cfg["size_per_head"], I, L, V, cfg["rotary_dim"], cfg.get("start_id", 0),
-                   cfg["end_id"], tp, 1, int8_mode, 1024, True, weights, int8_w, scales)
+                   cfg["end_id"], tp, 1, int8_mode, 1024, use_gptj_residual, weights, int8_w, scales)
     return op
 
 

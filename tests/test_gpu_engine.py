@@ -217,3 +217,31 @@ def test_long_sequences_leave_the_single_pass_attention_forms(gh, tiny):
             assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
             break
     assert r["sequence_lengths"].tolist() == o["sequence_lengths"].tolist()
+
+
+@pytest.mark.parametrize("int8_mode", [0, 1])
+def test_sequential_residual_layers_follow_hf_and_oracle(gh, tiny, int8_mode):
+    """use_gptj_residual = 0: h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h (GptNeoXDecoder.cc:313-331,362-367); the
+    engine runs these layers on its general path.  Pinned by HF's use_parallel_residual=False model."""
+    from tests.test_oracle_golden import _sequential_weights
+    cfg, w, _, _, z = tiny
+    w2, s = _sequential_weights(cfg, w)
+    layers, glob = weight_list_to_layers(cfg, w2)
+    if int8_mode:
+        layers = quantize_layers(layers)
+    op = gh.make_op(cfg, w2, int8_mode=int8_mode, use_gptj_residual=False)
+    B = 2
+    ids = np.stack([z["prompt"], z["prompt"][::-1]]).astype(np.int32)
+    r = gh.run_op(op, ids, [16, 16], 8, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 2
+    o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode, use_gptj_residual=0), layers, glob).generate(
+        ids, [16, 16], 8, return_logits=True)
+    for b in range(B):
+        for t in range(8):
+            _logit_close(r["logits"][t, b], o["logits"][t, b])
+            if r["output_ids"][b, 16 + t] != o["output_ids"][b, 16 + t]:
+                top2 = np.sort(o["logits"][t, b])[-2:]
+                assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
+                break
+    if not int8_mode:
+        assert r["output_ids"][0, 16:].tolist() == s["hf_tokens"].tolist()

@@ -89,3 +89,27 @@ def test_end_id_finishes_row_and_fills(tiny):
     assert out[19:].tolist() == [c["end_id"]] * 5
     assert r["steps"] == 3
     assert r["sequence_lengths"].tolist() == [19]
+
+
+def _sequential_weights(cfg, w):
+    """Weight list of the use_gptj_residual = 0 form of the tiny model: attention / FFN output biases kept apart."""
+    import os
+    from tests.helpers import GOLDEN
+    s = np.load(os.path.join(GOLDEN, "tiny_gptneox_seq.npz"))
+    L = cfg["num_layer"]
+    w2 = list(w)
+    for l in range(L):
+        w2[5 * L + l] = s["out_b"][l].astype(np.float32)
+        w2[9 * L + l] = s["ffn2_b"][l].astype(np.float32)
+    return w2, s
+
+
+def test_fp32_sequential_residual_matches_hf():
+    cfg, w, z = load_tiny()
+    w2, s = _sequential_weights(cfg, w)
+    layers, glob = weight_list_to_layers(cfg, w2)
+    m = orc.Model(dict(cfg, fp16=0, use_gptj_residual=0), layers, glob)
+    prompt = z["prompt"][None, :]
+    r = m.generate(prompt, [16], 8, return_logits=True)
+    assert r["output_ids"][0, 16:].tolist() == s["hf_tokens"].tolist()
+    np.testing.assert_allclose(r["logits"][:, 0, :], s["hf_logits"], atol=2e-4, rtol=1e-4)
