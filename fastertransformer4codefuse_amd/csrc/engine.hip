@@ -570,7 +570,7 @@ struct ftcf_gptneox {
                 d_lenpen    = c.take<float>(B);
             }
             if (S > 1) {
-                const size_t M = (size_t)B * S;
+                const size_t M = (size_t)(B / K) * S;  // beam search prefills one row per request
                 px             = c.take<f16>(M * H);
                 pnrm           = c.take<f16>(M * H);
                 pqkv           = c.take<f16>(M * 3 * hl);
@@ -600,16 +600,17 @@ struct ftcf_gptneox {
     }
 
     // GptNeoXContextDecoder::forward (GptNeoXContextDecoder.cc:283-507), parallel residual only
-    void context_decoder(int B, int S, const int* input_lengths, int s_max)
+    // B prompt rows; their K/V go to cache rows b * tile of a cache with B * tile rows (beam search: tile = beam_width)
+    void context_decoder(int B, int S, const int* input_lengths, int s_max, int tile)
     {
         const int    M       = B * S;
-        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;
         for (int l = 0; l < L; l++) {
             const LayerWeights& w = layers[l];
             launch_layernorm(px, w.ln1_g, w.ln1_b, pnrm, M, H, 1e-5f, true, stream);
             gemm(pnrm, w.qkv, nullptr, 0, pqkv, M, 3 * hl, H);
             launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B,
-                                     S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream);
+                                     S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream, tile);
             gemm(pctx, w.attn_out, nullptr, 0, patt, M, H, hl);
             if (!cfg.use_gptj_residual) {
                 // sequential residual (GptNeoXContextDecoder.cc:401-418,463-470): the TensorParallel layers reduce their
@@ -1068,7 +1069,9 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
         FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // `pl` dies at scope exit
     }
-    // beam search: inputs tiled K times, the context phase runs on all batch * K rows (GptNeoX.cc:560-574, 640-735)
+    // beam search: the reference tiles the inputs K times and runs the context phase on all batch * K rows
+    // (GptNeoX.cc:560-574, 640-735).  Every beam reads the prompt K/V of beam 0 anyway (the cache indirection starts at 0),
+    // so the prompt is prefilled once per request into cache row b * K and its last hidden state is tiled.
     const int* in_ids = a.input_ids;
     const int* in_len = a.input_lengths;
     if (K > 1) {
@@ -1079,9 +1082,15 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         in_len = tiled_len;
     }
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, in_len, state, B, S, s_max, stream, K);
-    if (S > 1) {
+    if (S > 1 && K > 1) {
+        launch_prompt_embedding(px, nullptr, wte, a.input_ids, batch, S, H, stream);
+        launch_tile_prompt_ids(step_ids, a.input_ids, batch, K, S, stream);
+        context_decoder(batch, S, a.input_lengths, s_max, K);
+        launch_gather_last_token(x, px, a.input_lengths, batch, S, H, stream, K);
+    }
+    else if (S > 1) {
         launch_prompt_embedding(px, step_ids, wte, in_ids, B, S, H, stream);
-        context_decoder(B, S, in_len, s_max);
+        context_decoder(B, S, in_len, s_max, 1);
         launch_gather_last_token(x, px, in_len, B, S, H, stream);
     }
     else {

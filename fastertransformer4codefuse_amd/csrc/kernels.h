@@ -112,8 +112,11 @@ void launch_prompt_embedding(f16* out, int* output_ids, const f16* table, const 
 // decode step: embedding of output_ids[(step-1)*B + b] where step is read from device state (decoding_kernels.cu:145-191)
 void launch_step_embedding(f16* out, const f16* table, const int* output_ids, const int* d_step, int B, int H,
                            hipStream_t s);
+// out[r] = hidden[r / tile][input_lengths[r / tile] - 1] for r < B * tile (beam search: every beam starts from beam 0's state)
 void launch_gather_last_token(f16* out, const f16* hidden, const int* input_lengths, int B, int S, int H,
-                              hipStream_t s);
+                              hipStream_t s, int tile = 1);
+// output_ids[s][b * K + k] = ids[b][s] (time-major ids of the tiled prompt)
+void launch_tile_prompt_ids(int* output_ids, const int* ids, int B, int K, int S, hipStream_t s);
 void launch_fp16_rowmajor_to_tiled(const f16* w, size_t K, size_t N, f16* out, hipStream_t s);
 
 // ---- attention : kernels_attn.hip ----
@@ -146,7 +149,7 @@ void   launch_mmha(const MmhaParams& p, hipStream_t s);
 void   launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
-                                hipStream_t s);
+                                hipStream_t s, int cache_row_mult = 1);  // K/V of prompt row b live in cache row b * mult
 
 // ---- fused attention + FFN1 weight stream : kernels_fused.hip ----
 void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8, int M, hipStream_t s);

@@ -100,7 +100,7 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
 // grid (B*S, nh), block dh.  q is rotated in place inside the qkv buffer; k/v go to the caches (zeros for padding
 // rows, as the reference's memset + un-padded scatter leaves them, GptContextAttentionLayer.cc:152-172).
 __global__ void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bias, const int* __restrict__ input_lengths,
-                                        f16* k_cache, f16* v_cache, int S, int nh, int dh, int rot, int s_max)
+                                        f16* k_cache, f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f16*      sq = reinterpret_cast<f16*>(smem);
@@ -131,7 +131,7 @@ __global__ void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bi
     }
     __syncthreads();
     base[0] = sq[d];
-    const size_t cidx = (((size_t)b * nh + h) * s_max + s) * dh + d;
+    const size_t cidx = (((size_t)b * crm * nh + h) * s_max + s) * dh + d;  // cache row b * crm (beam search: beam 0)
     k_cache[cidx]     = sk[d];
     v_cache[cidx]     = v;
 }
@@ -142,7 +142,8 @@ __global__ void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bi
 template<int DH>
 __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict__ qkv, const int* __restrict__ input_lengths,
                                                            const f16* __restrict__ k_cache, const f16* __restrict__ v_cache,
-                                                           int S, int nh, int s_max, f16* __restrict__ ctx, float qk_scale)
+                                                           int S, int nh, int s_max, f16* __restrict__ ctx, float qk_scale,
+                                                           int crm)
 {
     constexpr int KT  = 64;       // keys per tile
     constexpr int LDK = DH + 8;   // padded LDS row (halves)
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict
         *reinterpret_cast<f16x8*>(&sQ[r * DH + ch * 8]) =
             *reinterpret_cast<const f16x8*>(qkv + ((size_t)b * S + qi) * 3 * hl + h * DH + ch * 8);
     }
-    const f16* kc = k_cache + ((size_t)b * nh + h) * s_max * DH;
-    const f16* vc = v_cache + ((size_t)b * nh + h) * s_max * DH;
+    const f16* kc = k_cache + ((size_t)b * crm * nh + h) * s_max * DH;
+    const f16* vc = v_cache + ((size_t)b * crm * nh + h) * s_max * DH;
 
     float m_run[4], l_run[4], o[4][DPL];
 #pragma unroll
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
                                                                 const int* __restrict__ input_lengths,
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
-                                                                f16* __restrict__ ctx, float qk_scale)
+                                                                f16* __restrict__ ctx, float qk_scale, int crm)
 {
     constexpr int KT  = 64;        // keys per tile
     constexpr int LDK = DH + 8;    // sK row (halves): rows start in different banks
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
             qf[s2] = *reinterpret_cast<const f16x8*>(qp + s2 * 32);
         }
     }
-    const f16* kc = k_cache + ((size_t)b * nh + h) * s_max * DH;
-    const f16* vc = v_cache + ((size_t)b * nh + h) * s_max * DH;
+    const f16* kc = k_cache + ((size_t)b * crm * nh + h) * s_max * DH;
+    const f16* vc = v_cache + ((size_t)b * crm * nh + h) * s_max * DH;
     f32x4      o[NO];
     float      m_run[4], l_run[4];
 #pragma unroll
@@ -412,12 +413,13 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
 }
 
 void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
-                              f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx, hipStream_t s)
+                              f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx, hipStream_t s,
+                              int cache_row_mult)
 {
     FTCF_CHECK_ARG(dh == 64 || dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(S <= s_max, "prompt longer than the cache");
     hipLaunchKernelGGL(k_qkv_bias_rotary_cache, dim3(B * S, nh), dim3(dh), (size_t)2 * dh * 2, s, const_cast<f16*>(qkv),
-                       qkv_bias, input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max);
+                       qkv_bias, input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
     static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
@@ -425,22 +427,22 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
         dim3 grid((S + 15) / 16, nh, B);
         if (dh == 128) {
             hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                               s_max, ctx, qk_scale);
+                               s_max, ctx, qk_scale, cache_row_mult);
         }
         else {
             hipLaunchKernelGGL(k_context_attention<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                               s_max, ctx, qk_scale);
+                               s_max, ctx, qk_scale, cache_row_mult);
         }
     }
     else {
         dim3 grid((S + 63) / 64, nh, B);
         if (dh == 128) {
             hipLaunchKernelGGL(k_context_attention_mfma<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale);
+                               nh, s_max, ctx, qk_scale, cache_row_mult);
         }
         else {
             hipLaunchKernelGGL(k_context_attention_mfma<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale);
+                               nh, s_max, ctx, qk_scale, cache_row_mult);
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());

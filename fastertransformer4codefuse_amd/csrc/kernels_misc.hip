@@ -278,7 +278,7 @@ __global__ void k_prompt_embedding(f16* out, int* output_ids, const f16* table, 
     const int row = blockIdx.x;  // b*S + s
     const int b = row / S, s = row % S;
     const int id = ids[row];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && output_ids) {
         output_ids[(size_t)s * B + b] = id;
     }
     const f16* src = table + (size_t)id * H;
@@ -332,19 +332,36 @@ void launch_embedding(f16* out, const f16* table, const int* ids, int n_ids, int
 }
 
 // kernels/gpt_kernels.cu:438-470 lookupHiddenStateOfLastToken
-__global__ void k_gather_last_token(f16* out, const f16* hidden, const int* input_lengths, int S, int H)
+__global__ void k_gather_last_token(f16* out, const f16* hidden, const int* input_lengths, int S, int H, int tile)
 {
-    const int  b   = blockIdx.x;
+    const int  b   = blockIdx.x / tile;
     const f16* src = hidden + ((size_t)b * S + (input_lengths[b] - 1)) * H;
-    f16*       dst = out + (size_t)b * H;
+    f16*       dst = out + (size_t)blockIdx.x * H;
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
         *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
     }
 }
 void launch_gather_last_token(f16* out, const f16* hidden, const int* input_lengths, int B, int S, int H,
-                              hipStream_t s)
+                              hipStream_t s, int tile)
 {
-    hipLaunchKernelGGL(k_gather_last_token, dim3(B), dim3(256), 0, s, out, hidden, input_lengths, S, H);
+    hipLaunchKernelGGL(k_gather_last_token, dim3(B * tile), dim3(256), 0, s, out, hidden, input_lengths, S, H, tile);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+__global__ void k_tile_prompt_ids(int* output_ids, const int* ids, int B, int K, int S)
+{
+    const size_t total = (size_t)S * B * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int    bb = (int)(i % ((size_t)B * K));
+        const size_t s2 = i / ((size_t)B * K);
+        output_ids[i]   = ids[(size_t)(bb / K) * S + s2];
+    }
+}
+void launch_tile_prompt_ids(int* output_ids, const int* ids, int B, int K, int S, hipStream_t s)
+{
+    const size_t total = (size_t)S * B * K;
+    hipLaunchKernelGGL(k_tile_prompt_ids, dim3((int)std::min<size_t>((total + 255) / 256, 1024)), dim3(256), 0, s,
+                       output_ids, ids, B, K, S);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
