@@ -118,10 +118,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
         }
     }
 
-    // weight tiles: three k-steps in flight per wave (the first reader of a tile misses to HBM: ~900+ cycles, more than
-    // one k-step lasts); requests are clamped, never conditional
+    // weight tiles: two k-steps in flight per wave (the first reader of a tile misses to HBM: ~900+ cycles, more than one
+    // k-step lasts) -- a third one costs the fourth wave per SIMD (134 vs 124 VGPRs), measured slower; requests are clamped,
+    // never conditional
     typedef u32x4 BTile[NG][2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
-    BTile         B0, B1, B2;
+    BTile         B0, B1;
     auto load_b = [&](BTile& br, int ks) {
         ks = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
@@ -176,21 +177,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
     load_a(0);
     load_b(B0, 0);
     load_b(B1, 1);
-    load_b(B2, 2);
     store_a(0);
     load_a(1 < ksteps ? 1 : 0);
     __syncthreads();
-    for (int ks = 0; ks < ksteps; ks += 3) {
+    for (int ks = 0; ks < ksteps; ks += 2) {
         step(B0, ks);
-        load_b(B0, ks + 3);
+        load_b(B0, ks + 2);
         if (ks + 1 < ksteps) {
             step(B1, ks + 1);
         }
-        load_b(B1, ks + 4);
-        if (ks + 2 < ksteps) {
-            step(B2, ks + 2);
-        }
-        load_b(B2, ks + 5);
+        load_b(B1, ks + 3);
     }
     // C/D layout of mfma 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
