@@ -392,7 +392,7 @@ struct ftcf_gptneox {
     // decode / state views (valid after plan())
     f16 *x = nullptr, *nrm = nullptr, *nrm2 = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
     f16 *k_cache = nullptr, *v_cache = nullptr;
-    f16 *px = nullptr, *pnrm = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
+    f16 *px = nullptr, *pnrm = nullptr, *pnrm2 = nullptr, *pqkv = nullptr, *pctx = nullptr, *patt = nullptr, *pmid = nullptr,
         *pffn = nullptr;
     float *      logits = nullptr, *gather = nullptr, *mmha_ws = nullptr, *rot_table = nullptr;
     unsigned long long* chunk_ws = nullptr;
@@ -573,6 +573,7 @@ struct ftcf_gptneox {
                 const size_t M = (size_t)(B / K) * S;  // beam search prefills one row per request
                 px             = c.take<f16>(M * H);
                 pnrm           = c.take<f16>(M * H);
+                pnrm2          = c.take<f16>(M * H);
                 pqkv           = c.take<f16>(M * 3 * hl);
                 pctx           = c.take<f16>(M * hl);
                 patt           = c.take<f16>(M * H);
@@ -605,9 +606,19 @@ struct ftcf_gptneox {
     {
         const int    M       = B * S;
         const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;
+        // parallel-residual layers: both LayerNorms in one pass, fused with the previous layer's residual when no collective
+        // sits in between (as in the batched decode path)
+        const bool dual = cfg.use_gptj_residual && residual_dual_ln_supported(H);
+        const bool tp1  = cfg.tensor_para_size == 1;
         for (int l = 0; l < L; l++) {
             const LayerWeights& w = layers[l];
-            launch_layernorm(px, w.ln1_g, w.ln1_b, pnrm, M, H, 1e-5f, true, stream);
+            if (!dual) {
+                launch_layernorm(px, w.ln1_g, w.ln1_b, pnrm, M, H, 1e-5f, true, stream);
+            }
+            else if (l == 0 || !tp1) {
+                launch_residual_dual_ln(px, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm, pnrm2,
+                                        M, H, 1e-5f, stream);
+            }
             gemm(pnrm, w.qkv, nullptr, 0, pqkv, M, 3 * hl, H);
             launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B,
                                      S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream, tile);
@@ -624,12 +635,21 @@ struct ftcf_gptneox {
                 launch_add_bias_residual(px, pffn, patt, w.ffn2.bias, M, H, stream);
                 continue;
             }
-            launch_layernorm(px, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
-            gemm(pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
+            if (!dual) {
+                launch_layernorm(px, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
+            }
+            gemm(dual ? pnrm2 : pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
             gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
             // layer_input == layer_output for every layer with padding removal -> fp32-sum variant (:311-322,:445-461)
-            launch_add_bias_attn_ffn_residual(px, pffn, patt, px, w.ffn2.bias, M, H, cfg.tensor_para_size, 1, true,
-                                              stream);
+            if (dual && tp1) {
+                const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
+                launch_residual_dual_ln(px, pffn, patt, w.ffn2.bias, 1, 1, nx ? nx->ln1_g : nullptr, nx ? nx->ln1_b : nullptr,
+                                        nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, pnrm, pnrm2, M, H, 1e-5f, stream);
+            }
+            else {
+                launch_add_bias_attn_ffn_residual(px, pffn, patt, px, w.ffn2.bias, M, H, cfg.tensor_para_size, 1, true,
+                                                  stream);
+            }
             allreduce(px, (size_t)M * H);
         }
     }

@@ -97,48 +97,59 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
 // ---------------------------------------------------------------------------------------------------------------
 // prefill
 // ---------------------------------------------------------------------------------------------------------------
-// grid (B*S, nh), block dh.  q is rotated in place inside the qkv buffer; k/v go to the caches (zeros for padding
-// rows, as the reference's memset + un-padded scatter leaves them, GptContextAttentionLayer.cc:152-172).
-__global__ void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bias, const int* __restrict__ input_lengths,
-                                        f16* k_cache, f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm)
+// grid B*S, block 256: one workgroup per prompt token, all heads.  q is rotated in place inside the qkv buffer; k/v go to
+// the caches (zeros for padding rows, as the reference's memset + un-padded scatter leaves them,
+// GptContextAttentionLayer.cc:152-172).  The {cos, sin} of the token's position are computed once per workgroup; a thread
+// owns element d of a head and, inside the rotary range, its partner d + rot/2.  (The first form launched one 128-thread
+// workgroup per (token, head): 41k tiny workgroups per layer, 29 us.)
+__global__ __launch_bounds__(256) void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bias,
+                                                               const int* __restrict__ input_lengths, f16* k_cache,
+                                                               f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16*      sq = reinterpret_cast<f16*>(smem);
-    f16*      sk = sq + dh;
-    const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
-    const int b = row / S, s = row % S;
-    const int hl = nh * dh;
+    __shared__ float s_cs[128], s_sn[128];
+    const int  row = blockIdx.x;
+    const int  b = row / S, s = row % S;
+    const int  hl = nh * dh, half = rot / 2;
     const bool valid = s < input_lengths[b];
-    f16*   base = qkv + (size_t)row * 3 * hl + h * dh + d;
-    f16    q = (f16)0.f, k = (f16)0.f, v = (f16)0.f;
-    if (valid) {
-        q = base[0] + qkv_bias[h * dh + d];
-        k = base[hl] + qkv_bias[hl + h * dh + d];
-        v = base[2 * hl] + qkv_bias[2 * hl + h * dh + d];
-    }
-    sq[d] = q;
-    sk[d] = k;
-    __syncthreads();
-    if (valid && d < rot / 2) {
-        f16 a = sq[d], c = sq[d + rot / 2];
-        rotary_pair(a, c, d, rot, s);  // position = index in the (right padded) row
-        sq[d]           = a;
-        sq[d + rot / 2] = c;
-        f16 ka = sk[d], kc2 = sk[d + rot / 2];
-        rotary_pair(ka, kc2, d, rot, s);
-        sk[d]           = ka;
-        sk[d + rot / 2] = kc2;
+    if ((int)threadIdx.x < half) {
+        float cs, sn;
+        rotary_coef(threadIdx.x, rot, s, cs, sn);  // position = index in the (right padded) row
+        s_cs[threadIdx.x] = cs;
+        s_sn[threadIdx.x] = sn;
     }
     __syncthreads();
-    base[0] = sq[d];
-    const size_t cidx = (((size_t)b * crm * nh + h) * s_max + s) * dh + d;  // cache row b * crm (beam search: beam 0)
-    k_cache[cidx]     = sk[d];
-    v_cache[cidx]     = v;
+    f16* base = qkv + (size_t)row * 3 * hl;
+    for (int i = threadIdx.x; i < hl; i += blockDim.x) {
+        const int h = i / dh, d = i % dh;
+        if (d >= half && d < rot) {
+            continue;  // written by the thread that owns d - rot/2
+        }
+        const size_t cidx = (((size_t)b * crm * nh + h) * s_max + s) * dh + d;  // cache row b * crm (beam search: beam 0)
+        f16          q = (f16)0.f, k = (f16)0.f, v = (f16)0.f;
+        if (valid) {
+            q = base[i] + qkv_bias[i];
+            k = base[hl + i] + qkv_bias[hl + i];
+            v = base[2 * hl + i] + qkv_bias[2 * hl + i];
+        }
+        if (d < half) {
+            f16 q2 = (f16)0.f, k2 = (f16)0.f, v2 = (f16)0.f;
+            if (valid) {
+                q2 = base[i + half] + qkv_bias[i + half];
+                k2 = base[hl + i + half] + qkv_bias[hl + i + half];
+                v2 = base[2 * hl + i + half] + qkv_bias[2 * hl + i + half];
+                rotary_apply(q, q2, s_cs[d], s_sn[d]);
+                rotary_apply(k, k2, s_cs[d], s_sn[d]);
+            }
+            base[i + half]       = q2;
+            k_cache[cidx + half] = k2;
+            v_cache[cidx + half] = v2;
+        }
+        base[i]       = q;
+        k_cache[cidx] = k;
+        v_cache[cidx] = v;
+    }
 }
 
-// Causal attention with online softmax.  grid (ceil(S/16), nh, B), 256 threads: each wave owns 4 query rows,
-// K/V tiles of 64 keys are staged in LDS and shared by the 16 rows of the block.
-// QK: lane = key (no cross-lane reduction); PV: lane = 2 output dims (DH=128) / 1 dim (DH=64).
 template<int DH>
 __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict__ qkv, const int* __restrict__ input_lengths,
                                                            const f16* __restrict__ k_cache, const f16* __restrict__ v_cache,
@@ -418,8 +429,9 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
 {
     FTCF_CHECK_ARG(dh == 64 || dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(S <= s_max, "prompt longer than the cache");
-    hipLaunchKernelGGL(k_qkv_bias_rotary_cache, dim3(B * S, nh), dim3(dh), (size_t)2 * dh * 2, s, const_cast<f16*>(qkv),
-                       qkv_bias, input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+    FTCF_CHECK_ARG(rot <= 256, "rotary_embedding_dim must be <= 256");
+    hipLaunchKernelGGL(k_qkv_bias_rotary_cache, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias, input_lengths,
+                       k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
     static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
