@@ -102,6 +102,7 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
 // GptContextAttentionLayer.cc:152-172).  The {cos, sin} of the token's position are computed once per workgroup; a thread
 // owns element d of a head and, inside the rotary range, its partner d + rot/2.  (The first form launched one 128-thread
 // workgroup per (token, head): 41k tiny workgroups per layer, 29 us.)
+template<bool VEC>
 __global__ __launch_bounds__(256) void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bias,
                                                                const int* __restrict__ input_lengths, f16* k_cache,
                                                                f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm)
@@ -119,6 +120,53 @@ __global__ __launch_bounds__(256) void k_qkv_bias_rotary_cache(f16* qkv, const f
     }
     __syncthreads();
     f16* base = qkv + (size_t)row * 3 * hl;
+    if (VEC) {
+        // 16-byte pieces: piece c8 of a head holds d = c8*8 .. c8*8+7; inside the rotary range piece c8 < half/8 pairs with
+        // piece c8 + half/8 (needs rot % 16 == 0, dh % 8 == 0)
+        const int pph = dh / 8, hp = half / 8;
+        for (int i = threadIdx.x; i < nh * pph; i += blockDim.x) {
+            const int h = i / pph, c8 = i % pph;
+            if (c8 >= hp && c8 < 2 * hp) {
+                continue;  // written by the thread that owns piece c8 - hp
+            }
+            const int    e    = h * dh + c8 * 8;
+            const size_t cidx = (((size_t)b * crm * nh + h) * s_max + s) * dh + c8 * 8;
+            f16x8        q = {}, k = {}, v = {};
+            if (valid) {
+                q = *reinterpret_cast<const f16x8*>(base + e) + *reinterpret_cast<const f16x8*>(qkv_bias + e);
+                k = *reinterpret_cast<const f16x8*>(base + hl + e) + *reinterpret_cast<const f16x8*>(qkv_bias + hl + e);
+                v = *reinterpret_cast<const f16x8*>(base + 2 * hl + e) + *reinterpret_cast<const f16x8*>(qkv_bias + 2 * hl + e);
+            }
+            if (c8 < hp) {
+                f16x8 q2 = {}, k2 = {}, v2 = {};
+                if (valid) {
+                    const int e2 = e + half;
+                    q2 = *reinterpret_cast<const f16x8*>(base + e2) + *reinterpret_cast<const f16x8*>(qkv_bias + e2);
+                    k2 = *reinterpret_cast<const f16x8*>(base + hl + e2) + *reinterpret_cast<const f16x8*>(qkv_bias + hl + e2);
+                    v2 = *reinterpret_cast<const f16x8*>(base + 2 * hl + e2)
+                         + *reinterpret_cast<const f16x8*>(qkv_bias + 2 * hl + e2);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        f16 a = q[j], c = q2[j];
+                        rotary_apply(a, c, s_cs[c8 * 8 + j], s_sn[c8 * 8 + j]);
+                        q[j]  = a;
+                        q2[j] = c;
+                        f16 ka = k[j], kc2 = k2[j];
+                        rotary_apply(ka, kc2, s_cs[c8 * 8 + j], s_sn[c8 * 8 + j]);
+                        k[j]  = ka;
+                        k2[j] = kc2;
+                    }
+                }
+                *reinterpret_cast<f16x8*>(base + e + half)         = q2;
+                *reinterpret_cast<f16x8*>(k_cache + cidx + half)   = k2;
+                *reinterpret_cast<f16x8*>(v_cache + cidx + half)   = v2;
+            }
+            *reinterpret_cast<f16x8*>(base + e)       = q;
+            *reinterpret_cast<f16x8*>(k_cache + cidx) = k;
+            *reinterpret_cast<f16x8*>(v_cache + cidx) = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < hl; i += blockDim.x) {
         const int h = i / dh, d = i % dh;
         if (d >= half && d < rot) {
@@ -430,8 +478,14 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     FTCF_CHECK_ARG(dh == 64 || dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(S <= s_max, "prompt longer than the cache");
     FTCF_CHECK_ARG(rot <= 256, "rotary_embedding_dim must be <= 256");
-    hipLaunchKernelGGL(k_qkv_bias_rotary_cache, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias, input_lengths,
-                       k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+    if (rot % 16 == 0) {
+        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<true>, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
+                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+    }
+    else {
+        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<false>, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
+                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+    }
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
     static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
