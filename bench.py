@@ -289,6 +289,12 @@ def main():
                                f"{S}-in/{out_len}-out greedy decode", "weights": a.dtype, "tensor_parallel": tp,
                    "batch": B, "prompt_len": S, "output_len": out_len},
         "prefill_ms": st["prefill_ms"], "prefill_wall_ms": prefill_wall_ms, "e2e_ms": e2e_ms,
+        # context phase: 2*(4H^2+2HI)*L*S*B GEMM flops + 2*L*S^2*H*B causal attention flops, per GPU, vs the 2.5 PFLOP/s
+        # dense fp16 MFMA peak (MI355X_MICROARCH.md)
+        "prefill_tflops_per_gpu": ((2.0 * (4.0 * H * H + 2.0 * H * a.inter) * a.layers * S * B
+                                    + 2.0 * a.layers * S * S * H * B) / tp) / (st["prefill_ms"] * 1e-3) / 1e12,
+        "prefill_mfma_frac": ((2.0 * (4.0 * H * H + 2.0 * H * a.inter) * a.layers * S * B
+                               + 2.0 * a.layers * S * S * H * B) / tp) / (st["prefill_ms"] * 1e-3) / 2.5e15,
         "hbm_bytes_per_token_per_gpu": bpt,
         "path_roofline_frac": bpt * tok_s / 8e12,  # whole-token HBM roofline (8 TB/s), incl. KV + fp16 LM head
         "roofline": roof,

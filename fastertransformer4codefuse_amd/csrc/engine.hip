@@ -201,8 +201,7 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
         p.KT_b = 0;
         p.act = act;
         p.tp = 1;
-        static const int dbg_waves = getenv("FTCF_SPLITK_WAVES") ? atoi(getenv("FTCF_SPLITK_WAVES")) : 4;
-        plan_splitk(p, int8, m, dbg_waves);
+        plan_splitk(p, int8, m, 4);
         launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
     }
     else if (m <= 16) {
