@@ -543,7 +543,7 @@ struct ftcf_gptneox {
             smallm_partial = std::max(
                 gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8),
                 gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8));
-            smallm_ws = (B > 4 && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
+            smallm_ws = (B > STAGE_MAX_ROWS && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -588,7 +588,10 @@ struct ftcf_gptneox {
     // ---- FfnLayer / attention projections over M rows (general path) ----
     void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
     {
-        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, smallm_ws, smallm_partial, num_cu);
+        // (the split-K workspace is sized for the decode rows; a short prefill may bring more rows than that)
+        const bool ws_ok = smallm_ws && m <= 16 && gemm_smallm_workspace_bytes(m, n, k, int8) <= smallm_partial;
+        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, ws_ok ? smallm_ws : nullptr, smallm_partial,
+                      num_cu);
     }
 
     void allreduce(f16* buf, size_t count)
@@ -768,7 +771,7 @@ struct ftcf_gptneox {
                     launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
                                             nrm2, B, H, 1e-5f, stream);
                 }
-                if (B > 4 && B <= 16 && smallm_ws) {
+                if (B <= 16 && smallm_ws) {
                     // independent GEMMs share a launch (a dependent launch costs ~8 us of dispatch latency, most of a layer
                     // at tensor-parallel shard sizes): [QKV, FFN1] -> MMHA -> [out-proj, FFN2]
                     const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
@@ -801,7 +804,11 @@ struct ftcf_gptneox {
         }
     }
 
-    static constexpr int STAGE_MAX_ROWS = 4;
+    // Rows up to which the per-stage GEMV launches run (when the persistent kernel is not eligible).  Measured at 13B int8,
+    // TP = 1, ms per step, per-stage vs general path (burst GEMMs): B = 1: 3.34 vs 3.61 (and 1.28 vs 1.57 on a TP = 8
+    // shard); B = 2: 4.13 vs 3.85; B = 3: 4.64 vs 3.65; B = 4: 5.78 vs 3.73 -- the m = 2..4 forms of the GEMV kernels stream
+    // at a fraction of the m = 1 rate.  FTCF_STAGE_MAX_ROWS (<= 4) overrides, the tests use it to keep those forms covered.
+    int STAGE_MAX_ROWS = 1;
 
     // decoder attention of rows [r0, r0 + M) of the batch (KV cache [L][B][nh][s_max][dh]); `salt` makes the granule
     // tags of every launch of a token distinct
@@ -1485,6 +1492,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->lm_head = (const f16*)w->weights[12 * L + 3];
         FTCF_CHECK_ARG(e->wte && e->final_g && e->final_b && e->lm_head, "missing embedding / final layernorm / lm_head");
         e->k3_q = chunk_pick_q(e->H / 16, (e->hl + e->il) / (e->int8 ? TILE_K_I8 : TILE_K_F16));
+        if (const char* m = getenv("FTCF_STAGE_MAX_ROWS")) {
+            e->STAGE_MAX_ROWS = std::max(0, std::min(4, atoi(m)));
+        }
         if (const char* m = getenv("FTCF_K3_Q")) {
             e->k3_q = atoi(m);
         }

@@ -18,9 +18,12 @@ def gh():
 
 @pytest.fixture(params=["persistent", "launches"], autouse=True)
 def decode_path(request, monkeypatch):
-    """Every engine test runs twice: with the persistent decode-layer kernel (default for B <= 2) and with the per-stage
-    launches (FTCF_PERSIST=0, also what B = 3, 4 always use).  The engine reads the variable when it is created."""
+    """Every engine test runs twice: with the product defaults (persistent decode-layer kernel for B <= 2, general path with
+    the burst GEMMs above) and with the per-stage launches for up to 4 rows (FTCF_PERSIST=0 FTCF_STAGE_MAX_ROWS=4: what one
+    row runs under tensor parallelism; the 2..4-row forms stay covered).  The engine reads the variables when it is created."""
     monkeypatch.setenv("FTCF_PERSIST", "1" if request.param == "persistent" else "0")
+    if request.param == "launches":
+        monkeypatch.setenv("FTCF_STAGE_MAX_ROWS", "4")
     return request.param
 
 
@@ -82,8 +85,8 @@ MID = dict(head_num=8, size_per_head=128, inter_size=4096, num_layer=2, vocab_si
 @pytest.mark.parametrize("int8_mode", [0, 1])
 @pytest.mark.parametrize("B", [1, 2, 3, 6])
 def test_mid_model_fused_and_general_decode_paths(gh, B, int8_mode):
-    """H=1024/Dh=128: B<=2 runs the persistent layer kernel (or the per-stage launches, see `decode_path`), B<=4 the
-    per-stage GEMV launches, B=6 the general (MFMA GEMM) path; all must follow the oracle."""
+    """H=1024/Dh=128: with the defaults B<=2 runs the persistent layer kernel and B=3, 6 the general path (burst GEMMs);
+    in the `launches` variant B<=3 runs the per-stage GEMV launches.  All must follow the oracle."""
     cfg = MID
     w = random_model(cfg, seed=B + 10 * int8_mode, std=0.04)
     layers, glob = weight_list_to_layers(cfg, w)
