@@ -250,3 +250,42 @@ def test_sequential_residual_layers_follow_hf_and_oracle(gh, tiny, int8_mode):
                 break
     if not int8_mode:
         assert r["output_ids"][0, 16:].tolist() == s["hf_tokens"].tolist()
+
+
+def test_one_engine_serves_requests_of_changing_shape(gh, tiny):
+    """The arena is re-planned per request (and may grow), graphs are re-captured, hand-off slabs / split-K tickets are reset:
+    a request must not depend on what ran before it."""
+    from tests.test_gpu_beam import _replay
+    cfg, w, layers, glob, z = tiny
+    op = gh.make_op(cfg, w)
+    m = orc.Model(dict(cfg, fp16=1), layers, glob)
+    V = cfg["vocab_size"]
+    rng = np.random.RandomState(3)
+    first = None
+    for B, S, out, K in [(1, 16, 8, 1), (5, 3, 4, 1), (2, 1, 6, 3), (1, 16, 8, 1), (16, 9, 5, 1), (3, 40, 3, 2), (33, 2, 3, 1),
+                         (1, 16, 8, 1)]:
+        if (B, S) == (1, 16):
+            ids, lens = z["prompt"][None, :].astype(np.int32), np.array([16], np.int32)
+        else:
+            lens = rng.randint(1, S + 1, size=B).astype(np.int32)
+            lens[0] = S
+            ids = np.full((B, S), cfg["end_id"], np.int32)
+            for b in range(B):
+                ids[b, :lens[b]] = rng.randint(3, V, size=lens[b])
+        if K > 1:
+            r = gh.run_op_beam(op, ids, lens, out, V, K, return_logits=True)
+            p_ids, _, _ = _replay(cfg, ids, lens, out, K, r["logits"], orc.BeamParams(B))
+            assert r["output_ids"].tolist() == p_ids.tolist(), (B, S, out, K)
+            continue
+        r = gh.run_op(op, ids, lens, out, V, top_k=1)
+        o = m.generate(ids, lens, out, return_logits=True)
+        for b in range(B):
+            for t in range(out):
+                _logit_close(r["logits"][t, b], o["logits"][t, b], frac=0.03)
+                if o["output_ids"][b, lens[b] + t] == cfg["end_id"] or \
+                        r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
+                    break
+        if (B, S) == (1, 16):
+            first = r["output_ids"].copy() if first is None else first
+            assert np.array_equal(first, r["output_ids"])
+            assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
