@@ -192,3 +192,21 @@ def test_beam_width_out_of_range_is_rejected(gh, tiny):
     op = gh.make_op(cfg, w)
     with pytest.raises(RuntimeError):
         gh.run_op_beam(op, g["ids_a"], g["lens_a"], 4, cfg["vocab_size"], 65)
+
+
+@pytest.mark.parametrize("B,K,out", [(1, 16, 6), (2, 33, 5), (1, 64, 4)])
+def test_wide_beams_are_exact_given_the_same_logits(gh, tiny, B, K, out):
+    """beam_width up to the online beam search limit (64): rows = B*K reach the tiled GEMM path; the K*K candidate pool of the
+    batch kernel grows to 4096."""
+    cfg, w, layers, glob, g = tiny
+    op = gh.make_op(cfg, w)
+    z = g["ids_a"][0]
+    ids = np.stack([np.roll(z, i) for i in range(B)]).astype(np.int32)
+    lens = np.full(B, ids.shape[1], np.int32)
+    r = gh.run_op_beam(op, ids, lens, out, cfg["vocab_size"], K, return_logits=True, repetition_penalty=1.2,
+                       beam_search_diversity_rate=-0.1)
+    bp = orc.BeamParams(B, repetition_penalty=1.2, diversity_rate=-0.1)
+    p_ids, p_len, p_cum = _replay(cfg, ids, lens, out, K, r["logits"], bp)
+    assert r["output_ids"].tolist() == p_ids.tolist()
+    assert r["sequence_lengths"].tolist() == p_len.tolist()
+    np.testing.assert_allclose(r["cum_log_probs"], p_cum, rtol=1e-4, atol=1e-3)
