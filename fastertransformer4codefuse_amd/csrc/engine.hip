@@ -1211,8 +1211,8 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
     const int B = ses.B, S = ses.S, s_max = ses.s_max;
     const int tp = cfg.tensor_para_size;
     if (with_decoder) {
-            launch_step_embedding(x, wte, step_ids, &state->step, B, H, stream);
-            launch_rotary_table(rot_table, &state->step, pad_count, B, cfg.rotary_embedding_dim, stream);
+            launch_step_prologue(x, wte, step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
+                                 stream);
             decoder(B, s_max);
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4

@@ -147,6 +147,9 @@ size_t mmha_smem_bytes(int dh, int s_max, int nsplit);
 void   launch_mmha(const MmhaParams& p, hipStream_t s);
 // {cos, sin}(pos * 10000^(-2j/rot)), pos = step - 1 - pad_count[b], once per token (decoder_masked_multihead_attention_utils.h:1325-1329)
 void   launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s);
+// launch_step_embedding + launch_rotary_table in one launch
+void   launch_step_prologue(f16* out, const f16* table, const int* output_ids, const int* d_step, float* rot_table,
+                            const int* pad_count, int B, int H, int rot, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
                                 hipStream_t s, int cache_row_mult = 1);  // K/V of prompt row b live in cache row b * mult

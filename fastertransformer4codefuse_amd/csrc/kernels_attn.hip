@@ -60,6 +60,40 @@ __global__ void k_rotary_table(float* table, const int* d_step, const int* pad_c
     }
 }
 
+// Token prologue in ONE launch: the embedding row of the previous step's token (decoding_kernels.cu:145-191,
+// embeddingLookupPosEncoding without position table) and the rotary {cos, sin} table of this step, per row.  (Two
+// launches cost two dispatch latencies of ~5 us for a few KB of work.)
+__global__ __launch_bounds__(256) void k_step_prologue(f16* out, const f16* __restrict__ table,
+                                                       const int* __restrict__ output_ids, const int* d_step,
+                                                       float* rot_table, const int* __restrict__ pad_count, int B, int H,
+                                                       int rot)
+{
+    const int b    = blockIdx.x;
+    const int step = *d_step;
+    if ((int)threadIdx.x < rot / 2) {
+        const int pos = (step - 1) - (pad_count ? pad_count[b] : 0);
+        float     cs, sn;
+        rotary_coef(threadIdx.x, rot, pos, cs, sn);
+        rot_table[((size_t)b * (rot / 2) + threadIdx.x) * 2]     = cs;
+        rot_table[((size_t)b * (rot / 2) + threadIdx.x) * 2 + 1] = sn;
+    }
+    const int  id  = output_ids[(size_t)(step - 1) * B + b];
+    const f16* src = table + (size_t)id * H;
+    f16*       dst = out + (size_t)b * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+        *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+    }
+}
+
+void launch_step_prologue(f16* out, const f16* table, const int* output_ids, const int* d_step, float* rot_table,
+                          const int* pad_count, int B, int H, int rot, hipStream_t s)
+{
+    FTCF_CHECK_ARG(rot / 2 <= 256 && H % 8 == 0, "rotary_embedding_dim must be <= 512 and the hidden size a multiple of 8");
+    hipLaunchKernelGGL(k_step_prologue, dim3(B), dim3(256), 0, s, out, table, output_ids, d_step, rot_table, pad_count, B, H,
+                       rot);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 void launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s)
 {
     if (rot <= 0) {
