@@ -739,12 +739,16 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     }
 
     // ---- the workgroup's static share of the streaming stages ----
-    const int G   = NT0 + Il / 16;
-    const int g0  = (int)((long)G * bid / NB), g1 = (int)((long)G * (bid + 1) / NB);
+    // P1: every workgroup owns a range of QKV column groups AND a range of FFN1 column groups (QKV runs first in its run
+    // table: they are streamed first, so qkv is complete -- and published -- well before the stage ends)
+    const int NF  = Il / 16;
+    const int q0  = (int)((long)NT0 * bid / NB), q1 = (int)((long)NT0 * (bid + 1) / NB);
+    const int f0  = (int)((long)NF * bid / NB), f1 = (int)((long)NF * (bid + 1) / NB);
+    const int nq  = q1 - q0;
     const int rB0 = (int)((long)NG * PB * bid / NB), rB1 = (int)((long)NG * PB * (bid + 1) / NB);
     const int rA0 = (int)((long)NG * PA * bid / NB), rA1 = (int)((long)NG * PA * (bid + 1) / NB);
     const int nB = rB1 - rB0, nA = rA1 - rA0;
-    const int nruns1 = g1 - g0, nruns3 = nB + nA;
+    const int nruns1 = nq + (f1 - f0), nruns3 = nB + nA;
     const int n_items = p.B * p.nh * p.plan.nsplit;
     if (threadIdx.x == 0) {
         s.misc[0]  = 0;
@@ -752,10 +756,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
     }
     __syncthreads();
-    if ((int)threadIdx.x < nruns1) {  // P1: [QKV u FFN1] column groups g0..g1, full K each
+    if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
         const int  j   = threadIdx.x;
-        const int  cg  = g0 + j;
-        const bool seg = cg >= NT0;
+        const bool seg = j >= nq;
+        const int  cg  = seg ? NT0 + f0 + (j - nq) : q0 + j;
         const int  g   = seg ? cg - NT0 : cg;
         RunRec     r;
         r.tile0  = g * KT;
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 const int idx = tid + k * PS_NT;
                 r_b1[k]       = (f16)0.f;
                 if (idx < nruns1 * M * 16) {
-                    const int cg = g0 + idx / (M * 16);
+                    const int cg = s.rt1[idx / (M * 16)].rid;
                     if (cg >= NT0) {
                         r_b1[k] = PS_G(f16, lw.b_ffn1)[(cg - NT0) * 16 + (idx & 15)];
                     }
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                         for (int w = 0; w < PS_NW; w++) {
                             v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
                         }
-                        const int cg = g0 + j;
+                        const int cg = s.rt1[j].rid;
                         f16       o;
                         if (cg < NT0) {
                             o = (f16)v;
@@ -1315,8 +1319,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (NB < 1 || B * nh > NB) {
         return pl;
     }
-    const int KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK, NG = H / 16, G = 3 * Hl / 16 + Il / 16;
-    if ((G + NB - 1) / NB > PS_RMAX) {
+    const int KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK, NG = H / 16, NT0h = 3 * Hl / 16, NFh = Il / 16;
+    if ((NT0h + NB - 1) / NB + (NFh + NB - 1) / NB > PS_RMAX) {
         return pl;
     }
     int nsplit = NB / (B * nh);
@@ -1382,7 +1386,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations
     int e1 = 0, e3 = 0;
     for (int b = 0; b < NB; b++) {
-        const int g0 = (int)((long)G * b / NB), g1 = (int)((long)G * (b + 1) / NB);
+        const int nr1 = (int)((long)NT0h * (b + 1) / NB) - (int)((long)NT0h * b / NB)
+                        + (int)((long)NFh * (b + 1) / NB) - (int)((long)NFh * b / NB);
         const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
         const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);
         const int nB = rB1 - rB0, nA = rA1 - rA0;
@@ -1401,8 +1406,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
         }
         for (int w = 0; w < PS_NW; w++) {
             int tb, te;
-            ps_wave_range((g1 - g0) * KT, w, cs1, tb, te);
-            e1 = std::max(e1, ps_wave_entries(g1 - g0, nt1, tb, te));
+            ps_wave_range(nr1 * KT, w, cs1, tb, te);
+            e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
             ps_wave_range(T3, w, cs3, tb, te);
             e3 = std::max(e3, ps_wave_entries(nB + nA, nt3, tb, te));
         }
