@@ -172,6 +172,7 @@ struct PersistPlan {
     int    ok;        // 0: shape not eligible (caller uses the per-kernel path)
     int    NB;        // workgroups (<= CUs)
     int    nsplit;    // split-KV factor of the attention stage
+    int    uk;        // K / V wave-loads per lane of the attention stage (8: <= 256 keys per split, 12: <= 384)
     int    PA, PB;    // K pieces per 16-column group of out-proj / FFN2
     int    RLa, RLb;  // tiles per piece
     int    xs_halves; // LDS x region

@@ -40,7 +40,9 @@ constexpr int PS_RMAX     = 24;          // runs per workgroup and stage
 constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
 constexpr int PS_MAXP     = 16;          // PA + PB
 constexpr int PS_SPIN     = 1 << 18;
-constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane
+constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane (256 keys per workgroup) ...
+constexpr int PS_UK_LONG  = 12;          // ... or 12 (384 keys) for requests whose KV split does not fit 256: a second
+                                         // instantiation, because the 8-deep form scores 1 % better where both fit
 #ifndef PS_FULL_P1_V
 #define PS_FULL_P1_V false
 #endif
@@ -386,11 +388,11 @@ __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 // attention of one (row b, head h, split sp) on the whole 8-wave workgroup
 // (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.cuh::mmha_partial)
 // ---------------------------------------------------------------------------------------------------------------
-template<int DH>
+template<int DH, int UK>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
     static constexpr int KPI = 64 / LPK;
-    u32x4 kreg[PS_UK], vreg[PS_UK];
+    u32x4 kreg[UK], vreg[UK];
     unsigned mask_bits, bias2;
     int      tl, chunk, t_beg;
     float    rot_cs, rot_sn;
@@ -405,24 +407,28 @@ struct PsAttn {
         t_beg = sp * chunk;
         const auto* kc = PS_G(f16, lw.k_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
         const auto* vc = PS_G(f16, lw.v_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
+        // rows past the end of this split's chunk (the register capacity covers UK * 32 keys, the chunk may be shorter)
+        // re-read its last row: a cache hit, not K/V traffic of the neighbouring split
+        int t_last = t_beg + chunk - 1;
+        t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
 #pragma unroll
-        for (int u = 0; u < PS_UK; u++) {
+        for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < p.s_max ? t : p.s_max - 1;
+            t       = t < t_last ? t : t_last;
             kreg[u] = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
         }
 #pragma unroll
-        for (int u = 0; u < PS_UK; u++) {
+        for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < p.s_max ? t : p.s_max - 1;
+            t       = t < t_last ? t : t_last;
             vreg[u] = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
         }
         mask_bits = 0u;
         if (p.masked_tokens && sub == 0) {
 #pragma unroll
-            for (int u = 0; u < PS_UK; u++) {
+            for (int u = 0; u < UK; u++) {
                 int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-                t     = t < p.s_max ? t : p.s_max - 1;
+                t     = t < t_last ? t : t_last;
                 mask_bits |= (p.masked_tokens[(size_t)b * p.s_max + t] ? 1u : 0u) << u;
             }
         }
@@ -525,7 +531,7 @@ struct PsAttn {
         const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
         float       lmax        = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < PS_UK; u++) {
+        for (int u = 0; u < UK; u++) {
             const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             const f16x8 kv = __builtin_bit_cast(f16x8, kreg[u]);
             float       a  = 0.f;
@@ -585,7 +591,7 @@ struct PsAttn {
             acc[j] = 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < PS_UK; u++) {
+        for (int u = 0; u < UK; u++) {
             const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
                 const float pt = s_p[t - t_beg];
@@ -690,7 +696,7 @@ __device__ __forceinline__ void ps_attn_publish_zero(const PersistParams& p, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template<bool INT8, int M, int DH>
+template<bool INT8, int M, int DH, int UK>
 __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1105,7 +1111,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
 
             // =========================== attention ===============================================================
             asm volatile("" : "+v"(tid));
-            PsAttn<DH> at;
+            PsAttn<DH, UK> at;
             const bool has_item = bid < n_items;
             int        a_sp = 0, a_h = 0, a_b = 0;
             if (has_item) {
@@ -1326,9 +1332,10 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     int nsplit = NB / (B * nh);
     nsplit     = nsplit > MMHA_MAX_SPLIT ? MMHA_MAX_SPLIT : nsplit;
     const int chunk = ((((s_max + nsplit - 1) / nsplit) + 15) & ~15);
-    if (chunk > PS_NW * (64 / (dh / 8)) * PS_UK) {
+    if (chunk > PS_NW * (64 / (dh / 8)) * PS_UK_LONG) {
         return pl;  // the K/V rows of a split must fit the registers of one trip
     }
+    pl.uk = chunk > PS_NW * (64 / (dh / 8)) * PS_UK ? PS_UK_LONG : PS_UK;
     // K pieces: best balanced tile count per workgroup
     double best = 1e30;
     long   t3max = 0;
@@ -1432,16 +1439,16 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     return pl;
 }
 
-template<bool INT8, int M, int DH>
+template<bool INT8, int M, int DH, int UK>
 static void launch_ps(const PersistParams& p, hipStream_t s)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        FTCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH>),
+        FTCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_decode_persistent<INT8, M, DH>), dim3(p.plan.NB), dim3(PS_NT), p.plan.smem, s, p);
+    hipLaunchKernelGGL((k_decode_persistent<INT8, M, DH, UK>), dim3(p.plan.NB), dim3(PS_NT), p.plan.smem, s, p);
 }
 
 void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
@@ -1452,7 +1459,12 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
 #define PS_CASE(I8, MM, D)                                                                                             \
     if (int8 == I8 && p.B == MM && p.dh == D) {                                                                        \
-        launch_ps<I8, MM, D>(p, s);                                                                                    \
+        if (p.plan.uk == PS_UK_LONG) {                                                                                 \
+            launch_ps<I8, MM, D, PS_UK_LONG>(p, s);                                                                    \
+        }                                                                                                              \
+        else {                                                                                                         \
+            launch_ps<I8, MM, D, PS_UK>(p, s);                                                                         \
+        }                                                                                                              \
     }
     PS_CASE(true, 1, 128)
 #ifndef PS_ONLY_ONE

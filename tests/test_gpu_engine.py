@@ -289,3 +289,24 @@ def test_one_engine_serves_requests_of_changing_shape(gh, tiny):
             first = r["output_ids"].copy() if first is None else first
             assert np.array_equal(first, r["output_ids"])
             assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
+
+
+def test_persistent_kernel_long_key_ranges(gh, tiny, monkeypatch, decode_path):
+    """KV splits of more than 256 keys per 8 wave-loads (here 704 keys at size_per_head 64 with 24 workgroups, 6 splits)
+    select the 12-deep instantiation of the persistent kernel's attention; logits follow the oracle."""
+    if decode_path != "persistent":
+        pytest.skip("persistent path only")
+    monkeypatch.setenv("FTCF_PERSIST_NB", "24")
+    cfg, w, layers, glob, z = tiny
+    op = gh.make_op(cfg, w)
+    S, out = 4200, 5
+    ids = np.random.RandomState(6).randint(3, cfg["vocab_size"], size=(1, S)).astype(np.int32)
+    r = gh.run_op(op, ids, [S], out, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 1
+    o = orc.Model(dict(cfg, fp16=1), layers, glob).generate(ids, [S], out, return_logits=True)
+    for t in range(out):
+        _logit_close(r["logits"][t, 0], o["logits"][t, 0])
+        if r["output_ids"][0, S + t] != o["output_ids"][0, S + t]:
+            top2 = np.sort(o["logits"][t, 0])[-2:]
+            assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
+            break
