@@ -310,3 +310,44 @@ def test_persistent_kernel_long_key_ranges(gh, tiny, monkeypatch, decode_path):
             top2 = np.sort(o["logits"][t, 0])[-2:]
             assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
             break
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sampling_kernels_reproduce_the_oracle_given_the_same_logits(gh, tiny, seed):
+    """The GPU's own per-step logits pushed through the oracle's dynamic decode (same counter-based uniforms, same (value
+    desc, index asc) ordering): top-k / top-p / temperature / repetition-penalty sampling must pick the same tokens -- no
+    model noise in this comparison, only exp/sum rounding at a cumulative boundary could differ."""
+    cfg, w, layers, glob, z = tiny
+    rng = np.random.RandomState(50 + seed)
+    B, S, out = 4, 16, 10
+    V = cfg["vocab_size"]
+    ids = np.stack([np.roll(z["prompt"], i) for i in range(B)]).astype(np.int32)
+    kw = dict(top_k=[int(x) for x in rng.choice([0, 1, 3, 8, 50], size=B)],
+              top_p=[float(x) for x in rng.choice([0.0, 0.3, 0.8, 0.95], size=B)],
+              temperature=[float(x) for x in rng.choice([0.6, 1.0, 1.4], size=B)],
+              repetition_penalty=[float(x) for x in rng.choice([1.0, 1.15, 1.5], size=B)],
+              random_seed=[int(x) for x in rng.randint(0, 1 << 30, size=B)])
+    op = gh.make_op(cfg, w)
+    r = gh.run_op(op, ids, [S] * B, out, V, **kw)
+    sp = orc.Sampling(B, **kw)
+    total = S + out
+    step_ids = np.zeros((total, B), np.int32)
+    step_ids[:S] = ids.T
+    fin = np.zeros(B, np.uint8)
+    seq = np.full(B, S - 1, np.int32)
+    cum = np.zeros(B, np.float32)
+    draws = np.zeros(B, np.uint64)
+    lens = np.full(B, S, np.int32)
+    mismatches = 0
+    for t in range(out):
+        lg = np.ascontiguousarray(r["logits"][t], dtype=np.float32).copy()
+        orc.dynamic_decode(lg, S + t, S, lens, sp, cfg["end_id"], step_ids, fin, seq, cum, draws)
+        got = r["output_ids"][:, S + t]
+        bad = step_ids[S + t] != got
+        if bad.any():  # keep the replay on the GPU's trajectory (penalties look at the history)
+            mismatches += int(bad.sum())
+            step_ids[S + t] = got
+            fin[:] = np.where(bad, (got == cfg["end_id"]).astype(np.uint8), fin)
+        if fin.all():
+            break
+    assert mismatches <= 1, (mismatches, kw)
