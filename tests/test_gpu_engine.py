@@ -351,3 +351,39 @@ def test_sampling_kernels_reproduce_the_oracle_given_the_same_logits(gh, tiny, s
         if fin.all():
             break
     assert mismatches <= 1, (mismatches, kw)
+
+
+def test_begin_step_finish_equals_forward(gh, tiny):
+    """ftcf_gptneox_forward == begin + step(...) + finish (include/ftcf.h): the token loop may be driven in pieces."""
+    import ctypes as C
+    import torch
+    from fastertransformer4codefuse_amd import capi
+    cfg, w, layers, glob, z = tiny
+    op = gh.make_op(cfg, w)
+    B, S, out = 2, 16, 8
+    ids_np = np.stack([z["prompt"], z["prompt"][::-1]]).astype(np.int32)
+    ref = gh.run_op(op, ids_np, [S] * B, out, cfg["vocab_size"], top_k=1, return_logits=False)
+    ids = torch.from_numpy(ids_np).cuda()
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    out_ids = torch.zeros((B, 1, S + out), dtype=torch.int32, device="cuda")
+    seq = torch.zeros((B, 1), dtype=torch.int32, device="cuda")
+    top_k = np.array([1], np.int32)
+    fa = capi.ForwardArgs()
+    fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+    fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, out, 1
+    fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+    fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+    L = capi.lib()
+    done = C.c_int(0)
+    assert L.ftcf_gptneox_step(op._h, 1, C.byref(done)) != 0  # no request in flight
+    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))
+    total_done = 0
+    for n in (3, 2, 100):
+        capi.check(L.ftcf_gptneox_step(op._h, n, C.byref(done)))
+        assert done.value <= n
+        total_done += done.value
+    assert total_done == out
+    capi.check(L.ftcf_gptneox_finish(op._h))
+    torch.cuda.synchronize()
+    assert out_ids[:, 0].cpu().numpy().tolist() == ref["output_ids"].tolist()
+    assert seq[:, 0].cpu().numpy().tolist() == ref["sequence_lengths"].tolist()
