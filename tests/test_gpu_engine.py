@@ -387,3 +387,23 @@ def test_begin_step_finish_equals_forward(gh, tiny):
     torch.cuda.synchronize()
     assert out_ids[:, 0].cpu().numpy().tolist() == ref["output_ids"].tolist()
     assert seq[:, 0].cpu().numpy().tolist() == ref["sequence_lengths"].tolist()
+
+
+def test_invalid_requests_raise_and_leave_the_engine_usable(gh, tiny):
+    """Argument errors come back as exceptions with a message (the reference TORCH_CHECKs / exits); the engine keeps working."""
+    import torch
+    from fastertransformer4codefuse_amd.capi import FtcfError
+    cfg, w, layers, glob, z = tiny
+    op = gh.make_op(cfg, w)
+    ids = torch.from_numpy(z["prompt"][None, :].astype(np.int32)).cuda()
+    lens = torch.tensor([16], dtype=torch.int32, device="cuda")
+    with pytest.raises((RuntimeError, FtcfError)):
+        op.forward(ids, lens, 0)  # output_len must be >= 1
+    with pytest.raises((RuntimeError, FtcfError)):
+        op.forward(ids, lens, 4, 1, torch.tensor([1, 2, 3], dtype=torch.int32))  # top_k of size 3 for batch 1
+    with pytest.raises((RuntimeError, FtcfError)):
+        op.forward(ids.cpu(), lens, 4)  # host tensor
+    with pytest.raises((RuntimeError, FtcfError)):
+        op.forward(ids.to(torch.int64), lens, 4)  # wrong dtype
+    r = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1, return_logits=False)
+    assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
