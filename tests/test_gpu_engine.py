@@ -407,3 +407,30 @@ def test_invalid_requests_raise_and_leave_the_engine_usable(gh, tiny):
         op.forward(ids.to(torch.int64), lens, 4)  # wrong dtype
     r = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1, return_logits=False)
     assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
+
+
+@pytest.mark.parametrize("int8_mode", [0, 1])
+def test_mid_model_long_ragged_prefill(gh, int8_mode):
+    """Prefill kernels on shapes that cross their tile sizes: 257 / 130-token prompts (64-query and 64-key tiles of the MFMA
+    attention, 128-row tiles of the GEMM), size_per_head 128, ragged batch."""
+    cfg = MID
+    w = random_model(cfg, seed=77 + int8_mode, std=0.04)
+    layers, glob = weight_list_to_layers(cfg, w)
+    if int8_mode:
+        layers = quantize_layers(layers)
+    rng = np.random.RandomState(9)
+    S, out = 257, 4
+    lens = np.array([257, 130], np.int32)
+    ids = np.full((2, S), cfg["end_id"], dtype=np.int32)
+    for b in range(2):
+        ids[b, :lens[b]] = rng.randint(3, cfg["vocab_size"], size=lens[b])
+    op = gh.make_op(cfg, w, int8_mode=int8_mode)
+    r = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
+    o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode), layers, glob).generate(ids, lens, out, return_logits=True)
+    for b in range(2):
+        for t in range(out):
+            _logit_close(r["logits"][t, b], o["logits"][t, b], frac=0.03)
+            if r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
+                top2 = np.sort(o["logits"][t, b])[-2:]
+                assert top2[1] - top2[0] < 0.03 * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
+                break
