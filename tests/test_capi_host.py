@@ -78,3 +78,29 @@ def test_batched_3d_quantize_and_argument_checks():
         symmetric_quantize_last_axis_of_batched_matrix_int8(torch.zeros(4))
     with pytest.raises(capi.FtcfError):
         symmetric_quantize_last_axis_of_batched_matrix_int8(torch.zeros(60, 16))  # K % 64 != 0
+
+
+def test_full_size_quantize_and_layout_round_trips():
+    """CodeFuse-13B FFN matrix (5120 x 20480), where only size-independent properties are checked: tiled <-> row-major and
+    CUDA-SM80 <-> row-major are exact inverses, every column reaches 127 / -128 (the scale is max|w| / 128 as in
+    cutlass_preprocessors.cc:603-643), dequantised error <= scale / 2 except where +128 was clamped to 127."""
+    torch.manual_seed(3)
+    K, N = 5120, 20480
+    w = (torch.randn(K, N) * 0.02).half().contiguous()
+    q, s = symmetric_quantize_last_axis_of_batched_matrix_int8(w)
+    L = capi.lib()
+    q_rm = torch.empty((K, N), dtype=torch.int8)
+    capi.check(L.ftcf_int8_tiled_to_rowmajor(capi.vp(q), C.c_size_t(K), C.c_size_t(N), capi.vp(q_rm)))
+    q2 = torch.empty_like(q)
+    capi.check(L.ftcf_int8_rowmajor_to_tiled(capi.vp(q_rm), C.c_size_t(K), C.c_size_t(N), capi.vp(q2)))
+    assert torch.equal(q, q2)
+    cu = torch.empty((K * N,), dtype=torch.int8)
+    capi.check(L.ftcf_int8_rowmajor_to_cuda_sm80(capi.vp(q_rm), C.c_size_t(K), C.c_size_t(N), capi.vp(cu)))
+    back = torch.empty((K, N), dtype=torch.int8)
+    capi.check(L.ftcf_int8_cuda_sm80_to_rowmajor(capi.vp(cu), C.c_size_t(K), C.c_size_t(N), capi.vp(back)))
+    assert torch.equal(back, q_rm)
+    qa = q_rm.to(torch.int16).abs()
+    assert bool((qa.max(dim=0).values >= 127).all())
+    err = (q_rm.float() * s.float()[None, :] - w.float()).abs()
+    lim = torch.where(q_rm == 127, s.float()[None, :] * 1.0, s.float()[None, :] * 0.5) + 1e-6
+    assert bool((err <= lim).all())
