@@ -6,10 +6,13 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one decoded token (one pass of the per-token hot path: L decoder layers + LM head + dynamic decode).
-The 1024-token prefill runs through the real context path before the timed region (KV cache resident in HBM), then W
-untimed + K timed decode steps (W + K = 512 by default -> KV length 1024..1536).  Weights are synthetic
-(random int8 + fp16 scales of CodeFuse-13B's shape, generated on the device); there is no network for checkpoints.
-Rank 0 prints ONE JSON line.
+The request is ALWAYS the headline one -- a 1024-token prompt prefilled through the real context path (KV cache resident
+in HBM) and --output-len (512) generated tokens -- whatever --steps / --warmup say: the K timed steps (preceded by W
+untimed ones) are a window of that request centred on output token 256, i.e. on the mean KV length 1280 of the whole
+request (K + W >= 512: the whole request is the window).  The steps before and after the window run untimed, then one
+complete ftcf_gptneox_forward of the same request gives the end-to-end latency.  return_cum_log_probs = 1 as in the
+reference harness (codefuse_example.py:745).  Weights are synthetic (random int8 + fp16 scales of CodeFuse-13B's shape,
+generated on the device); there is no network for checkpoints.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -32,6 +35,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--dtype", default="int8", choices=["int8", "fp16"])
     p.add_argument("--prompt-len", type=int, default=1024)
+    p.add_argument("--output-len", type=int, default=512)
     p.add_argument("--batch", type=int, default=1)
     p.add_argument("--layers", type=int, default=40)
     p.add_argument("--heads", type=int, default=40)
@@ -93,48 +97,64 @@ def bytes_per_token(a, tp, t_mean):
     return (L * (4 * H * H + 2 * H * I) * w + V * H * 2 + 2 * L * t_mean * H * 2 * a.batch) / tp
 
 
-def cpu_baseline(a):
-    """Oracle (CPU restatement, kind "port") on a bounded sample: one decode step at KV length 1024 over 2 of the L
-    layers (+ nothing else), all host cores; tokens/s extrapolated by L/2."""
+def cpu_baseline(a, budget_s=25.0, max_steps=8):
+    """Oracle (CPU restatement, kind "port") on the FULL model: all L layers of CodeFuse-13B-shaped weight-only int8
+    (13.1 GB of int8 weights in host RAM, every layer its own random matrices), KV caches pre-filled to the prompt
+    length with synthetic rows, then whole decode steps -- L decoder layers + final LayerNorm + the V x H LM head +
+    greedy arg-max -- on all host cores: one warm-up step, then up to `max_steps` timed steps or `budget_s` seconds,
+    whichever comes first (workload B)."""
     from oracle import oracle as orc
-    from tests.helpers import quantize_layers  # noqa: F401
-    Lc = min(2, a.layers)
-    H, I, nh, dh = a.heads * a.head_dim, a.inter, a.heads, a.head_dim
-    rng = np.random.RandomState(0)
+    Lc = a.layers
+    H, I, nh, dh, V = a.heads * a.head_dim, a.inter, a.heads, a.head_dim, a.vocab
+    rng = np.random.default_rng(0)
+    int8 = a.dtype == "int8"
+
+    def rand_q(K, N):  # uniform int8 in [-127, 127] at memory speed
+        q = np.frombuffer(rng.bytes(K * N), dtype=np.int8).reshape(K, N).copy()
+        q[q == -128] = 0
+        return q
+
     layers = []
+    ones, zeros = np.ones(H, np.float32), np.zeros(H, np.float32)
     for _ in range(Lc):
-        lay = dict(ln1_g=np.ones(H, np.float32), ln1_b=np.zeros(H, np.float32), ln2_g=np.ones(H, np.float32),
-                   ln2_b=np.zeros(H, np.float32), qkv_b=np.zeros(3 * H, np.float32), ffn1_b=np.zeros(I, np.float32),
-                   ffn2_b=np.zeros(H, np.float32))
+        lay = dict(ln1_g=ones, ln1_b=zeros, ln2_g=ones, ln2_b=zeros, qkv_b=np.zeros(3 * H, np.float32),
+                   ffn1_b=np.zeros(I, np.float32), ffn2_b=zeros)
         for name, (K, N) in dict(qkv=(H, 3 * H), out=(H, H), ffn1=(H, I), ffn2=(I, H)).items():
-            if a.dtype == "int8":
-                lay[name + "_q"] = rng.randint(-127, 128, size=(K, N)).astype(np.int8)
+            if int8:
+                lay[name + "_q"] = rand_q(K, N)
                 lay[name + "_s"] = np.full(N, 2e-4, np.float32)
             else:
-                lay[name + "_w"] = (rng.standard_normal((K, N)).astype(np.float32) * 0.02)
+                lay[name + "_w"] = rand_q(K, N).astype(np.float32) * np.float32(2e-4)
         layers.append(lay)
-    glob = dict(wte=np.zeros((8, H), np.float32), final_ln_g=np.ones(H, np.float32), final_ln_b=np.zeros(H, np.float32),
-                lm_head=np.zeros((8, H), np.float32))
-    cfg = dict(head_num=nh, size_per_head=dh, inter_size=I, num_layer=Lc, vocab_size=8, rotary_dim=a.rotary, end_id=2,
-               int8_mode=1 if a.dtype == "int8" else 0, fp16=1)
+    head = rand_q(V, H).astype(np.float32) * np.float32(1e-3)
+    glob = dict(wte=head, final_ln_g=ones, final_ln_b=zeros, lm_head=head)
+    cfg = dict(head_num=nh, size_per_head=dh, inter_size=I, num_layer=Lc, vocab_size=V, rotary_dim=a.rotary, end_id=2,
+               int8_mode=1 if int8 else 0, fp16=1)
     m = orc.Model(cfg, layers, glob)
     t = a.prompt_len
-    s_max = t + 8
-    kc = (rng.standard_normal((Lc, 1, nh, s_max, dh)).astype(np.float32) * 0.5)
-    vc = (rng.standard_normal((Lc, 1, nh, s_max, dh)).astype(np.float32) * 0.5)
-    x = rng.standard_normal((1, H)).astype(np.float32)
-    args = (np.array([t], np.int32), np.zeros(1, np.int32), np.zeros((1, s_max), np.uint8), np.zeros(1, np.uint8))
-    m.decoder_step(x, kc, vc, *args, t + 1)  # warm
+    s_max = t + max_steps + 2
+    kc = rng.standard_normal((Lc, 1, nh, s_max, dh), dtype=np.float32) * np.float32(0.5)
+    vc = rng.standard_normal((Lc, 1, nh, s_max, dh), dtype=np.float32) * np.float32(0.5)
+    zero1, mask = np.zeros(1, np.int32), np.zeros((1, s_max), np.uint8)
+    fin = np.zeros(1, np.uint8)
+
+    def one_step(tok, pos):
+        x = head[tok:tok + 1]  # embedding row (wte)
+        y = m.decoder_step(x, kc, vc, np.array([pos], np.int32), zero1, mask, fin, pos + 1)
+        logits = orc.lm_head(orc.layernorm(y, ones, zeros), head)
+        return int(np.argmax(logits[0]))
+
+    tok = one_step(3, t)  # warm-up (page faults, thread pool)
     t0 = time.time()
     reps = 0
-    while time.time() - t0 < 10.0 and reps < 8:
-        m.decoder_step(x, kc, vc, *args, t + 1)
+    while reps < max_steps and (reps == 0 or time.time() - t0 < budget_s):
+        tok = one_step(tok, t + 1 + reps)
         reps += 1
     dt = (time.time() - t0) / reps
-    tok_s = 1.0 / (dt * a.layers / Lc)
-    return {"value": tok_s, "unit": "tokens/s", "cores": int(orc.lib().orc_num_threads()), "kind": "port",
-            "sample": f"{reps} decode steps at KV length {t} over {Lc} of {a.layers} layers "
-                      f"(no LM head), extrapolated x{a.layers / Lc:g}; oracle/ftcf_oracle.c"}
+    return {"value": 1.0 / dt, "unit": "tokens/s", "cores": int(orc.lib().orc_num_threads()), "kind": "port",
+            "sample": f"{reps} whole decode steps (all {Lc} layers of the {'int8' if int8 else 'fp16'} model + final LN + "
+                      f"{V}x{H} LM head + arg-max) at KV length {t + 1}..{t + reps}, bs=1, after one warm-up step; "
+                      f"oracle/ftcf_oracle.c", "s_per_step": dt}
 
 
 def main():
@@ -171,13 +191,20 @@ def main():
     op = GptNeoXOp(group, rank, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, end_id, tp, 1,
                    1 if a.dtype == "int8" else 0, 2048, True, weights, int8_w, scales)
     B, S = a.batch, a.prompt_len
-    out_len = a.warmup + a.steps
+    out_len = a.output_len
+    # the timed window inside the request: K steps centred on output token out_len / 2 (KV length S + out_len / 2 = the
+    # request's mean), W untimed steps right before it; the rest of the request runs untimed around the window
+    steps = min(a.steps, out_len)
+    warmup = min(a.warmup, out_len - steps)
+    first = max(warmup, min(out_len - steps, out_len // 2 - steps // 2))  # output index of the first timed step
+    pre, post = first - warmup, out_len - first - steps
     gi = torch.Generator().manual_seed(42)
     ids = torch.randint(3, a.vocab, (B, S), generator=gi, dtype=torch.int32).to(dev)
     lens = torch.full((B,), S, dtype=torch.int32, device=dev)
     total = S + out_len
     out_ids = torch.empty((B, 1, total), dtype=torch.int32, device=dev)
     seq = torch.empty((B, 1), dtype=torch.int32, device=dev)
+    cum = torch.empty((B, 1), dtype=torch.float32, device=dev)
     top_k = np.array([1], np.int32)
     minlen = np.array([out_len], np.int32)  # end_id cannot be sampled: all steps run
 
@@ -187,7 +214,8 @@ def main():
         fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, olen, 1
         fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
         fa.min_length, fa.n_min_length = minlen.ctypes.data, 1
-        fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+        fa.return_cum_log_probs = 1  # codefuse_example.py:745
+        fa.output_ids, fa.sequence_lengths, fa.cum_log_probs = out_ids.data_ptr(), seq.data_ptr(), cum.data_ptr()
         return fa
 
     L = capi.lib()
@@ -195,6 +223,12 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def run_steps(n):
+        if n > 0:
+            done = C.c_int(0)
+            capi.check(L.ftcf_gptneox_step(op._h, n, C.byref(done)))
+            assert done.value == n, f"only {done.value} of {n} steps ran"
 
     # ---- untimed: one short request to warm every kernel / allocation ----
     fa = make_args(out_len)
@@ -208,17 +242,16 @@ def main():
     capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))  # 1024-token prefill through the real context path
     torch.cuda.synchronize()
     prefill_wall_ms = (time.perf_counter() - tp0) * 1e3
-    done = C.c_int(0)
-    capi.check(L.ftcf_gptneox_step(op._h, a.warmup, C.byref(done)))
-    assert done.value == a.warmup
+    run_steps(pre)
+    run_steps(warmup)
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    capi.check(L.ftcf_gptneox_step(op._h, a.steps, C.byref(done)))
+    run_steps(steps)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    assert done.value == a.steps, f"only {done.value} of {a.steps} steps ran"
+    run_steps(post)
     capi.check(L.ftcf_gptneox_finish(op._h))
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -226,8 +259,8 @@ def main():
     elapsed = float(elapsed.item())
     st = op.stats()
 
-    # ---- end-to-end latency of the whole request (prefill + 512 tokens), the reference README's metric ----
-    e2e_ms = None
+    # ---- end-to-end latency of the whole request (prefill + out_len tokens), the reference README's metric ----
+    e2e_ms = e2e_decode_tok_s = None
     if not a.no_e2e:
         torch.cuda.synchronize()
         barrier()
@@ -236,17 +269,24 @@ def main():
         torch.cuda.synchronize()
         barrier()
         e2e_ms = (time.perf_counter() - t2) * 1e3
+        se = op.stats()
+        e2e_decode_tok_s = se["decode_steps"] * B / (se["decode_ms"] * 1e-3) if se["decode_ms"] > 0 else None
 
     # ---- roofline leg: HIP events around every weight-streaming launch of a short profiled run ----
     KIND_NAMES = {0: "k_ln_gemv_group (LN1 -> QKV weight stream)", 1: "k_gemv_chunked (out-proj + FFN2 weight stream)",
                   2: "k_lm_head", 3: "k_mmha_ln_gemv (attention || LN2 -> FFN1 weight stream)",
-                  4: "k_decode_persistent (all layers of one token: weights + KV cache)"}
+                  4: "k_decode_persistent (all layers of one token: weights + KV cache)",
+                  5: "k_gemm_smallm_burst (batched decode: two weight matrices per launch, read once for all rows)"}
     roof = None
     if a.profile_steps > 0:
-        op.set_profiling(True)
+        # the profiled steps sit at the same place of the request as the timed window (same KV lengths)
+        nprof = min(a.profile_steps, out_len)
+        pfirst = max(0, min(out_len - nprof, out_len // 2 - nprof // 2))
         fa2 = make_args(out_len)
         capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa2)))
-        capi.check(L.ftcf_gptneox_step(op._h, a.profile_steps, None))
+        run_steps(pfirst)
+        op.set_profiling(True)
+        run_steps(nprof)
         capi.check(L.ftcf_gptneox_finish(op._h))
         ps = op.stats()
         op.set_profiling(False)
@@ -258,7 +298,8 @@ def main():
             # the counters cannot ride along with this timing run); only quoted when it was measured on this very config
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_int8_tp1.json")))
+                import glob
+                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1]))
                 c = pm["config"]
                 if (ps["gemv_kind"] == 4 and a.dtype == c["dtype"] and world == c["tensor_parallel"] and a.layers == c["layers"]
                         and H == c["hidden"] and a.inter == c["inter"] and a.batch == 1):
@@ -267,18 +308,20 @@ def main():
                 pass
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": traffic, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
-                    "launches": ps["gemv_launches"], "measured_over": f"{a.profile_steps} profiled decode steps"}
+                    "launches": ps["gemv_launches"],
+                    "measured_over": f"{nprof} profiled decode steps (output tokens {pfirst}..{pfirst + nprof - 1}), "
+                                     "HIP events on the engine's stream around every launch of that kernel"}
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    tok_s = a.steps * B / elapsed
-    t_mean = S + a.warmup + a.steps / 2.0
-    bpt = bytes_per_token(a, tp, t_mean)
+    tok_s = steps * B / elapsed
+    t_mean = S + first + steps / 2.0  # mean KV length of the timed steps
+    bpt = bytes_per_token(a, tp, t_mean)  # HBM bytes of ONE step (weights once, K/V rows of all B rows)
     res = {
-        "metric": "decode_tokens_per_sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "metric": "decode_tokens_per_sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong",
         # the reference's README quotes 75 tok/s (1xA100) / 98 tok/s (2xA100 TP=2) for int8, 48 / 77 fp16
         "vs_baseline": (tok_s / {("int8", 1): 75.0, ("int8", 2): 98.0, ("fp16", 1): 48.0, ("fp16", 2): 77.0}[(a.dtype, world)]
                         if (a.dtype, world) in (("int8", 1), ("int8", 2), ("fp16", 1), ("fp16", 2))
@@ -287,22 +330,29 @@ def main():
         "config": {"workload": f"CodeFuse-13B-shaped GPT-NeoX (L={a.layers},H={H},I={a.inter},V={a.vocab}) "
                                f"{'weight-only int8' if a.dtype == 'int8' else 'fp16'} TP={tp}, bs={B}, "
                                f"{S}-in/{out_len}-out greedy decode", "weights": a.dtype, "tensor_parallel": tp,
-                   "batch": B, "prompt_len": S, "output_len": out_len},
+                   "batch": B, "prompt_len": S, "output_len": out_len, "return_cum_log_probs": 1,
+                   "timed_window": f"output tokens {first}..{first + steps - 1} of the {S}-in/{out_len}-out request "
+                                   f"(KV length {S + first}..{S + first + steps - 1}, mean {t_mean:g}; request mean "
+                                   f"{S + out_len / 2:g}); {pre} + {warmup} steps before and {post} after run untimed"},
         "prefill_ms": st["prefill_ms"], "prefill_wall_ms": prefill_wall_ms, "e2e_ms": e2e_ms,
+        "e2e_decode_tokens_per_sec": e2e_decode_tok_s,  # all out_len tokens of the end-to-end run (HIP events)
         # context phase: 2*(4H^2+2HI)*L*S*B GEMM flops + 2*L*S^2*H*B causal attention flops, per GPU, vs the 2.5 PFLOP/s
         # dense fp16 MFMA peak (MI355X_MICROARCH.md)
         "prefill_tflops_per_gpu": ((2.0 * (4.0 * H * H + 2.0 * H * a.inter) * a.layers * S * B
                                     + 2.0 * a.layers * S * S * H * B) / tp) / (st["prefill_ms"] * 1e-3) / 1e12,
         "prefill_mfma_frac": ((2.0 * (4.0 * H * H + 2.0 * H * a.inter) * a.layers * S * B
                                + 2.0 * a.layers * S * S * H * B) / tp) / (st["prefill_ms"] * 1e-3) / 2.5e15,
-        "hbm_bytes_per_token_per_gpu": bpt,
-        "path_roofline_frac": bpt * tok_s / 8e12,  # whole-token HBM roofline (8 TB/s), incl. KV + fp16 LM head
+        "hbm_bytes_per_step_per_gpu": bpt,
+        # whole-step HBM roofline (8 TB/s), incl. KV + fp16 LM head: bytes of one step x steps per second
+        "path_roofline_frac": bpt * (tok_s / B) / 8e12,
         "roofline": roof,
     }
     if a.fake_tp > 1:
         res["invalid"] = f"--fake-tp {a.fake_tp}: one rank of a TP={a.fake_tp} job without its peers (timing aid only)"
         res["vs_baseline"] = None
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.dtype != "int8":
+        res["cpu_baseline"] = {"skipped": "the CPU leg holds the model as int8 + fp32 scales (13 GB); run --dtype int8"}
+    elif world == 1 and not a.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(a)
         except Exception as e:  # the oracle is only a reported baseline

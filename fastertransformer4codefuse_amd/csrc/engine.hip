@@ -368,7 +368,7 @@ struct Carver {
     }
 };
 
-enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND_PERSIST = 4, KIND_COUNT = 5 };
+enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND_PERSIST = 4, KIND_SMALLM = 5, KIND_COUNT = 6 };
 
 }  // namespace
 
@@ -412,7 +412,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
-    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
+    int                 persist = 1, persist_per_layer = 0, persist_nb = 0;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -525,7 +525,10 @@ struct ftcf_gptneox {
             // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
             // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
             if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (cfg.tensor_para_size == 1 || persist_per_layer)) {
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb);
+                if (pplan.ok && !persist_resident(pplan, int8, B, dh, num_cu)) {
+                    pplan = PersistPlan{};  // not every workgroup would be resident: the hand-offs could never complete
+                }
             }
             if (pplan.ok) {
                 ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
@@ -776,11 +779,13 @@ struct ftcf_gptneox {
                     // at tensor-parallel shard sizes): [QKV, FFN1] -> MMHA -> [out-proj, FFN2]
                     const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
                                               {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
-                    launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, stream);
+                    timed(KIND_SMALLM, wbytes * H * (3.0 * hl + il),
+                          [&] { launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, stream); });
                     launch_mmha(mp, stream);
                     const SmallmDesc p3[2] = {{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl},
                                               {mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}};
-                    launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream);
+                    timed(KIND_SMALLM, wbytes * H * ((double)hl + il),
+                          [&] { launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream); });
                 }
                 else {
                     gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
@@ -1517,12 +1522,6 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_PERSIST_NB")) {
             e->persist_nb = atoi(m);
-        }
-        if (const char* m = getenv("FTCF_PERSIST_CS1")) {
-            e->persist_cs1 = atoi(m);
-        }
-        if (const char* m = getenv("FTCF_PERSIST_CS3")) {
-            e->persist_cs3 = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_TP_GRAPH")) {

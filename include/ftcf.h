@@ -185,7 +185,7 @@ typedef struct {
     long  gemv_launches;
     double gemv_bytes;     /* algorithmic weight bytes those launches streamed */
     int   gemv_kind;       /* which launch kind those three describe: 0 LN->QKV, 1 out-proj+FFN2, 2 LM head,
-                              3 MMHA||FFN1, 4 persistent decode layers */
+                              3 MMHA||FFN1, 4 persistent decode layers, 5 batched-decode burst GEMM pair */
     int   decode_path;     /* decoder of the last request: 0 per-stage launches, 1 persistent layers (one launch per
                               token, or per layer with tensor parallelism), 2 general (batched GEMM) path */
 } ftcf_forward_stats;

@@ -89,10 +89,30 @@ int orc_num_threads(void)
     return omp_get_max_threads();
 }
 
-float orc_round_half(float x)
+/* the software conversion above is the definition; where the host has F16C (every AVX2 machine) the hardware
+ * conversion -- round to nearest even, subnormals, overflow to inf: the same function, checked value by value in
+ * tests/test_oracle_quant.py -- replaces it, which makes the m = 1 GEMVs of the CPU baseline ~10x faster */
+float orc_round_half_soft(float x)
 {
     return orc_half_bits_to_float(orc_float_to_half_bits(x));
 }
+#if defined(__F16C__)
+#include <immintrin.h>
+static inline float orc_round_half_inl(float x)
+{
+    return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+}
+float orc_round_half(float x)
+{
+    return orc_round_half_inl(x);
+}
+#define orc_round_half(x) orc_round_half_inl(x)
+#else
+float orc_round_half(float x)
+{
+    return orc_round_half_soft(x);
+}
+#endif
 
 #define RT(x) (fp16 ? orc_round_half(x) : (x))
 #define HALF_FLT_MAX 65504.f

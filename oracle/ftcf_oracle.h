@@ -76,7 +76,8 @@ typedef struct {
 
 /* ---- scalar helpers ---- */
 int      orc_num_threads(void);
-float    orc_round_half(float x);
+float    orc_round_half(float x);      /* F16C where available, else the software conversion */
+float    orc_round_half_soft(float x); /* the software conversion (definition) */
 uint16_t orc_float_to_half_bits(float x);
 float    orc_half_bits_to_float(uint16_t h);
 float    orc_uniform(uint64_t seed, uint64_t row, uint64_t draw);   /* (0,1] */

@@ -60,6 +60,8 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_round_half.restype = C.c_float
         _lib.orc_round_half.argtypes = [C.c_float]
+        _lib.orc_round_half_soft.restype = C.c_float
+        _lib.orc_round_half_soft.argtypes = [C.c_float]
         _lib.orc_uniform.restype = C.c_float
         _lib.orc_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         _lib.orc_generate.restype = C.c_int

@@ -72,3 +72,145 @@ def test_full_size_properties(full, monkeypatch):
             break
     # prompt tokens come back unchanged, generated ids are in range
     assert np.array_equal(t1[0, :S], ids1.cpu().numpy()[0]) and (t1[0, S:] >= 0).all() and (t1[0, S:] < V).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 2: CodeFuse-13B fp16, TP=1, bs=1, 1024-in (25 GB of fp16 weights + their tiled copies)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_fp16_properties(monkeypatch):
+    from fastertransformer4codefuse_amd import capi
+    from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
+    capi.require_gpu()
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(layers=40, heads=40, head_dim=128, inter=20480, vocab=100864, rotary=32, dtype="fp16")
+    weights, int8_w, scales = bench.synth_weights(a, 1, torch.device("cuda", 0))
+    mk = lambda: GptNeoXOp(None, 0, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, 2, 1, 1, 0, 2048, True,
+                           weights, int8_w, scales)
+    V, S, out = a.vocab, 1024, 5
+    g = torch.Generator().manual_seed(43)
+    ids1 = torch.randint(3, V, (1, S), generator=g, dtype=torch.int32).cuda()
+    op = mk()
+    t1, l1 = _run(op, ids1, out, V)
+    assert op.stats()["decode_path"] == 1  # the fp16 instantiation of the persistent kernel at H = 5120
+    t2, l2 = _run(op, ids1, out, V)
+    assert np.array_equal(t1, t2) and np.array_equal(l1, l2)
+    assert np.isfinite(l1).all()
+    del op
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("FTCF_PERSIST", "0")
+    op0 = mk()
+    t0, l0 = _run(op0, ids1, out, V)
+    assert op0.stats()["decode_path"] == 0
+    scale = np.abs(l1).max()
+    for t in range(out):
+        assert np.abs(l0[t, 0] - l1[t, 0]).max() <= 5e-3 * scale, (t, np.abs(l0[t, 0] - l1[t, 0]).max() / scale)
+        if t0[0, S + t] != t1[0, S + t]:
+            top2 = np.sort(l1[t, 0])[-2:]
+            assert top2[1] - top2[0] <= 5e-3 * scale, "paths disagree without a near tie"
+            break
+    assert np.array_equal(t1[0, :S], ids1.cpu().numpy()[0]) and (t1[0, S:] >= 0).all() and (t1[0, S:] < V).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's single-GPU regime: int8, bs=16, 256-in (general path: burst GEMMs, batched attention / LM head)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_bs16_properties(full):
+    a = full[0]
+    V, S, out = a.vocab, 256, 4
+    g = torch.Generator().manual_seed(44)
+    ids = torch.randint(3, V, (4, S), generator=g, dtype=torch.int32)
+    ids16 = ids.repeat(4, 1).contiguous().cuda()  # rows r and r + 4k hold the same prompt
+    op = _op(full)
+    tb, lb = _run(op, ids16, out, V)
+    assert op.stats()["decode_path"] == 2
+    tb2, lb2 = _run(op, ids16, out, V)
+    assert np.array_equal(tb, tb2) and np.array_equal(lb, lb2)  # deterministic (in-launch split-K merge is ordered)
+    for r in range(4):
+        for k in range(1, 4):  # identical rows of one batch: bit-identical results
+            assert np.array_equal(tb[r], tb[r + 4 * k]) and np.array_equal(lb[:, r], lb[:, r + 4 * k])
+    # the same prompts one at a time (persistent bs = 1 kernel) against their rows of the batch
+    for r in range(2):
+        t1, l1 = _run(op, ids16[r:r + 1], out, V)
+        scale = np.abs(l1).max()
+        for t in range(out):
+            err = np.abs(lb[t, r] - l1[t, 0]).max()
+            assert err <= 5e-3 * scale, (r, t, err / scale)
+            if tb[r, S + t] != t1[0, S + t]:
+                top2 = np.sort(l1[t, 0])[-2:]
+                assert top2[1] - top2[0] <= 5e-3 * scale
+                break
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The oracle at the 13B layer shape: two layers of H = 5120 / I = 20480 (the oracle finishes those in seconds) on the same
+# kind of synthetic weights, every decode path of the engine against the oracle's logits
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["int8", "fp16"])
+def test_13b_layer_shape_against_oracle(dtype, monkeypatch):
+    import ctypes as C
+    from fastertransformer4codefuse_amd import capi
+    from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
+    from oracle import oracle as orc
+    capi.require_gpu()
+    sys.path.insert(0, ROOT)
+    import bench
+    Lc, V = 2, 2048
+    a = argparse.Namespace(layers=Lc, heads=40, head_dim=128, inter=20480, vocab=V, rotary=32, dtype=dtype)
+    H, I = 5120, 20480
+    weights, int8_w, scales = bench.synth_weights(a, 1, torch.device("cuda", 0))
+    f = lambda t: t.float().cpu().numpy()
+    layers = []
+    for l in range(Lc):
+        W = lambda gidx: weights[gidx * Lc + l]
+        lay = dict(ln1_b=f(W(0)), ln1_g=f(W(1)), qkv_b=f(W(3)), ffn1_b=f(W(7)), ffn2_b=f(W(9)), ln2_b=f(W(10)),
+                   ln2_g=f(W(11)))
+        for i, (name, (K, N)) in enumerate(dict(qkv=(H, 3 * H), out=(H, H), ffn1=(H, I), ffn2=(I, H)).items()):
+            if dtype == "int8":
+                qt = int8_w[i * Lc + l].cpu().contiguous()
+                q_rm = torch.empty((K, N), dtype=torch.int8)
+                capi.check(capi.lib().ftcf_int8_tiled_to_rowmajor(capi.vp(qt), C.c_size_t(K), C.c_size_t(N), capi.vp(q_rm)))
+                lay[name + "_q"], lay[name + "_s"] = q_rm.numpy(), f(scales[i * Lc + l])
+            else:
+                lay[name + "_w"] = f(W((2, 4, 6, 8)[i]))
+        layers.append(lay)
+    glob = dict(wte=f(weights[12 * Lc]), final_ln_g=f(weights[12 * Lc + 1]), final_ln_b=f(weights[12 * Lc + 2]),
+                lm_head=f(weights[12 * Lc + 3]))
+    cfg = dict(head_num=40, size_per_head=128, inter_size=I, num_layer=Lc, vocab_size=V, rotary_dim=32, end_id=2,
+               int8_mode=1 if dtype == "int8" else 0, fp16=1)
+    m = orc.Model(cfg, layers, glob)
+    S, out = 24, 3
+    g = torch.Generator().manual_seed(45)
+    ids = torch.randint(3, V, (2, S), generator=g, dtype=torch.int32)
+    ref = m.generate(ids.numpy(), [S, S], out, return_logits=True)
+    scale = np.abs(ref["logits"]).max()
+    mk = lambda: GptNeoXOp(None, 0, 40, 128, I, Lc, V, 32, 0, 2, 1, 1, 1 if dtype == "int8" else 0, 2048, True, weights,
+                           int8_w, scales)
+
+    def check(tok, lg, rows, what):
+        for j, r in enumerate(rows):
+            for t in range(out):
+                err = np.abs(lg[t, j] - ref["logits"][t, r]).max() / scale
+                assert err <= 1e-2, (what, r, t, err)  # layer outputs at the 13B shape: rtol 1e-2 of the logit range
+                if tok[j, S + t] != ref["output_ids"][r, S + t]:
+                    top2 = np.sort(ref["logits"][t, r])[-2:]
+                    assert top2[1] - top2[0] <= 1e-2 * scale, (what, "token flip without a near tie")
+                    break
+
+    op = mk()
+    t1, l1 = _run(op, ids[:1].cuda(), out, V)  # persistent kernel, one row
+    assert op.stats()["decode_path"] == 1
+    check(t1, l1, [0], "persistent m=1")
+    t2, l2 = _run(op, ids.cuda(), out, V)  # persistent kernel, two rows
+    assert op.stats()["decode_path"] == 1
+    check(t2, l2, [0, 1], "persistent m=2")
+    ids16 = ids.repeat(8, 1).contiguous().cuda()
+    t16, l16 = _run(op, ids16, out, V)  # general path: burst GEMMs at m = 16
+    assert op.stats()["decode_path"] == 2
+    check(t16[:2], l16[:, :2], [0, 1], "general m=16")
+    del op
+    monkeypatch.setenv("FTCF_PERSIST", "0")
+    op0 = mk()
+    t0, l0 = _run(op0, ids[:1].cuda(), out, V)  # per-stage launches (the TP > 1 single-row path)
+    assert op0.stats()["decode_path"] == 0
+    check(t0, l0, [0], "per-stage m=1")

@@ -45,22 +45,38 @@ def quant(w_np):
     return q, s
 
 
-@pytest.mark.parametrize("m", [1, 2, 3, 4, 8, 33, 177])
-@pytest.mark.parametrize("n,k", [(1024, 4096), (2048, 8192)])
-def test_fpA_intB_gemm_matches_reference_formula(m, n, k):
+_GRID_CACHE = {}
+
+
+def _grid_weights(n, k):
+    """one quantised N(0, 0.002) matrix per (n, k) of the reference's grid, shared by all m"""
+    if (n, k) not in _GRID_CACHE:
+        _GRID_CACHE.clear()  # (a 16384 x 4096 fp32 matrix is 268 MB: keep one)
+        g = torch.Generator().manual_seed(734876213 + n * 7 + k)
+        w = (torch.randn(k, n, generator=g) * 0.002).half().float().numpy()
+        q, s = quant(w)
+        q_rm, s_o = orc.symmetric_quantize_int8(w, True)
+        _GRID_CACHE[(n, k)] = (q.cuda(), s.cuda(), q_rm, s_o)
+    return _GRID_CACHE[(n, k)]
+
+
+# th_gemm_dequantize.py:111-115: the reference's whole grid (compute_m x compute_n x compute_k); k = 16384 is the long-K /
+# split-K accumulation case, m covers the GEMV (1..4), burst (<= 16) and tiled MFMA (> 16) forms incl. ragged row counts
+@pytest.mark.parametrize("k", [4096, 8192, 16384])
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_fpA_intB_gemm_matches_reference_formula(n, k):
     # th_gemm_dequantize.py:65-115: weights N(0, 0.002), rtol 1e-3 / atol 2e-3 vs matmul(act, q.to(fp16) * scale)
-    torch.manual_seed(734876213)
-    w = (torch.randn(k, n) * 0.002).half().float().numpy()
-    q, s = quant(w)
-    q_rm, s_o = orc.symmetric_quantize_int8(w, True)
-    act = torch.randn(m, k).half()
-    ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, fp16=True)
-    out = torch.empty((m, n), dtype=torch.float16, device="cuda")
-    A = act.cuda()
-    capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(D(q)), capi.vp(D(s)), None, 0, capi.vp(out),
-                                             m, n, k, sp()))
-    torch.cuda.synchronize()
-    torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3)
+    qd, sd, q_rm, s_o = _grid_weights(n, k)
+    for m in (256, 177, 195, 125, 66, 33, 8, 2, 1, 3, 4, 16):
+        g = torch.Generator().manual_seed(m * 1000003 + n + k)
+        act = torch.randn(m, k, generator=g).half()
+        ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, fp16=True)
+        out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        A = act.cuda()
+        capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(qd), capi.vp(sd), None, 0, capi.vp(out),
+                                                 m, n, k, sp()))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3, msg=lambda t: f"m={m}: {t}")
 
 
 @pytest.mark.parametrize("m", [4, 128])

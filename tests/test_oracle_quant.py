@@ -93,3 +93,23 @@ def test_uniform_is_in_half_open_interval_and_deterministic():
     assert min(u) > 0.0 and max(u) <= 1.0
     assert u[:5] == [orc.lib().orc_uniform(7, 3, i) for i in range(5)]
     assert abs(np.mean(u) - 0.5) < 0.05
+
+
+def test_hardware_half_rounding_is_the_software_definition():
+    """oracle/ftcf_oracle.c uses the F16C conversion where the host has it; the software round-to-nearest-even
+    conversion is the definition.  Every class of value: normals, half subnormals, ties, overflow, inf, nan, signed 0."""
+    import ctypes as C
+    lib = orc.lib()
+    rng = np.random.RandomState(7)
+    vals = np.concatenate([
+        rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.randint(-9, 6, 20000).astype(np.float32),
+        np.float32([0.0, -0.0, 65504.0, 65519.99, 65520.0, 65536.0, 1e9, -1e9, np.inf, -np.inf, 2.0 ** -14, 2.0 ** -24,
+                    2.0 ** -25, 2.0 ** -25 * 1.0000001, 2.0 ** -26, 5.9604645e-08, 6.1035156e-05, 1.0 + 2.0 ** -11,
+                    1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -11 + 2.0 ** -20]),
+        (np.arange(0, 2049, dtype=np.float32) + 0.5) * np.float32(2.0 ** -24),  # ties between half subnormals
+    ])
+    for v in vals:
+        a, b = lib.orc_round_half(C.c_float(v)), lib.orc_round_half_soft(C.c_float(v))
+        assert a == b and np.signbit(a) == np.signbit(b), (v, a, b)
+    nan = lib.orc_round_half(C.c_float(np.nan))
+    assert np.isnan(nan) and np.isnan(lib.orc_round_half_soft(C.c_float(np.nan)))
