@@ -412,7 +412,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
-    int                 persist = 1, persist_per_layer = 0, persist_nb = 0;
+    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -525,7 +525,7 @@ struct ftcf_gptneox {
             // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
             // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
             if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (cfg.tensor_para_size == 1 || persist_per_layer)) {
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb);
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
                 if (pplan.ok && !persist_resident(pplan, int8, B, dh, num_cu)) {
                     pplan = PersistPlan{};  // not every workgroup would be resident: the hand-offs could never complete
                 }
@@ -1522,6 +1522,12 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_PERSIST_NB")) {
             e->persist_nb = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_CS1")) {
+            e->persist_cs1 = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_CS3")) {
+            e->persist_cs3 = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_TP_GRAPH")) {

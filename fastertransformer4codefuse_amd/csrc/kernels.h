@@ -172,11 +172,12 @@ struct PersistPlan {
     int    ok;        // 0: shape not eligible (caller uses the per-kernel path)
     int    NB;        // workgroups (<= CUs)
     int    nsplit;    // split-KV factor of the attention stage
-    int    uk;        // K / V wave-loads per lane of the attention stage (8: <= 256 keys per split, 16: <= 512)
+    int    uk;        // K / V wave-loads per lane of the attention stage (8: <= 256 keys per split, 12: <= 384)
     int    PA, PB;    // K pieces per 16-column group of out-proj / FFN2
     int    RLa, RLb;  // tiles per piece
     int    xs_halves; // LDS x region
-    int    nbmax;     // batches (of 8 tiles of one run) in the longer of a workgroup's two stage queues
+    int    e1, e3;    // tile-table entries per wave (P1 / P3)
+    int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
     size_t smem;
 };
 struct PersistParams {
@@ -199,7 +200,8 @@ struct PersistParams {
     float               eps;
     long long*          ts;          // optional [NB][L][8 waves][16] wall-clock stamps (100 MHz), or NULL
 };
-PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb);
+PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
+                         int cs1, int cs3);
 // every workgroup of the plan's grid resident at once on this device?  (also raises the kernel's dynamic-LDS limit there)
 bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu);
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);

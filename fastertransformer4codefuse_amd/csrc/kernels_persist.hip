@@ -40,9 +40,9 @@ constexpr int PS_RMAX     = 24;          // runs per workgroup and stage
 constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
 constexpr int PS_MAXP     = 16;          // PA + PB
 constexpr int PS_SPIN     = 1 << 18;
-constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane (256 keys per workgroup at dh = 128) ...
-constexpr int PS_UK_LONG  = 16;          // ... or 16 (512 keys) for requests whose KV split does not fit 256.  The rows live
-                                         // in the weight stream's four register batches, which are idle during the attention
+constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane (256 keys per workgroup) ...
+constexpr int PS_UK_LONG  = 12;          // ... or 12 (384 keys) for requests whose KV split does not fit 256: a second
+                                         // instantiation, because the 8-deep form scores 1 % better where both fit
 #ifndef PS_FULL_P1_V
 #define PS_FULL_P1_V false
 #endif
@@ -53,16 +53,16 @@ constexpr int PS_UK_LONG  = 16;          // ... or 16 (512 keys) for requests wh
 constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
 constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
 
+typedef const PersistLayer PsLayerC;
+#define PS_LAYER(p, l) ((p).layers[l])
 #define PS_RLX __ATOMIC_RELAXED
 #define PS_AGT __HIP_MEMORY_SCOPE_AGENT
 // pointers that come out of the per-layer table in memory are GLOBAL: say so (a flat access also counts on lgkmcnt)
 #define PS_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
 
-// Batch descriptor (one per PS_U consecutive k tiles of ONE run; 8 bytes in LDS):
-//   low  word : index of the first tile inside its weight array
-//   high word : bit 0 weight array of the stage, 1 x row stride select, 2 wait for the late x vector (ctx), 3..7 run,
-//               8..24 LDS half offset of the first tile's x, 25..28 valid tiles (0: padding batch, never consumed)
-constexpr unsigned PS_BD_SEL = 1u, PS_BD_XSEL = 2u, PS_BD_WAIT = 4u;
+// batch-table entry (one per PS_U tiles of ONE run, consecutive k): bit 0 valid, 1 flush after the batch, 2..6 run,
+// 8..24 LDS half offset of the first tile's x, 25 x stride select, 26 wait for the late x vector, 27..30 valid tiles
+constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25, PS_BT_WAIT = 1u << 26;
 
 struct RunRec {  // static per launch (LDS)
     int tile0;  // first tile of the run inside its weight array
@@ -72,16 +72,8 @@ struct RunRec {  // static per launch (LDS)
     int xsel;   // x row stride select
     int rid;    // stage specific id (P1: combined group, P3: global piece id)
     int grp;    // 16-column group
-    int b0;     // first batch of the run in the stage's batch queue (the run has (nt + PS_U - 1) / PS_U batches)
-    // how the run's result is published (static per launch, so that the publishing code inside the stream loop needs no
-    // kernel parameters: everything it captures would stay live -- and spill -- across the whole loop)
-    u64* dst;      // granule of (row 0, column 0)
-    int  mstride;  // granules between the rows of x (pairs of halves) -- unused for fp32 pieces
-    int  kind;     // PS_PUB_*
+    int pad;
 };
-constexpr int PS_PUB_PLAIN = 0;  // f16(y), pairs of halves          (qkv: the attention adds the bias)
-constexpr int PS_PUB_GELU  = 1;  // gelu(y + bias), pairs of halves  (mid)
-constexpr int PS_PUB_F32   = 2;  // fp32 partial sums, one granule per value, [M][16] (K pieces)
 
 __device__ __forceinline__ int ps_rfl(int v)
 {
@@ -145,142 +137,113 @@ __device__ __forceinline__ void ps_sweep(const u64* g, const int n, const int ti
     }
 }
 
+// wave w's share of T tiles: control waves get cs/16 of a streamer wave's share and sit at the END of the flat space
+// (P3 puts the out-proj pieces there: the control waves are the ones that wait for ctx anyway).  Shares start at whole
+// batches, so that with run lengths that are multiples of PS_U every batch lies inside one run.
+__host__ __device__ inline void ps_wave_range(const int T, const int w, const int cs, int& tb, int& te)
+{
+    const int total = PS_NC * cs + (PS_NW - PS_NC) * 16;
+    const int c0    = (w >= PS_NC) ? (w - PS_NC) * 16 : (PS_NW - PS_NC) * 16 + w * cs;
+    const int c1    = c0 + ((w < PS_NC) ? cs : 16);
+    tb              = (int)((long)T * c0 / total) / PS_U * PS_U;
+    te              = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
+}
+// table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
+template<typename NT>
+__host__ __device__ inline int ps_wave_entries(const int nruns, NT&& run_nt, const int tb, const int te)
+{
+    int e = 0, pre = 0;
+    for (int j = 0; j < nruns; j++) {
+        const int nt = run_nt(j);
+        const int a = tb > pre ? tb : pre, b = te < pre + nt ? te : pre + nt;
+        if (b > a) {
+            e += (b - a + PS_U - 1) / PS_U * PS_U;
+        }
+        pre += nt;
+    }
+    return e;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// Weight stream of a workgroup over one stage.  The stage's tiles are cut into BATCHES of PS_U consecutive k tiles of one
-// run (8 KiB of contiguous weights per wave-batch); the batches form a QUEUE in LDS (descriptor table + head counter)
-// that the eight waves drain dynamically: a wave claims its next batch with one LDS atomic when it issues the loads, i.e.
-// PS_NBUF - 1 batches ahead of consuming it.  Static per-wave shares ended up to 7 us apart inside a workgroup (the CU's
-// memory pipeline serves whoever issued first, and the control waves join late by design); with the queue every wave
-// stops within one batch of the others and there is no share to tune.
-// Each batch accumulates into its own fp32 slot part[batch][M*16]; the wave that completes the LAST batch of a run
-// (per-run LDS counter) sums the run's slots in batch order -- deterministic whoever computed them -- and PUBLISHES the
-// run (qkv / mid / K-piece granules) at once: hand-offs leave as soon as their run is done (qkv after ~1/3 of P1), not
-// after an end-of-stage barrier and epilogue.
-// Every load in the loop is unconditional (a claim past the end of the queue maps to a padding descriptor whose 8 loads
-// read one 16-byte word): the compiler counts vmcnt exactly and three batches stay in flight while one is consumed.
+// Weight stream of one wave over its share [tb, te) of the workgroup's flat tile space, driven by two per-wave LDS
+// tables: lt[i] = {weight array select, tile index}, ct[i] = {x offset, run, flush, valid}.  PS_NBUF register batches
+// of PS_U tiles rotate; the tables are padded to a whole number of rotations with entries that re-read tile 0 of the
+// stage (an L2 / MALL hit, never HBM) and are not consumed, so the loop has NO conditional load: the compiler counts
+// vmcnt exactly and three batches stay in flight while one is consumed.  The accumulator is flushed to
+// part[run][wave] after the last tile of the wave's piece of a run (a wave meets a run in ONE contiguous piece).
 // ---------------------------------------------------------------------------------------------------------------
 struct PsStage {
-    const u64*    bt;  // [nb + 1] batch descriptors; entry nb is the padding batch
-    int           nb;
-    int*          qh;  // queue head (LDS)
-    int*          rc;  // [runs] completed batches per run (LDS)
-    const RunRec* rt;
-    const char *  w0, *w1;
-    int           xs0, xs1;
+    const unsigned *lt, *bt;  // per tile: {array select, tile index}; per batch: descriptor (see PS_BT_*)
+    int             nrot;  // rotations (PS_NBUF batches each), >= 1
+    const char *    w0, *w1;
+    int             xs0, xs1;
 };
 
 template<bool INT8, int M>
 struct PsStream {
     static constexpr int TK = TileK<INT8>::value;
+    u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
+    f32x4      acc;
     PsStage    g;
     const f16* rsc;
     const f16* xs;
     float*     part;
     const int* flag;    // LDS arrival counter of the second x vector
     int        target;  // value it reaches when that vector is staged
-    const f16* bias;    // [runs][16] bias of the PS_PUB_GELU runs (LDS)
-    unsigned   tag;     // granule tag of this layer
-    int        lane, lane16;
-    int        i0, i1, i2, i3;      // queue index of the batch in R0..R3
-    unsigned   h0, h1, h2, h3;      // and the high word of its descriptor
+    int        lane, wid;
 
     __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx,
-                                         const f16* bias_, const unsigned tag_, const int* flag_ = nullptr,
-                                         const int target_ = 0)
+                                         const int* flag_ = nullptr, const int target_ = 0)
     {
         flag   = flag_;
         target = target_;
-        bias   = bias_;
-        tag    = tag_;
-        g      = g_;
-        rsc    = rsc_;
-        xs     = xs_;
-        part   = part_;
-        lane   = tx & 63;
-        lane16 = lane * 16;
-        i0 = i1 = i2 = i3 = g_.nb;
-        h0 = h1 = h2 = h3 = 0u;
+        g    = g_;
+        rsc  = rsc_;
+        xs   = xs_;
+        part = part_;
+        lane = tx & 63;
+        wid  = ps_rfl(tx >> 6);
+        acc  = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // claim the next batch of the queue and request its tiles
-    __device__ __forceinline__ void issue(u32x4 (&r)[PS_U], int& idx, unsigned& dhi)
+    __device__ __forceinline__ void load(u32x4 (&r)[PS_U], const int i)
     {
-        int i = 0;
-        if (lane == 0) {
-            i = __hip_atomic_fetch_add(g.qh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        i           = ps_rfl(i);
-        i           = i < g.nb ? i : g.nb;
-        const u64 d = g.bt[i];
-        const unsigned lo = (unsigned)ps_rfl((int)(unsigned)d), hi = (unsigned)ps_rfl((int)(unsigned)(d >> 32));
-        const unsigned cnt  = (hi >> 25) & 15u;
-        const char*    base = (hi & PS_BD_SEL) ? g.w1 : g.w0;
-        const unsigned voff = cnt ? (unsigned)lane16 : 0u;  // padding batch: all lanes read the same 16 bytes (one line)
-        const unsigned last = cnt ? cnt - 1u : 0u;
 #pragma unroll
         for (int u = 0; u < PS_U; u++) {
-            const unsigned uu = (unsigned)u < last ? (unsigned)u : last;  // tiles past the run's end re-read its last one
+            const unsigned e    = g.lt[i * PS_U + u];
+            const char*    base = (e >> 31) ? g.w1 : g.w0;
             r[u] = __builtin_nontemporal_load(
-                (const __attribute__((address_space(1))) u32x4*)(base + (size_t)(lo + uu) * TILE_BYTES + voff));
-        }
-        idx = i;
-        dhi = hi;
-    }
-    // The wave that completed a run's last batch: sum of the run's batch slots in batch order (deterministic whoever
-    // computed them), epilogue, granules.  qkv = y (no bias: the attention adds it, like the reference's MMHA),
-    // mid = gelu(y + b) (epilogue_helpers.h:52-62 fused fp32 form for int8, activation_kernels.cu:401-426 half form for
-    // fp16 weights), K pieces = fp32 partial sums.
-    __device__ __forceinline__ void publish(const int j)
-    {
-        const RunRec* rr   = g.rt + j;
-        const int     b0   = ps_rfl(rr->b0), nbj = (ps_rfl(rr->nt) + PS_U - 1) / PS_U, kind = ps_rfl(rr->kind);
-        const int     r    = lane < M * 16 ? lane : 0;
-        float         v    = 0.f;
-        for (int b = 0; b < nbj; b++) {
-            v += part[(size_t)(b0 + b) * (M * 16) + r];
-        }
-        u64* dst = rr->dst;
-        if (kind == PS_PUB_F32) {
-            if (lane < M * 16) {
-                st_granule(dst + lane, tag, v);
-            }
-            return;
-        }
-        const int m = r >> 4, c = r & 15;
-        f16       o = (f16)v;
-        if (kind == PS_PUB_GELU) {
-            const f16 bb = bias[j * 16 + c];
-            if constexpr (INT8) {
-                o = (f16)gelu_f32(v + (float)bb);
-            }
-            else {
-                o = gelu_f16((f16)v + bb);
-            }
-        }
-        const unsigned x0 = f16_bits(o);
-        const unsigned x1 = __shfl_down(x0, 1, 64);
-        if (lane < M * 16 && (c & 1) == 0) {
-            st_granule_u32(dst + (size_t)m * ps_rfl(rr->mstride) + (c >> 1), tag, x0 | (x1 << 16));
+                (const __attribute__((address_space(1))) u32x4*)(base + ((size_t)(e & 0x7fffffffu) * 64 + lane) * 16));
         }
     }
-    __device__ __forceinline__ void consume(const u32x4 (&r)[PS_U], const int idx, const unsigned hi)
+    __device__ __forceinline__ void flush(const int j)
     {
-        const unsigned cnt = (hi >> 25) & 15u;
-        if (cnt == 0u) {
+        if (lane < 16) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                part[((size_t)j * PS_NW + wid) * (M * 16) + m * 16 + lane] = acc_row(acc, m);
+            }
+        }
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void consume(const u32x4 (&r)[PS_U], const int i)
+    {
+        const unsigned bd = (unsigned)ps_rfl((int)g.bt[i]);
+        if (!(bd & PS_BT_FAST)) {
             return;  // padding batch
         }
-        if (hi & PS_BD_WAIT) {  // rare: only a batch that reaches the late vector before it is staged actually spins
+        if (bd & PS_BT_WAIT) {  // rare: only the first batch of a wave that touches the late vector actually spins
             while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)flag) < target) {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        const int  j   = (int)((hi >> 3) & 31u);
-        const f16* xr  = a_frag_ptr<INT8, M>(xs + ((hi >> 8) & 0x1ffffu), (hi & PS_BD_XSEL) ? g.xs1 : g.xs0, lane);
+        const int  j   = (bd >> 2) & 31;
+        const int  cnt = (bd >> 27) & 15;
+        const f16* xr  = a_frag_ptr<INT8, M>(xs + ((bd >> 8) & 0x1ffffu), (bd & PS_BT_XSEL) ? g.xs1 : g.xs0, lane);
         f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
         if constexpr (INT8) {
             const f16 sc = rsc[j * 16 + (lane & 15)];
             sc2          = f16x2{sc, sc};
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (cnt == PS_U) {  // straight-line code like the per-kernel GEMV stream
 #pragma unroll
             for (int u = 0; u < PS_U; u++) {
@@ -290,124 +253,130 @@ struct PsStream {
         else {
 #pragma unroll
             for (int u = 0; u < PS_U; u++) {
-                if ((unsigned)u < cnt) {
+                if (u < cnt) {
                     consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
                 }
             }
         }
-        if (lane < 16) {
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                part[((size_t)idx * M + m) * 16 + lane] = acc_row(acc, m);
-            }
-        }
-        // the slot is written before the run's counter moves (DS operations of a wave execute in order; the fences only
-        // keep the compiler from reordering them and wait on lgkmcnt), so whoever sees the final count sees every slot
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        int old = 0;
-        if (lane == 0) {
-            old = __hip_atomic_fetch_add(&g.rc[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        old = ps_rfl(old);
-        const int nbj = (ps_rfl(g.rt[j].nt) + PS_U - 1) / PS_U;
-        if (old == nbj - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            publish(j);
+        if (bd & PS_BT_FLUSH) {
+            flush(j);
         }
     }
     // the first rotation: issued before the hand-off this stage waits for.  The streamer waves issue only half of it
     // there and the rest when they start consuming: a 192 KiB burst per CU sits in FRONT of the control waves' sweeps in
     // the CU's memory pipeline and stretched each hand-off hop to 6-7 us (measured)
-    __device__ __forceinline__ void prime_lo(u32x4 (&R0)[PS_U], u32x4 (&R1)[PS_U])
+    __device__ __forceinline__ void prime_lo()
     {
-        issue(R0, i0, h0);
-        issue(R1, i1, h1);
+        load(R0, 0);
+        load(R1, 1);
     }
-    __device__ __forceinline__ void prime_hi(u32x4 (&R2)[PS_U], u32x4 (&R3)[PS_U])
+    __device__ __forceinline__ void prime_hi()
     {
-        issue(R2, i2, h2);
-        issue(R3, i3, h3);
+        load(R2, 2);
+        load(R3, 3);
+    }
+    __device__ __forceinline__ void prime()
+    {
+        prime_lo();
+        prime_hi();
     }
     // HI: the second half of the first rotation is still to be issued.  Compile time: a load under a run-time condition
     // makes the compiler's vmcnt bookkeeping conservative for the whole stream (measured: 340 -> 192 tokens/s)
     template<bool HI>
-    __device__ __forceinline__ void run(u32x4 (&R0)[PS_U], u32x4 (&R1)[PS_U], u32x4 (&R2)[PS_U], u32x4 (&R3)[PS_U])
+    __device__ __forceinline__ void run()
     {
         if constexpr (HI) {
-            prime_hi(R2, R3);
+            prime_hi();
             __builtin_amdgcn_sched_barrier(0);
         }
-        // claims are handed out in order, so the most recent one (i3 after a full rotation) tells whether the queue has
-        // run dry; the up to three padding batches issued on the way out cost eight one-line loads each
-        while (i3 < g.nb) {
-            consume(R0, i0, h0);
+        const int last = (g.nrot - 1) * PS_NBUF;
+        for (int i = 0; i < last; i += PS_NBUF) {
+            consume(R0, i);
             __builtin_amdgcn_sched_barrier(0);
-            issue(R0, i0, h0);
+            load(R0, i + 4);
             __builtin_amdgcn_sched_barrier(0);
-            consume(R1, i1, h1);
+            consume(R1, i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            issue(R1, i1, h1);
+            load(R1, i + 5);
             __builtin_amdgcn_sched_barrier(0);
-            consume(R2, i2, h2);
+            consume(R2, i + 2);
             __builtin_amdgcn_sched_barrier(0);
-            issue(R2, i2, h2);
+            load(R2, i + 6);
             __builtin_amdgcn_sched_barrier(0);
-            consume(R3, i3, h3);
+            consume(R3, i + 3);
             __builtin_amdgcn_sched_barrier(0);
-            issue(R3, i3, h3);
+            load(R3, i + 7);
             __builtin_amdgcn_sched_barrier(0);
         }
-        consume(R0, i0, h0);
-        consume(R1, i1, h1);
-        consume(R2, i2, h2);
-        consume(R3, i3, h3);
+        consume(R0, last);
+        consume(R1, last + 1);
+        consume(R2, last + 2);
+        consume(R3, last + 3);
     }
 };
 
-// The batch queue of a stage from the workgroup's static run table (runs in queue order, RunRec::b0 set): one thread per
-// batch.  Entry nb is the padding batch (the workgroup's first tile of the stage: one address per workgroup, no hot spot).
+// One wave fills its tables for a stage from the workgroup's static run table: every piece of a run the wave owns is
+// padded to whole batches (padding tiles re-read the wave's own first tile -- one shared address would be a hot spot --
+// and are never consumed), so a batch never spans two runs.  One lane per batch.
 template<int TK>
-__device__ __forceinline__ void ps_build_queue(const RunRec* rt, const int nruns, u64* bt, const int nb, const bool gate_sel1)
+__device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
+                                                unsigned* lt, unsigned* bt, const int entries)
 {
-    for (int bi = threadIdx.x; bi <= nb; bi += PS_NT) {
-        u64 d = 0;
-        if (bi == nb) {
-            d = (u64)(unsigned)(nruns > 0 ? rt[0].tile0 : 0) | ((u64)(unsigned)(nruns > 0 ? rt[0].sel : 0) << 32);
-        }
-        else {
-            for (int j = 0; j < nruns; j++) {
-                const RunRec r   = rt[j];
-                const int    nbj = (r.nt + PS_U - 1) / PS_U;
-                if (bi >= r.b0 && bi < r.b0 + nbj) {
-                    const int      t   = (bi - r.b0) * PS_U;
-                    const int      cnt = (r.nt - t < PS_U) ? r.nt - t : PS_U;
-                    const unsigned hi  = (r.sel ? PS_BD_SEL : 0u) | (r.xsel ? PS_BD_XSEL : 0u)
-                                        | ((gate_sel1 && r.xsel) ? PS_BD_WAIT : 0u) | ((unsigned)j << 3)
-                                        | ((unsigned)(r.xoff + t * TK) << 8) | ((unsigned)cnt << 25);
-                    d = (u64)(unsigned)(r.tile0 + t) | ((u64)hi << 32);
-                }
+    const int lane = threadIdx.x & 63;
+    // the wave's first tile (padding address): uniform
+    unsigned pad = 0u;
+    {
+        int pre = 0;
+        for (int j = 0; j < nruns; j++) {
+            const int nt = rt[j].nt;
+            if (tb < te && tb >= pre && tb < pre + nt) {
+                pad = ((unsigned)rt[j].sel << 31) | (unsigned)(rt[j].tile0 + tb - pre);
             }
+            pre += nt;
         }
-        bt[bi] = d;
+    }
+    for (int bi = lane; bi < entries / PS_U; bi += 64) {
+        // locate batch bi: pieces of the runs intersecting [tb, te), each padded to whole batches
+        int      pre = 0, eb = 0;  // tiles before run j, batches before run j's piece
+        unsigned bd  = 0u;
+        int      first = 0, cnt = 0, sel = 0;
+        for (int j = 0; j < nruns; j++) {
+            const RunRec r  = rt[j];
+            const int    a  = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
+            const int    nb = b > a ? (b - a + PS_U - 1) / PS_U : 0;
+            if (bi >= eb && bi < eb + nb) {
+                const int t   = a + (bi - eb) * PS_U;
+                const int off = t - pre;
+                cnt   = (b - t < PS_U) ? b - t : PS_U;
+                first = r.tile0 + off;
+                sel   = r.sel;
+                bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
+                     | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
+                     | ((unsigned)cnt << 27);
+            }
+            eb += nb;
+            pre += r.nt;
+        }
+        for (int u = 0; u < PS_U; u++) {
+            lt[bi * PS_U + u] = (u < cnt) ? (((unsigned)sel << 31) | (unsigned)(first + u)) : pad;
+        }
+        bt[bi] = bd;
     }
 }
 
 struct PsSmem {
     f16*      xraw;  // [M][H]
     f16*      xs;    // x region (P1: LN1(x) | LN2(x) ; P3: mid | ctx)
-    float*    part;  // [max(nb1, nb3)][M*16] one fp32 slot per batch
+    float*    part;  // [RMAX][NW][M*16]
     char*     att;   // attention scratch
     RunRec*   rt1;   // [RMAX] P1 runs
     RunRec*   rt3;   // [RMAX] P3 runs
     f16*      rsc;   // [RMAX][16] scales of the current stage
-    f16*      b1;    // [RMAX][16] FFN1 bias of the P1 runs
     float*    red;   // 64
-    int*      misc;  // 128: [0] nmerge, [1..8] merge groups, [32] ctx arrivals, [33] control pair barrier,
-                     //      [34] / [35] queue heads of P1 / P3, [64..64+RMAX) / [96..96+RMAX) run counters of P1 / P3
-    u64 *     bt1, *bt3;  // [nb1 + 1], [nb3 + 1]
+    int*      misc;  // 64: [0] nmerge, [1..8] merge groups
+    unsigned *lt1, *lt3;  // [NW][e1], [NW][e3]
+    unsigned *bt1, *bt3;  // [NW][e1 / PS_U], [NW][e3 / PS_U]
 };
-constexpr int PS_MISC_INTS = 128, PS_QH1 = 34, PS_QH3 = 35, PS_RC1 = 64, PS_RC3 = 96;
-static_assert(PS_RMAX <= 32, "run counters");
 
 __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 {
@@ -425,18 +394,14 @@ template<int DH, int UK>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
     static constexpr int KPI = 64 / LPK;
-    static_assert(UK <= 2 * PS_U, "K rows live in R0|R1, V rows in R2|R3");
+    u32x4 kreg[UK], vreg[UK];
     unsigned mask_bits, bias2;
     int      tl, chunk, t_beg;
     float    rot_cs, rot_sn;
     bool     fin;
 
-    // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table.
-    // The rows go into the weight stream's register batches (K: R0 | R1, V: R2 | R3), which are idle between the end of a
-    // wave's P1 stream and its first P3 batch: no registers of their own, so they can be requested as soon as the wave
-    // leaves the P1 queue -- before the workgroup barrier and the P3 set-up -- without spilling.
-    __device__ __forceinline__ void issue(const PersistParams& p, const PersistLayer& lw, int h, int b, int sp, const int tx,
-                                          u32x4 (&K0)[PS_U], u32x4 (&K1)[PS_U], u32x4 (&V0)[PS_U], u32x4 (&V1)[PS_U])
+    // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table
+    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx)
     {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
@@ -452,13 +417,13 @@ struct PsAttn {
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             t       = t < t_last ? t : t_last;
-            (u < PS_U ? K0[u % PS_U] : K1[u % PS_U]) = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
+            kreg[u] = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
         }
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             t       = t < t_last ? t : t_last;
-            (u < PS_U ? V0[u % PS_U] : V1[u % PS_U]) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+            vreg[u] = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
         }
         mask_bits = 0u;
         if (p.masked_tokens && sub == 0) {
@@ -516,9 +481,8 @@ struct PsAttn {
         }
     }
     // returns false when the row is finished (nothing published)
-    __device__ __forceinline__ bool compute(const PersistParams& p, const PersistLayer& lw, char* smem, u64* gout,
-                                            const unsigned tag, int h, int b, const int tx, const u32x4 (&K0)[PS_U],
-                                            const u32x4 (&K1)[PS_U], const u32x4 (&V0)[PS_U], const u32x4 (&V1)[PS_U])
+    __device__ __forceinline__ bool compute(const PersistParams& p, PsLayerC& lw, char* smem, u64* gout,
+                                            const unsigned tag, int h, int b, const int tx)
     {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
@@ -571,7 +535,7 @@ struct PsAttn {
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            const f16x8 kv = __builtin_bit_cast(f16x8, u < PS_U ? K0[u % PS_U] : K1[u % PS_U]);
+            const f16x8 kv = __builtin_bit_cast(f16x8, kreg[u]);
             float       a  = 0.f;
             a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
             a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
@@ -633,7 +597,7 @@ struct PsAttn {
             const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
                 const float pt = s_p[t - t_beg];
-                const f16x8 vv = __builtin_bit_cast(f16x8, u < PS_U ? V0[u % PS_U] : V1[u % PS_U]);
+                const f16x8 vv = __builtin_bit_cast(f16x8, vreg[u]);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     acc[j] = fmaf(pt, (float)vv[j], acc[j]);
@@ -745,6 +709,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     const int     KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK;
     const int     NT0 = 3 * Hl / 16, NG = H / 16;
     const int     PA = p.plan.PA, PB = p.plan.PB, RLa = p.plan.RLa, RLb = p.plan.RLb;
+    const int     E1 = p.plan.e1, E3 = p.plan.e3;
 
     PsSmem s;
     {
@@ -754,7 +719,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         s.xs = reinterpret_cast<f16*>(q);
         q += (size_t)p.plan.xs_halves * 2;
         s.part = reinterpret_cast<float*>(q);
-        q += (size_t)p.plan.nbmax * M * 16 * 4;
+        q += (size_t)PS_RMAX * PS_NW * M * 16 * 4;
         s.att = q;
         q += ps_att_bytes(DH, p.s_max, p.plan.nsplit);
         s.rt1 = reinterpret_cast<RunRec*>(q);
@@ -763,15 +728,17 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         q += sizeof(RunRec) * PS_RMAX;
         s.rsc = reinterpret_cast<f16*>(q);
         q += PS_RMAX * 16 * 2;
-        s.b1 = reinterpret_cast<f16*>(q);
-        q += PS_RMAX * 16 * 2;
         s.red = reinterpret_cast<float*>(q);
         q += 64 * 4;
         s.misc = reinterpret_cast<int*>(q);
-        q += PS_MISC_INTS * 4;
-        s.bt1 = reinterpret_cast<u64*>(q);
-        q += (size_t)(p.plan.nbmax + 1) * 8;
-        s.bt3 = reinterpret_cast<u64*>(q);
+        q += 64 * 4;
+        s.lt1 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E1 * 4;
+        s.lt3 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * E3 * 4;
+        s.bt1 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * (E1 / PS_U) * 4;
+        s.bt3 = reinterpret_cast<unsigned*>(q);
     }
     const int      step     = *p.d_step;
     const unsigned tag_base = (unsigned)step * 256u + 1u;
@@ -780,9 +747,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     }
 
     // ---- the workgroup's static share of the streaming stages ----
-    // P1: every workgroup owns a range of QKV column groups AND a range of FFN1 column groups; the QKV runs come first in
-    // its queue, so qkv is complete -- and published by whoever finishes a run's last batch -- after about a third of the
-    // stage, and the attention finds it waiting
+    // P1: every workgroup owns a range of QKV column groups AND a range of FFN1 column groups (QKV runs first in its run
+    // table: they are streamed first, so qkv is complete -- and published -- well before the stage ends)
     const int NF  = Il / 16;
     const int q0  = (int)((long)NT0 * bid / NB), q1 = (int)((long)NT0 * (bid + 1) / NB);
     const int f0  = (int)((long)NF * bid / NB), f1 = (int)((long)NF * (bid + 1) / NB);
@@ -792,8 +758,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
     const int nB = rB1 - rB0, nA = rA1 - rA0;
     const int nruns1 = nq + (f1 - f0), nruns3 = nB + nA;
     const int n_items = p.B * p.nh * p.plan.nsplit;
-    if (threadIdx.x < PS_MISC_INTS) {
-        s.misc[threadIdx.x] = 0;  // nmerge, ctx arrivals, control pair barrier, queue heads, run counters
+    if (threadIdx.x == 0) {
+        s.misc[0]  = 0;
+        s.misc[32] = 0;  // ctx arrival counter (+PS_NC per layer)
+        s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
     }
     __syncthreads();
     if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
@@ -809,10 +777,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         r.xsel   = 0;
         r.rid    = cg;
         r.grp    = g;
-        r.b0     = j * ((KT + PS_U - 1) / PS_U);
-        r.dst     = seg ? p.gm + ((size_t)g * 16 >> 1) : p.gq + ((size_t)cg * 16 >> 1);
-        r.mstride = seg ? Il / 2 : 3 * Hl / 2;
-        r.kind    = seg ? PS_PUB_GELU : PS_PUB_PLAIN;
+        r.pad    = 0;
         s.rt1[j] = r;
     }
     if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
@@ -845,25 +810,22 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             r.xsel       = 0;
             r.rid        = idx;
         }
-        r.grp     = g;
-        r.b0      = 0;
-        r.dst     = p.gp + (size_t)r.rid * (M * 16);
-        r.mstride = 0;
-        r.kind    = PS_PUB_F32;
-        s.rt3[j]  = r;
+        r.grp    = g;
+        r.pad    = 0;
+        s.rt3[j] = r;
     }
     __syncthreads();
     PsStage sg1{}, sg3{};
     int     mid_lo = 0, mid_hi = 0, ctx_lo = 0, ctx_hi = 0;  // K ranges (halves) of mid / ctx this workgroup consumes
     {
-        int  nb3 = 0;
+        int T1 = 0, T3 = 0;
+        for (int j = 0; j < nruns1; j++) {
+            T1 += s.rt1[j].nt;
+        }
         bool fb = true, fa = true;
-        for (int j = 0; j < nruns3; j++) {  // (every thread: uniform results, b0 written by thread 0)
+        for (int j = 0; j < nruns3; j++) {
             const RunRec r = s.rt3[j];
-            if (threadIdx.x == 0) {
-                s.rt3[j].b0 = nb3;
-            }
-            nb3 += (r.nt + PS_U - 1) / PS_U;
+            T3 += r.nt;
             if (r.sel == 0) {
                 const int lo = r.xoff, hi = r.xoff + r.nt * TK;
                 mid_lo = fb ? lo : (lo < mid_lo ? lo : mid_lo);
@@ -877,27 +839,34 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 fa     = false;
             }
         }
+        T1 = ps_rfl(T1);
+        T3 = ps_rfl(T3);
         mid_lo = ps_rfl(mid_lo);
         mid_hi = ps_rfl(mid_hi);
         ctx_lo = ps_rfl(ctx_lo);
         ctx_hi = ps_rfl(ctx_hi);
-        sg1.bt = s.bt1;
-        sg1.nb = ps_rfl(nruns1 * ((KT + PS_U - 1) / PS_U));
-        sg1.qh = &s.misc[PS_QH1];
-        sg1.rc = &s.misc[PS_RC1];
-        sg1.rt = s.rt1;
-        sg3.bt = s.bt3;
-        sg3.nb = ps_rfl(nb3);
-        sg3.qh = &s.misc[PS_QH3];
-        sg3.rc = &s.misc[PS_RC3];
-        sg3.rt = s.rt3;
+        const int w = ps_rfl(wid);
+        int       tb, te;
+        ps_wave_range(T1, w, p.plan.cs1, tb, te);
+        int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
+        sg1.lt   = s.lt1 + (size_t)w * E1;
+        sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
+        sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
+        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
+                            sg1.nrot * PS_U * PS_NBUF);
+        ps_wave_range(T3, w, p.plan.cs3, tb, te);
+        ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
+        sg3.lt   = s.lt3 + (size_t)w * E3;
+        sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
+        sg3.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+        sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
+        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
+                            sg3.nrot * PS_U * PS_NBUF);
         sg1.xs0 = sg1.xs1 = H + XPAD;  // LDS rows of x are padded: see XPAD
         sg3.xs0 = Il + XPAD;
         sg3.xs1 = Hl + XPAD;
     }
-    __syncthreads();  // rt3[].b0
-    ps_build_queue<TK>(s.rt1, nruns1, s.bt1, sg1.nb, false);
-    ps_build_queue<TK>(s.rt3, nruns3, s.bt3, sg3.nb, true);
     __syncthreads();
 
     // Control waves and streamer waves run SEPARATE instantiations of the layer loop (same barriers, in the same order):
@@ -907,7 +876,6 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         constexpr bool    CTRL = decltype(role)::value;
         int               tid  = threadIdx.x;
         PsStream<INT8, M> st;
-        u32x4             R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];  // weight batches; K / V rows during the attention
         auto stamp = [&](const int l, const int k) {
             const int lane = tid & 63, wid = tid >> 6;
             if (p.ts && lane == 0) {
@@ -916,41 +884,41 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         };
         // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
         f16   r_sc1 = (f16)1.f, r_sc3 = (f16)1.f;  // scale of (run tid/16, column tid%16) of P1 / P3
-        f16   r_b1 = (f16)0.f;                     // ffn1 bias of (run tid/16, column tid%16) of P1
-        f16   r_bres[2];                           // residual bias of the merge items
+        f16   r_b1[2], r_bres[2];                  // ffn1 bias of the P1 epilogue items / residual bias of the merge items
         f16x8 r_ln[4][PS_NLN];                     // ln1_g, ln1_b, ln2_g, ln2_b vectors tid, tid + 512
         auto  load_sc1 = [&](const int l) {
             if constexpr (INT8) {
-                r_sc1 = (f16)1.f;
                 if (tid < nruns1 * 16) {
-                    const PersistLayer& lw = p.layers[l];
+                    PsLayerC& lw = PS_LAYER(p, l);
                     const RunRec&       r  = s.rt1[tid >> 4];
                     r_sc1 = PS_G(f16, r.sel ? lw.s_ffn1 : lw.s_qkv)[r.grp * 16 + (tid & 15)];
                 }
             }
         };
         auto load_p1_consts = [&](const int l) {  // LN parameters, ffn1 bias, P3 scales of layer l
-            const PersistLayer& lw = p.layers[l];
-            // (unconditional, clamped: a conditional assignment would carry the previous layer's values -- 32 VGPRs --
-            // through the whole loop body, weight streams included)
+            PsLayerC& lw = PS_LAYER(p, l);
 #pragma unroll
             for (int k = 0; k < PS_NLN; k++) {
                 const int v = tid + k * PS_NT;
-                const int o = (v * 8 < H) ? v * 8 : 0;
-                r_ln[0][k]  = *PS_G(f16x8, lw.ln1_g + o);
-                r_ln[1][k]  = *PS_G(f16x8, lw.ln1_b + o);
-                r_ln[2][k]  = *PS_G(f16x8, lw.ln2_g + o);
-                r_ln[3][k]  = *PS_G(f16x8, lw.ln2_b + o);
+                if (v * 8 < H) {
+                    r_ln[0][k] = *PS_G(f16x8, lw.ln1_g + v * 8);
+                    r_ln[1][k] = *PS_G(f16x8, lw.ln1_b + v * 8);
+                    r_ln[2][k] = *PS_G(f16x8, lw.ln2_g + v * 8);
+                    r_ln[3][k] = *PS_G(f16x8, lw.ln2_b + v * 8);
+                }
             }
-            r_b1 = (f16)0.f;
-            if (tid < nruns1 * 16) {
-                const int cg = s.rt1[tid >> 4].rid;
-                if (cg >= NT0) {
-                    r_b1 = PS_G(f16, lw.b_ffn1)[(cg - NT0) * 16 + (tid & 15)];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int idx = tid + k * PS_NT;
+                r_b1[k]       = (f16)0.f;
+                if (idx < nruns1 * M * 16) {
+                    const int cg = s.rt1[idx / (M * 16)].rid;
+                    if (cg >= NT0) {
+                        r_b1[k] = PS_G(f16, lw.b_ffn1)[(cg - NT0) * 16 + (idx & 15)];
+                    }
                 }
             }
             if constexpr (INT8) {
-                r_sc3 = (f16)1.f;
                 if (tid < nruns3 * 16) {
                     const RunRec& r = s.rt3[tid >> 4];
                     r_sc3 = PS_G(f16, r.sel ? lw.s_out : lw.s_ffn2)[r.grp * 16 + (tid & 15)];
@@ -959,7 +927,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
         };
         auto load_p3_consts = [&](const int l) {  // residual bias of layer l, P1 scales of layer l + 1
             if constexpr (CTRL) {
-                const PersistLayer& lw = p.layers[l];
+                PsLayerC& lw = PS_LAYER(p, l);
                 const int           nm = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -970,53 +938,45 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                     }
                 }
             }
-            // (clamped, not conditional: values assigned under a condition are carried around the layer loop, i.e. stay live
-            // through both weight streams; after the last layer the loads are harmless re-reads)
-            load_sc1(l + 1 < p.l_end ? l + 1 : l);
+            if (l + 1 < p.l_end) {
+                load_sc1(l + 1);
+            }
         };
-        // per layer: scales of the stage's runs -> LDS, the OTHER stage's queue state back to zero (nobody is inside it:
-        // a workgroup barrier lies between its last use and here, and another one before its next use), bind the stream
+        // per layer: scales of the stage's runs -> LDS, zero the partial buffer, bind the stream
         auto setup_p1 = [&](const int l) {
-            const PersistLayer& lw = p.layers[l];
+            PsLayerC& lw = PS_LAYER(p, l);
             if constexpr (INT8) {
                 if (tid < nruns1 * 16) {
                     s.rsc[tid] = r_sc1;
                 }
             }
-            if (tid < PS_RMAX) {
-                s.misc[PS_RC3 + tid] = 0;
-            }
-            if (tid == PS_RMAX) {
-                s.misc[PS_QH3] = 0;
+            for (int i = tid; i < nruns1 * PS_NW * M * 16; i += PS_NT) {
+                s.part[i] = 0.f;
             }
             load_p1_consts(l);
             sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
             sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
-            st.bind(sg1, s.rsc, s.xs, s.part, tid, s.b1, tag_base + (unsigned)l);
+            st.bind(sg1, s.rsc, s.xs, s.part, tid);
             if constexpr (!CTRL) {
-                st.prime_lo(R0, R1);
+                st.prime_lo();
                 if constexpr (PS_FULL_P1) {
-                    st.prime_hi(R2, R3);
+                    st.prime_hi();
                 }
             }
         };
         auto setup_p3 = [&](const int l) {
-            const PersistLayer& lw = p.layers[l];
+            PsLayerC& lw = PS_LAYER(p, l);
             if constexpr (INT8) {
                 if (tid < nruns3 * 16) {
                     s.rsc[tid] = r_sc3;
                 }
             }
-            if (tid < PS_RMAX) {
-                s.misc[PS_RC1 + tid] = 0;
+            for (int i = tid; i < nruns3 * PS_NW * M * 16; i += PS_NT) {
+                s.part[i] = 0.f;
             }
-            if (tid == PS_RMAX) {
-                s.misc[PS_QH1] = 0;
-            }
-            load_p3_consts(l);
             sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
             sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
-            st.bind(sg3, s.rsc, s.xs, s.part, tid, s.b1, tag_base + (unsigned)l, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
+            st.bind(sg3, s.rsc, s.xs, s.part, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
         };
 
         load_sc1(p.l_begin);
@@ -1026,7 +986,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             // becomes dozens of long-lived VGPRs that spill around the register batches
             asm volatile("" : "+v"(tid));
             const int           lane = tid & 63, wid = tid >> 6;
-            const PersistLayer& lw  = p.layers[l];
+            PsLayerC& lw  = PS_LAYER(p, l);
             const unsigned      tag = tag_base + (unsigned)l;
             stamp(l, 0);
             // =========================== S0: layer input -> xraw (control waves) =================================
@@ -1101,16 +1061,53 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                         }
                     }
                 }
-                if (tid < nruns1 * 16) {
-                    s.b1[tid] = r_b1;  // (fetched in setup_p1, ahead of the prefetch: the oldest load in flight)
-                }
                 if constexpr (CTRL) {
-                    st.prime_lo(R0, R1);
+                    st.prime_lo();
                 }
                 stamp(l, 2);
                 __syncthreads();
-                st.template run<CTRL || !PS_FULL_P1>(R0, R1, R2, R3);
+                st.template run<CTRL || !PS_FULL_P1>();
                 stamp(l, 3);
+                __syncthreads();
+                // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int idx = tid + k * PS_NT;
+                    if (idx < nruns1 * M * 16) {
+                        const int j = idx / (M * 16), r = idx % (M * 16), m = r >> 4, c = r & 15;
+                        float     v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < PS_NW; w++) {
+                            v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                        }
+                        const int cg = s.rt1[j].rid;
+                        f16       o;
+                        if (cg < NT0) {
+                            o = (f16)v;
+                        }
+                        else {
+                            if constexpr (INT8) {
+                                o = (f16)gelu_f32(v + (float)r_b1[k]);  // epilogue_helpers.h:52-62
+                            }
+                            else {
+                                o = gelu_f16((f16)v + r_b1[k]);  // activation_kernels.cu:401-426
+                            }
+                        }
+                        const unsigned b0 = f16_bits(o);
+                        const unsigned b1 = __shfl_down(b0, 1, 64);
+                        if ((c & 1) == 0) {
+                            // (two stores, not one through a selected pointer: the compiler turns that select into a
+                            // table in scratch memory, and a kernel that uses scratch pays for it at every dispatch)
+                            if (cg < NT0) {
+                                st_granule_u32(p.gq + (((size_t)m * 3 * Hl + cg * 16 + c) >> 1), tag, b0 | (b1 << 16));
+                            }
+                            else {
+                                st_granule_u32(p.gm + (((size_t)m * Il + (cg - NT0) * 16 + c) >> 1), tag, b0 | (b1 << 16));
+                            }
+                        }
+                    }
+                }
+                stamp(l, 4);
             }
 
             // =========================== attention ===============================================================
@@ -1123,30 +1120,23 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                 const int hb = bid / p.plan.nsplit;
                 a_h          = hb % p.nh;
                 a_b          = hb / p.nh;
-                // the wave has left the P1 queue: its register batches are free, the K / V rows can be on their way while
-                // the other waves finish
-#ifndef PS_EXP_LATE_KV
-                at.issue(p, lw, a_h, a_b, a_sp, tid, R0, R1, R2, R3);
-#endif
             }
-            stamp(l, 4);
-            __syncthreads();  // every wave is out of P1: slots / scales / queue state can be reused
+            __syncthreads();  // part / scales reuse
             setup_p3(l);
             stamp(l, 5);
             bool live = false;
             u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
             if (has_item) {
-#ifdef PS_EXP_LATE_KV
-                at.issue(p, lw, a_h, a_b, a_sp, tid, R0, R1, R2, R3);
-#endif
+                // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
+                at.issue(p, lw, a_h, a_b, a_sp, tid);
                 at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
                 stamp(l, 6);
-                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, R0, R1, R2, R3);
+                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid);
             }
             if constexpr (CTRL) {
-                // the K range of mid this workgroup's FFN2 pieces read -> LDS.  Before the barrier, i.e. before the
-                // streamer waves' prefetch burst (a sweep queued behind the burst took 5 us), and after the attention
-                // (ahead of it, it made the attention wait for the slowest FFN1)
+                // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there).
+                // Before the barrier, i.e. before the streamer waves' prefetch burst (a sweep queued behind the burst
+                // took 5 us), and after the attention (ahead of it, it made the attention wait for the slowest FFN1)
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
@@ -1159,18 +1149,22 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
             __syncthreads();  // mid staged, attention scratch free
             stamp(l, 8);
             if constexpr (!CTRL) {
+                // (the constants of the layer's end -- residual bias, next layer's scales -- are fetched HERE and not in
+                // the P3 set-up: their table reads are synchronous round trips, and the set-up sits on the attention's
+                // critical path, ahead of the K/V request)
+                load_p3_consts(l);
                 // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
                 // and the control waves, which carry the attention's critical path, must not wait for it
-                st.prime_lo(R0, R1);  // the streamer waves issue no other load until the end of the P3 stream
+                st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
                 if constexpr (PS_FULL_P3) {
-                    st.prime_hi(R2, R3);
+                    st.prime_hi();
                 }
             }
             // =========================== P3: [FFN2 u out-proj] -> residual ========================================
             // The streamer waves start on the FFN2 pieces at once; the control waves finish the attention (merge of the
             // split partials by wave 0 of the split-0 workgroups), stage the K range of ctx the out-proj pieces read and
-            // announce it through an LDS counter that gates every batch touching ctx (those sit at the END of the queue),
-            // then join the queue.
+            // announce it through an LDS counter that gates every batch touching ctx; their own share is the END of the
+            // workgroup's tile space, i.e. the out-proj pieces.
             if constexpr (CTRL) {
                 if (has_item && a_sp == 0 && wid == 0) {
                     if (live) {
@@ -1189,23 +1183,43 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                                 });
                 }
                 stamp(l, 14);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                 if (lane == 0) {
                     atomicAdd(&s.misc[32], 1);  // DS operations of a wave execute in order: the writes above are visible
                 }
-                st.prime_lo(R0, R1);
+                load_p3_consts(l);
+                st.prime_lo();
             }
             stamp(l, 9);
-            st.template run<CTRL || !PS_FULL_P3>(R0, R1, R2, R3);
+            st.template run<CTRL || !PS_FULL_P3>();
             stamp(l, 10);
+            __syncthreads();
+            asm volatile("" : "+v"(tid));
+            // K pieces -> granules
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int idx = tid + k * PS_NT;
+                if (idx < nruns3 * M * 16) {
+                    const int j = idx / (M * 16), r = idx % (M * 16);
+                    float     v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < PS_NW; w++) {
+                        v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                    }
+                    st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
+                }
+            }
             const int  nmerge = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
             const bool last   = (l == p.l_end - 1);
             // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
             const int inplace = (l > 0 && l < p.L - 1) ? 1 : 0;
-            __syncthreads();  // every wave is out of P3: the streamer waves start the next layer's weight stream now
-            asm volatile("" : "+v"(tid));
-            // (unconditional, clamped -- see load_p3_consts: after the last layer this re-requests two batches of its weights)
-            setup_p1(l + 1 < p.l_end ? l + 1 : l);
+            __syncthreads();  // part / scales are free: the streamer waves start the next layer's weight stream now
+            // (the control waves carry the layer boundary's critical path -- pieces -> merge -> x' -> gather: they merge
+            // FIRST and fetch the next layer's constants afterwards, under the gather's wait)
+            if constexpr (!CTRL) {
+                if (l + 1 < p.l_end) {
+                    setup_p1(l + 1);
+                }
+            }
             stamp(l, 11);
             // merge the groups this workgroup owns (control waves) -> x'
             if constexpr (CTRL) {
@@ -1272,6 +1286,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
                     }
                 }
             }
+            if constexpr (CTRL) {
+                if (l + 1 < p.l_end) {
+                    setup_p1(l + 1);
+                }
+            }
             stamp(l, 12);
             // xraw is rewritten by the next layer's gather: only the two control waves touch it between here and the
             // barrier after that gather, so they synchronise among themselves (the streamer waves are busy issuing
@@ -1298,13 +1317,15 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int nbmax)
+static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3)
 {
-    return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)nbmax * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
-           + 2 * sizeof(RunRec) * PS_RMAX + 2 * PS_RMAX * 16 * 2 + 64 * 4 + PS_MISC_INTS * 4 + 2 * (size_t)(nbmax + 1) * 8;
+    return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)PS_RMAX * PS_NW * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
+           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (e1 + e3) * 4
+           + (size_t)PS_NW * (e1 + e3) / PS_U * 4;
 }
 
-PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb)
+PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
+                         int cs1, int cs3)
 {
     PersistPlan pl{};
     const int   M  = B;
@@ -1312,7 +1333,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (M < 1 || M > 2 || (dh != 64 && dh != 128) || H % TK || Hl % TK || Il % TK || H % 16 || Hl % 16 || Il % 16) {
         return pl;
     }
-    if (H > PS_NLN * PS_NT * 8) {
+    if (cs1 < 1 || cs1 > 16 || cs3 < 1 || cs3 > 16 || H > PS_NLN * PS_NT * 8) {
         return pl;
     }
     const int NB = force_nb > 0 ? force_nb : num_cu;
@@ -1332,6 +1353,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     pl.uk = chunk > PS_NW * (64 / (dh / 8)) * PS_UK ? PS_UK_LONG : PS_UK;
     // K pieces: best balanced tile count per workgroup
     double best = 1e30;
+    long   t3max = 0;
     for (int PA = 1; PA <= 8; PA *= 2) {
         for (int PB = 1; PB <= 16; PB *= 2) {
             if (PA + PB > PS_MAXP) {
@@ -1376,36 +1398,55 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
                 pl.PB  = PB;
                 pl.RLa = RLa;
                 pl.RLb = RLb;
+                t3max  = mx;
             }
         }
     }
     if (best > 1e29) {
         return pl;
     }
-    // batches per stage: the maximum over the workgroups (every run is padded to whole batches)
-    int nbmax = 1;
+    // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations
+    int e1 = 0, e3 = 0;
     for (int b = 0; b < NB; b++) {
         const int nr1 = (int)((long)NT0h * (b + 1) / NB) - (int)((long)NT0h * b / NB)
                         + (int)((long)NFh * (b + 1) / NB) - (int)((long)NFh * b / NB);
         const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
         const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);
-        int       nb3 = 0;
-        for (int i = rB0; i < rB1; i++) {
-            nb3 += (std::min(pl.RLb, KT_b - (i / NG) * pl.RLb) + PS_U - 1) / PS_U;
+        const int nB = rB1 - rB0, nA = rA1 - rA0;
+        auto nt1 = [&](int) { return KT; };
+        auto nt3 = [&](int j) {
+            if (j < nB) {
+                const int t0 = ((rB0 + j) / NG) * pl.RLb;
+                return std::min(pl.RLb, KT_b - t0);
+            }
+            const int t0 = ((rA0 + j - nB) / NG) * pl.RLa;
+            return std::min(pl.RLa, KT_a - t0);
+        };
+        int T3 = 0;
+        for (int j = 0; j < nB + nA; j++) {
+            T3 += nt3(j);
         }
-        for (int i = rA0; i < rA1; i++) {
-            nb3 += (std::min(pl.RLa, KT_a - (i / NG) * pl.RLa) + PS_U - 1) / PS_U;
+        for (int w = 0; w < PS_NW; w++) {
+            int tb, te;
+            ps_wave_range(nr1 * KT, w, cs1, tb, te);
+            e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
+            ps_wave_range(T3, w, cs3, tb, te);
+            e3 = std::max(e3, ps_wave_entries(nB + nA, nt3, tb, te));
         }
-        nbmax = std::max(nbmax, std::max(nr1 * ((KT + PS_U - 1) / PS_U), nb3));
     }
-    pl.nbmax      = nbmax;
+    const int rot = PS_U * PS_NBUF;
+    pl.e1         = std::max(rot, (e1 + rot - 1) / rot * rot);
+    pl.e3         = std::max(rot, (e3 + rot - 1) / rot * rot);
+    (void)t3max;
     pl.NB         = NB;
     pl.nsplit     = nsplit;
+    pl.cs1        = cs1;
+    pl.cs3        = cs3;
     pl.xs_halves  = M * std::max(2 * (H + XPAD), Il + Hl + 2 * XPAD);
     if (pl.xs_halves > 0x1ffff) {
         return pl;
     }
-    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.nbmax);
+    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3);
     if (pl.smem > 160 * 1024) {
         return pl;
     }
