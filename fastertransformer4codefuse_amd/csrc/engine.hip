@@ -8,7 +8,9 @@
 //   DecoderSelfAttentionLayer / FfnLayer / DynamicDecodeLayer are the launch helpers used by those.
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -71,9 +73,48 @@ static void require_device()
 // ---------------------------------------------------------------------------------------------------------------
 // communicator (RCCL over xGMI) -- utils/nccl_utils.cc:56-435, nccl_inherit_utils.cc:25-68
 // ---------------------------------------------------------------------------------------------------------------
+// A communicator is either an RCCL communicator (one process per GPU, the product) or a member of a LOCAL GROUP: the ranks
+// of a tensor-parallel job living in ONE process on ONE device, each driven by its own host thread (ftcf_comm_init_local).
+// The local group exists so that the engine's tensor-parallel path -- column / row sharding, the per-layer all-reduce, the
+// x / TP residual, the vocabulary split + all-gather + transpose, and the in-kernel exchange of the persistent decode
+// kernel -- can be executed and checked against TP = 1 and the oracle on a single-GPU box.  Its collectives are host
+// synchronous (stream sync + thread barrier + a summing / copying kernel): slow, deterministic, test infrastructure.
+struct LocalGroup {
+    int                     world = 0;
+    std::mutex              m;
+    std::condition_variable cv;
+    int                     arrived = 0;
+    long                    gen = 0;
+    std::vector<void*>      slot;   // per rank: the buffer it brought to the collective in progress
+    std::vector<void*>      win;    // per rank: exchange window (device memory), see ftcf_comm::window
+    std::vector<size_t>     win_bytes;
+    std::vector<const void*> item;  // per rank: an opaque pointer for the group launch of the persistent kernel
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const long g = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+        }
+        else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+
 struct ftcf_comm {
-    ncclComm_t comm = nullptr;
-    int        world = 1, rank = 0, device = 0;
+    ncclComm_t                  comm = nullptr;
+    std::shared_ptr<LocalGroup> local;
+    int                         world = 1, rank = 0, device = 0;
+    void*                       tmp = nullptr;  // local group: result buffer of the emulated all-reduce
+    size_t                      tmp_bytes = 0;
+    // in-kernel exchange windows of the persistent tensor-parallel decode kernel: win[r] = rank r's window as THIS rank
+    // addresses it (own memory for r == rank; a peer mapping -- hipIpc over xGMI -- or, in a local group, the same device)
+    std::vector<void*>          win;
+    size_t                      win_bytes = 0;
+    bool                        win_ok = false;
 };
 
 #define FTCF_NCCL_CHECK(expr)                                                                                          \
@@ -83,6 +124,120 @@ struct ftcf_comm {
             throw Error(FTCF_ERR_COMM, std::string("RCCL error ") + ncclGetErrorString(_r) + " (" #expr ")");          \
         }                                                                                                              \
     } while (0)
+
+// ---- local group collectives (test infrastructure, see above) ----
+__global__ void k_local_allreduce_f16(f16* out, const f16* const* src, int world, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < world; r++) {  // rank order, fp32, rounded once: the same value on every rank
+            a += (float)src[r][i];
+        }
+        out[i] = (f16)a;
+    }
+}
+__global__ void k_local_allreduce_f32(float* out, const float* const* src, int world, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < world; r++) {
+            a += src[r][i];
+        }
+        out[i] = a;
+    }
+}
+
+static void local_allreduce(ftcf_comm* c, void* buf, size_t count, bool fp16, hipStream_t s)
+{
+    LocalGroup& g   = *c->local;
+    const size_t esz = fp16 ? 2 : 4;
+    const size_t ptr_bytes = sizeof(void*) * (size_t)g.world;
+    if (c->tmp_bytes < count * esz + ptr_bytes + 256) {
+        if (c->tmp) {
+            FTCF_HIP_CHECK(hipFree(c->tmp));
+        }
+        c->tmp_bytes = count * esz + ptr_bytes + 256;
+        FTCF_HIP_CHECK(hipMalloc(&c->tmp, c->tmp_bytes));
+    }
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));  // my contribution is complete
+    g.slot[c->rank] = buf;
+    g.barrier();
+    char* ptrs = (char*)c->tmp + ((count * esz + 255) & ~(size_t)255);
+    FTCF_HIP_CHECK(hipMemcpyAsync(ptrs, g.slot.data(), ptr_bytes, hipMemcpyHostToDevice, s));
+    const int blocks = (int)std::min<size_t>(1024, (count + 255) / 256);
+    if (fp16) {
+        hipLaunchKernelGGL(k_local_allreduce_f16, dim3(blocks), dim3(256), 0, s, (f16*)c->tmp, (const f16* const*)ptrs,
+                           g.world, count);
+    }
+    else {
+        hipLaunchKernelGGL(k_local_allreduce_f32, dim3(blocks), dim3(256), 0, s, (float*)c->tmp,
+                           (const float* const*)ptrs, g.world, count);
+    }
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    g.barrier();  // every rank has read every buffer: they may be overwritten now
+    FTCF_HIP_CHECK(hipMemcpyAsync(buf, c->tmp, count * esz, hipMemcpyDeviceToDevice, s));
+}
+
+static void local_allgather(ftcf_comm* c, void* buf, size_t count_per_rank, bool fp16, hipStream_t s)
+{
+    LocalGroup& g   = *c->local;
+    const size_t seg = count_per_rank * (fp16 ? 2 : 4);
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    g.slot[c->rank] = buf;
+    g.barrier();
+    for (int r = 0; r < g.world; r++) {  // rank r's segment lives at offset r in ITS buffer (in-place convention)
+        if (r != c->rank) {
+            FTCF_HIP_CHECK(hipMemcpyAsync((char*)buf + (size_t)r * seg, (const char*)g.slot[r] + (size_t)r * seg, seg,
+                                          hipMemcpyDeviceToDevice, s));
+        }
+    }
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    g.barrier();
+}
+
+static std::mutex                                        g_local_mu;
+static std::map<std::string, std::weak_ptr<LocalGroup>> g_local_groups;
+static long                                              g_local_next = 1;
+
+extern "C" int ftcf_comm_local_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES])
+{
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(g_local_mu);
+        memset(id, 0, FTCF_UNIQUE_ID_BYTES);
+        snprintf((char*)id, FTCF_UNIQUE_ID_BYTES, "ftcf-local-group-%ld", g_local_next++);
+    });
+}
+
+extern "C" int ftcf_comm_init_local(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_size, int rank, int device,
+                                    ftcf_comm_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(out != nullptr && world_size >= 1 && rank >= 0 && rank < world_size, "bad communicator args");
+        require_device();
+        auto c    = std::make_unique<ftcf_comm>();
+        c->world  = world_size;
+        c->rank   = rank;
+        c->device = device;
+        {
+            std::lock_guard<std::mutex> lk(g_local_mu);
+            const std::string key((const char*)id, strnlen((const char*)id, FTCF_UNIQUE_ID_BYTES));
+            FTCF_CHECK_ARG(!key.empty(), "local group id is empty: call ftcf_comm_local_unique_id");
+            auto g = g_local_groups[key].lock();
+            if (!g) {
+                g        = std::make_shared<LocalGroup>();
+                g->world = world_size;
+                g->slot.assign(world_size, nullptr);
+                g->win.assign(world_size, nullptr);
+                g->win_bytes.assign(world_size, 0);
+                g->item.assign(world_size, nullptr);
+                g_local_groups[key] = g;
+            }
+            FTCF_CHECK_ARG(g->world == world_size, "local group: world size mismatch");
+            c->local = g;
+        }
+        *out = c.release();
+    });
+}
 
 extern "C" int ftcf_comm_get_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES])
 {
@@ -119,6 +274,12 @@ extern "C" int ftcf_comm_destroy(ftcf_comm_t c)
             if (c->comm) {
                 ncclCommDestroy(c->comm);
             }
+            if (c->tmp) {
+                (void)hipFree(c->tmp);
+            }
+            if (c->local && c->win_ok && c->rank < (int)c->win.size() && c->win[c->rank]) {
+                (void)hipFree(c->win[c->rank]);
+            }
             delete c;
         }
     });
@@ -127,7 +288,11 @@ extern "C" int ftcf_comm_destroy(ftcf_comm_t c)
 extern "C" int ftcf_comm_allreduce_sum(ftcf_comm_t c, void* buf, size_t count, ftcf_dtype dtype, void* stream)
 {
     return guarded([&] {
-        FTCF_CHECK_ARG(c && c->comm, "communicator not initialised");
+        FTCF_CHECK_ARG(c && (c->comm || c->local), "communicator not initialised");
+        if (c->local) {
+            local_allreduce(c, buf, count, dtype == FTCF_FP16, (hipStream_t)stream);
+            return;
+        }
         FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, dtype == FTCF_FP16 ? ncclFloat16 : ncclFloat32, ncclSum,
                                       c->comm, (hipStream_t)stream));
     });
@@ -136,7 +301,11 @@ extern "C" int ftcf_comm_allreduce_sum(ftcf_comm_t c, void* buf, size_t count, f
 extern "C" int ftcf_comm_allgather(ftcf_comm_t c, void* buf, size_t count_per_rank, ftcf_dtype dtype, void* stream)
 {
     return guarded([&] {
-        FTCF_CHECK_ARG(c && c->comm, "communicator not initialised");
+        FTCF_CHECK_ARG(c && (c->comm || c->local), "communicator not initialised");
+        if (c->local) {
+            local_allgather(c, buf, count_per_rank, dtype == FTCF_FP16, (hipStream_t)stream);
+            return;
+        }
         const size_t esz = dtype == FTCF_FP16 ? 2 : 4;
         // in place: rank r's data lives at buf + r*count (ftNcclAllGather, nccl_utils.cc:70-82)
         FTCF_NCCL_CHECK(ncclAllGather((const char*)buf + (size_t)c->rank * count_per_rank * esz, buf, count_per_rank,
@@ -600,7 +769,11 @@ struct ftcf_gptneox {
     void allreduce(f16* buf, size_t count)
     {
         if (cfg.tensor_para_size > 1) {
-            FTCF_CHECK_ARG(cfg.comm && cfg.comm->comm, "tensor_para_size > 1 needs a communicator");
+            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local), "tensor_para_size > 1 needs a communicator");
+            if (cfg.comm->local) {
+                local_allreduce(cfg.comm, buf, count, true, stream);
+                return;
+            }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, stream));
         }
     }
@@ -1241,7 +1414,12 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
             float* mine = gather + (size_t)cfg.tensor_para_rank * B * vl;
             timed(KIND_LM_HEAD, 2.0 * vl * H,
                   [&] { lm(lm_head + (size_t)cfg.tensor_para_rank * vl * H, mine, vl, vl); });
-            FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
+            if (cfg.comm->local) {
+                local_allgather(cfg.comm, gather, (size_t)B * vl, false, stream);
+            }
+            else {
+                FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
+            }
             hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, stream, logits, gather, tp, B, vl);
         }
         if (a.debug_logits) {
@@ -1275,7 +1453,7 @@ int ftcf_gptneox::step(int max_steps)
         const bool with_decoder = !(S > 1 && step == S);
         // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
         // has been validated on a multi-GPU node (this round's boxes have one GPU)
-        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || tp_graph) && !a.debug_logits;
+        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local)) && !a.debug_logits;
         if (graph_ok) {
             if (!ses.graph_exec) {
                 // capture ONE regular decode step (all pointers are fixed for the session, the step counter lives

@@ -23,12 +23,27 @@ def _check_input(t, name, dtype=None):
         raise RuntimeError(f"{name} has invalid dtype {t.dtype}, expected {dtype}")
 
 
+class LocalTensorParallelGroup:
+    """Test infrastructure: the ranks of a tensor-parallel job inside ONE process on ONE device (one host thread per rank,
+    see include/ftcf.h `ftcf_comm_init_local`).  Pass one shared instance as `comm` to every rank's GptNeoXOp."""
+
+    def __init__(self):
+        ids = np.zeros(capi.UNIQUE_ID_BYTES, dtype=np.uint8)
+        capi.check(capi.lib().ftcf_comm_local_unique_id(ids.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self.id = ids
+
+
 def init_tensor_parallel_comm(group, rank, world_size, device):
     """Counterpart of nccl_inherit::ftNcclInitialize (th_op/gptneox/utils/nccl_inherit_utils.cc:25-68).
 
     The reference reaches into ProcessGroupNCCL's protected broadcastUniqueNCCLID through a reinterpret_cast
     (`HackGroupNCCL`); here rank 0 creates the RCCL unique id and it travels as a plain byte tensor through the
     caller's process group (any backend)."""
+    if isinstance(group, LocalTensorParallelGroup):
+        comm = C.c_void_p()
+        capi.check(capi.lib().ftcf_comm_init_local(group.id.ctypes.data_as(C.POINTER(C.c_uint8)), world_size, rank, device,
+                                                   C.byref(comm)))
+        return comm
     import torch.distributed as dist
     ids = np.zeros(capi.UNIQUE_ID_BYTES, dtype=np.uint8)
     if os.environ.get("FTCF_FAKE_TP") == "1":

@@ -112,6 +112,11 @@ typedef struct ftcf_comm*    ftcf_comm_t;
 int ftcf_comm_get_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES]);
 int ftcf_comm_init(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_size, int rank, int device, ftcf_comm_t* comm);
 int ftcf_comm_destroy(ftcf_comm_t comm);
+/* LOCAL GROUP (test infrastructure): the ranks of a tensor-parallel job inside ONE process on ONE device, each driven by
+ * its own host thread.  Same engine code path as RCCL ranks (sharding, per-layer all-reduce, vocabulary split, in-kernel
+ * exchange); the collectives are host-synchronous.  Lets a single-GPU box execute and check tensor_para_size > 1. */
+int ftcf_comm_local_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES]);
+int ftcf_comm_init_local(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_size, int rank, int device, ftcf_comm_t* comm);
 /* ftNcclAllReduceSum / ftNcclAllGather (in place, fp16 / fp32) exposed for tests */
 int ftcf_comm_allreduce_sum(ftcf_comm_t comm, void* buf, size_t count, ftcf_dtype dtype, void* stream);
 int ftcf_comm_allgather(ftcf_comm_t comm, void* buf, size_t count_per_rank, ftcf_dtype dtype, void* stream);

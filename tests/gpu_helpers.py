@@ -13,11 +13,12 @@ def dev(a, dtype=torch.float16):
 
 
 def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True):
-    """cfg: dict like tests.helpers ; w: reference-order list of float32 numpy arrays (full, TP=1 layout)."""
+    """cfg: dict like tests.helpers ; w: reference-order list of float32 numpy arrays -- the full TP=1 layout, or with
+    tp > 1 the shard of `rank` (tests.helpers.shard_weights)."""
     L = cfg["num_layer"]
     H = cfg["head_num"] * cfg["size_per_head"]
     I = cfg["inter_size"]
-    shapes = {2: (H, 3 * H), 4: (H, H), 6: (H, I), 8: (I, H)}
+    shapes = {2: (H, 3 * H // tp), 4: (H // tp, H), 6: (H, I // tp), 8: (I // tp, H)}
     weights, int8_w, scales = [], [None] * (4 * L), [None] * (4 * L)
     for g in range(12):
         for l in range(L):
