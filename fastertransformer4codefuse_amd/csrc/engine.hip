@@ -114,7 +114,7 @@ struct ftcf_comm {
     // addresses it (own memory for r == rank; a peer mapping -- hipIpc over xGMI -- or, in a local group, the same device)
     std::vector<void*>          win;
     size_t                      win_bytes = 0;
-    bool                        win_ok = false;
+    bool                        win_ok = false, win_tried = false;
 };
 
 #define FTCF_NCCL_CHECK(expr)                                                                                          \
@@ -193,6 +193,200 @@ static void local_allgather(ftcf_comm* c, void* buf, size_t count_per_rank, bool
     }
     FTCF_HIP_CHECK(hipStreamSynchronize(s));
     g.barrier();
+}
+
+// ---- exchange windows of the persistent tensor-parallel decode kernel ----------------------------------------------
+// One window per rank, written by every rank from inside its kernel (system-scope granule stores) and polled by the owner:
+//   local group : plain device memory, the peers' pointers come through the group;
+//   RCCL ranks  : fine-grained device memory exported with hipIpcGetMemHandle, the handles travel through an RCCL
+//                 all-gather, peers map them with hipIpcOpenMemHandle (xGMI peer access), and a hand-shake kernel proves
+//                 on THIS hardware that a granule stored by a peer's kernel becomes visible to a polling kernel here --
+//                 any failure on any rank (agreed on through an all-reduce) leaves win_ok false on EVERY rank and the
+//                 engine keeps the RCCL path (per-stage launches + ncclAllReduce per layer).
+// Collective: every rank must call it with the same size.
+__global__ void k_window_handshake(unsigned long long* const* win, int world, int rank, unsigned tag, int* result,
+                                   long long limit_ticks)
+{
+    // granule [rank] of every rank's window <- {tag, rank}; then wait for every peer's granule in the own window
+    const int t = threadIdx.x;
+    if (t < world) {
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(win[t] + rank),
+                           ((unsigned long long)tag << 32) | (unsigned)rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    bool            ok = true;
+    const long long t0 = wall_clock64();
+    if (t < world) {
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(
+                (const __attribute__((address_space(1))) unsigned long long*)(win[rank] + t), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(v >> 32) == tag && (unsigned)v == (unsigned)t) {
+                break;
+            }
+            if (wall_clock64() - t0 > limit_ticks) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    if (!ok) {
+        atomicExch(result, 0);
+    }
+}
+
+static void comm_barrier(ftcf_comm* c, hipStream_t s, int* d_scratch)
+{
+    if (c->local) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        c->local->barrier();
+        return;
+    }
+    FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// all-reduce (min) of a host flag over the communicator
+static int comm_agree(ftcf_comm* c, int flag, hipStream_t s, int* d_scratch)
+{
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_scratch, &flag, sizeof(int), hipMemcpyHostToDevice, s));
+    FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
+    int out = 0;
+    FTCF_HIP_CHECK(hipMemcpyAsync(&out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    return out;
+}
+
+static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
+{
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    if (c->win_ok && c->win_bytes >= bytes) {
+        return;
+    }
+    if (c->win_tried && !c->local) {
+        return;  // the RCCL ranks agreed once that the windows do not work here: stay on the collective path
+    }
+    c->win_tried = true;
+    c->win.assign(c->world, nullptr);
+    if (c->local) {
+        LocalGroup& g = *c->local;
+        void*       mine = nullptr;
+        FTCF_HIP_CHECK(hipMalloc(&mine, bytes));
+        FTCF_HIP_CHECK(hipMemsetAsync(mine, 0, bytes, s));
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        g.barrier();  // nobody is still using the old windows
+        if (g.win[c->rank]) {
+            (void)hipFree(g.win[c->rank]);
+        }
+        g.win[c->rank]       = mine;
+        g.win_bytes[c->rank] = bytes;
+        g.barrier();
+        for (int r = 0; r < c->world; r++) {
+            c->win[r] = g.win[r];
+        }
+        g.barrier();
+        c->win_bytes = bytes;
+        c->win_ok    = true;
+        return;
+    }
+    // ---- RCCL ranks: IPC mapping + hand-shake, with a collective agreement after every step that can fail ----
+    struct Rec {
+        hipIpcMemHandle_t h;
+        int               ok, pad[3];
+    };
+    int* d_scratch = nullptr;
+    FTCF_HIP_CHECK(hipMalloc((void**)&d_scratch, 256));
+    FTCF_HIP_CHECK(hipMemsetAsync(d_scratch, 0, 256, s));
+    void* mine = nullptr;
+    Rec   me{};
+    me.ok = 1;
+    if (getenv("FTCF_TP_WINDOWS") && atoi(getenv("FTCF_TP_WINDOWS")) == 0) {
+        me.ok = 0;
+    }
+    if (me.ok && hipExtMallocWithFlags(&mine, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        mine = nullptr;
+        if (hipMalloc(&mine, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            mine  = nullptr;
+            me.ok = 0;
+        }
+    }
+    if (me.ok && hipIpcGetMemHandle(&me.h, mine) != hipSuccess) {
+        (void)hipGetLastError();
+        me.ok = 0;
+    }
+    std::vector<Rec> recs(c->world);
+    Rec*             d_recs = nullptr;
+    FTCF_HIP_CHECK(hipMalloc((void**)&d_recs, sizeof(Rec) * c->world));
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_recs + c->rank, &me, sizeof(Rec), hipMemcpyHostToDevice, s));
+    FTCF_NCCL_CHECK(ncclAllGather(d_recs + c->rank, d_recs, sizeof(Rec), ncclChar, c->comm, s));
+    FTCF_HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs, sizeof(Rec) * c->world, hipMemcpyDeviceToHost, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    int ok = 1;
+    for (int r = 0; r < c->world; r++) {
+        ok &= recs[r].ok;
+    }
+    std::vector<void*> opened(c->world, nullptr);
+    if (ok) {
+        for (int r = 0; r < c->world && ok; r++) {
+            if (r == c->rank) {
+                c->win[r] = mine;
+            }
+            else if (hipIpcOpenMemHandle(&opened[r], recs[r].h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                opened[r] = nullptr;
+                ok        = 0;
+            }
+            else {
+                c->win[r] = opened[r];
+            }
+        }
+    }
+    ok = comm_agree(c, ok, s, d_scratch);
+    if (ok) {
+        // hand-shake on the hardware: zero, barrier, every rank's kernel stores to all and polls its own (2 s bound)
+        FTCF_HIP_CHECK(hipMemsetAsync(mine, 0, bytes, s));
+        comm_barrier(c, s, d_scratch + 1);
+        void** d_win = nullptr;
+        int*   d_res = nullptr;
+        FTCF_HIP_CHECK(hipMalloc((void**)&d_win, sizeof(void*) * c->world + 64));
+        d_res = reinterpret_cast<int*>(reinterpret_cast<char*>(d_win) + sizeof(void*) * c->world);
+        const int one = 1;
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_win, c->win.data(), sizeof(void*) * c->world, hipMemcpyHostToDevice, s));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_res, &one, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_window_handshake, dim3(1), dim3(64), 0, s, (unsigned long long* const*)d_win, c->world, c->rank,
+                           0x5eedu, d_res, (long long)200000000);  // 100 MHz ticks: 2 s
+        int res = 0;
+        FTCF_HIP_CHECK(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, s));
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(d_win);
+        ok = comm_agree(c, res, s, d_scratch);
+        if (ok) {
+            FTCF_HIP_CHECK(hipMemsetAsync(mine, 0, bytes, s));
+            comm_barrier(c, s, d_scratch + 1);
+        }
+    }
+    (void)hipFree(d_recs);
+    (void)hipFree(d_scratch);
+    if (!ok) {
+        for (int r = 0; r < c->world; r++) {
+            if (opened[r]) {
+                (void)hipIpcCloseMemHandle(opened[r]);
+            }
+        }
+        if (mine) {
+            (void)hipFree(mine);
+        }
+        c->win.assign(c->world, nullptr);
+        c->win_ok = false;
+        if (c->rank == 0) {
+            fprintf(stderr, "[ftcf] tensor-parallel exchange windows unavailable: RCCL all-reduce per layer instead\n");
+        }
+        return;
+    }
+    c->win_bytes = bytes;
+    c->win_ok    = true;
 }
 
 static std::mutex                                        g_local_mu;
@@ -581,7 +775,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
-    int                 persist = 1, persist_per_layer = 0, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
+    int                 persist = 1, persist_tp = 1, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -589,6 +783,7 @@ struct ftcf_gptneox {
                        *ps_ga = nullptr;
     size_t              ps_slab_n = 0;
     int*                ps_err = nullptr;
+    int*                tp_scratch = nullptr;  // device int for the barrier all-reduce of the tensor-parallel windows
     long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
     std::string         ps_ts_file;
 
@@ -604,6 +799,9 @@ struct ftcf_gptneox {
     {
         for (void* p : owned) {
             (void)hipFree(p);
+        }
+        if (tp_scratch) {
+            (void)hipFree(tp_scratch);
         }
         if (stream) {
             (void)hipStreamDestroy(stream);
@@ -690,12 +888,19 @@ struct ftcf_gptneox {
             rot_table          = c.take<float>((size_t)B * 256);
             chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, std::min(B, 4), 8) / 8);
             pplan = PersistPlan{};
-            // With tensor parallelism there is a collective between the layers: the persistent kernel would run one
-            // launch per layer, which measured slower (296 vs 314 tokens/s at TP=1 sizes, and the fixed cost weighs more
-            // on smaller shards) than the per-stage launches -- those stay in charge for TP > 1.
-            if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (cfg.tensor_para_size == 1 || persist_per_layer)) {
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, persist_nb, persist_cs1, persist_cs3);
-                if (pplan.ok && !persist_resident(pplan, int8, B, dh, num_cu)) {
+            // With tensor parallelism the per-layer all-reduce happens INSIDE the persistent launch, through the ranks'
+            // exchange windows (persist_device.cuh ps_tp_exchange); where the windows are not available (peer mapping or
+            // hand-shake failed, FTCF_TP_PERSIST=0) the per-stage launches + RCCL all-reduce stay in charge.
+            const int  tpn      = cfg.tensor_para_size;
+            const bool tp_local = tpn > 1 && cfg.comm && cfg.comm->local;
+            if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
+                // (a local group shares ONE device: every rank gets 1 / world of its compute units)
+                const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3);
+                const bool resident = !pplan.ok ? false
+                                      : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
+                                                 : persist_resident(pplan, int8, B, dh, num_cu, tpn);
+                if (!resident) {
                     pplan = PersistPlan{};  // not every workgroup would be resident: the hand-offs could never complete
                 }
             }
@@ -855,6 +1060,11 @@ struct ftcf_gptneox {
         pp.s_max = s_max;
         pp.B = B;
         pp.tp = cfg.tensor_para_size;
+        pp.tp_rank = cfg.tensor_para_rank;
+        for (int r = 0; r < PERSIST_MAX_TP; r++) {
+            pp.xw[r] = (cfg.tensor_para_size > 1 && cfg.comm && r < (int)cfg.comm->win.size())
+                           ? static_cast<unsigned long long*>(cfg.comm->win[r]) : nullptr;
+        }
         pp.plan = pplan;
         pp.d_step = &state->step;
         pp.seq_len = seq_len;
@@ -881,19 +1091,29 @@ struct ftcf_gptneox {
             // algorithmic bytes of a layer: its four weight matrices + the K/V rows of the current length
             const double layer_bytes = wbytes * ((double)H * 3 * hl + (double)H * il + (double)hl * H + (double)il * H)
                                        + 4.0 * ses.next_step * hl * B;
-            if (cfg.tensor_para_size == 1 && !persist_per_layer) {
-                pp.l_begin = 0;
-                pp.l_end   = L;
-                timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_persistent(pp, int8, stream); });
-            }
-            else {
-                for (int l = 0; l < L; l++) {
-                    pp.l_begin = l;
-                    pp.l_end   = l + 1;
-                    timed(KIND_PERSIST, layer_bytes, [&] { launch_decode_persistent(pp, int8, stream); });
-                    allreduce(x, (size_t)B * H);
+            pp.l_begin = 0;
+            pp.l_end   = L;
+            if (cfg.tensor_para_size > 1 && cfg.comm->local) {
+                // local group: ONE launch runs every rank (workgroups [r * NB, (r + 1) * NB) = rank r), issued by rank 0
+                // between two thread barriers; the other ranks' streams are idle meanwhile
+                LocalGroup& g = *cfg.comm->local;
+                FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // this rank's inputs (x, rotary table, state) are complete
+                g.item[cfg.tensor_para_rank] = &pp;
+                g.barrier();
+                if (cfg.tensor_para_rank == 0) {
+                    PersistGroupParams gp{};
+                    for (int r = 0; r < g.world; r++) {
+                        gp.p[r] = *static_cast<const PersistParams*>(g.item[r]);
+                    }
+                    gp.world = g.world;
+                    gp.nb    = pplan.NB;
+                    launch_decode_persistent_group(gp, int8, stream);
+                    FTCF_HIP_CHECK(hipStreamSynchronize(stream));
                 }
+                g.barrier();
+                return;
             }
+            timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_persistent(pp, int8, stream); });
             return;
         }
         for (int l = 0; l < L; l++) {
@@ -1191,7 +1411,24 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     const int total = S + out_len;  // max_output_seq_len == max_seq_len == max_cache_seq_len (GptNeoX.cc:520-523)
     const int s_max = total;
     ses.K = K;  // (decoder path selection reads it)
+    const int  tpn     = cfg.tensor_para_size;
+    const bool want_tp = tpn > 1 && persist && persist_tp && K == 1 && B <= 2 && cfg.use_gptj_residual && tpn <= PERSIST_MAX_TP;
+    if (want_tp) {
+        // (collective: every rank sees the same request shape) room for two rows: [tp][2 * H / 2] granules
+        comm_ensure_window(cfg.comm, (size_t)tpn * H * 8, stream);
+    }
     plan(B, S, total, K);
+    if (want_tp && pplan.ok) {
+        // granule tags repeat from request to request: every rank's window is zeroed between two barriers -- nobody is
+        // still writing into it from the previous request, nobody writes before it is clean
+        if (!tp_scratch) {
+            FTCF_HIP_CHECK(hipMalloc((void**)&tp_scratch, 256));
+            FTCF_HIP_CHECK(hipMemsetAsync(tp_scratch, 0, 256, stream));
+        }
+        comm_barrier(cfg.comm, stream, tp_scratch);
+        FTCF_HIP_CHECK(hipMemsetAsync(cfg.comm->win[cfg.tensor_para_rank], 0, (size_t)tpn * H * 8, stream));
+        comm_barrier(cfg.comm, stream, tp_scratch);
+    }
 
     // ---- runtime args: routing of TopKSamplingLayer.cu:27-77 / TopPSamplingLayer.cu:30-110 ----
     auto top_k = broadcast_arg<int>(a.top_k, a.n_top_k, batch, 0, "top_k");
@@ -1692,8 +1929,8 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_PERSIST")) {
             e->persist = atoi(m);
         }
-        if (const char* m = getenv("FTCF_PERSIST_PER_LAYER")) {
-            e->persist_per_layer = atoi(m);
+        if (const char* m = getenv("FTCF_TP_PERSIST")) {
+            e->persist_tp = atoi(m);
         }
         if (const char* m = getenv("FTCF_PERSIST_TS")) {
             e->ps_ts_file = m;

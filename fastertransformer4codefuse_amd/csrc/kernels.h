@@ -199,12 +199,26 @@ struct PersistParams {
     const float*        rot_table;
     float               eps;
     long long*          ts;          // optional [NB][L][8 waves][16] wall-clock stamps (100 MHz), or NULL
+    // tensor parallel (tp > 1): this rank and the exchange windows of ALL ranks as this rank addresses them (own memory
+    // for xw[tp_rank], peer mappings otherwise); window layout [tp source ranks][M*H/2] granules of {tag, pair of halves}
+    int                 tp_rank;
+    unsigned long long* xw[8];
+};
+constexpr int PERSIST_MAX_TP = 8;
+struct PersistGroupParams {  // local group launch: every rank's parameters, nb workgroups each
+    PersistParams p[PERSIST_MAX_TP];
+    int           world, nb;
 };
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
                          int cs1, int cs3);
 // every workgroup of the plan's grid resident at once on this device?  (also raises the kernel's dynamic-LDS limit there)
-bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu);
+bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp = 1);
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
+// all ranks of a local group in one launch (grid = world * NB): residency of the whole group
+bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world);
+void        launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipStream_t s);
+// tensor-parallel instantiations (kernels_persist_tp.hip); nullptr when the shape has none
+const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
 
 // ---- dynamic decode : kernels_sampling.hip ----
 struct DecodeState {  // device resident, one per engine

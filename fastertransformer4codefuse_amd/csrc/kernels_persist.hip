@@ -1,1318 +1,8 @@
-// Persistent decode layers (m <= 2 rows): ONE launch runs layers [l_begin, l_end) of the decode step of
-// GptNeoXDecoder<T>::forward (models/gptneox/GptNeoXDecoder.cc:245-384) on one resident 8-wave workgroup per CU.
-//
-// Why: as separate launches every stage pays its own ramp and tail (the last waves of a grid stream alone while the rest
-// of the chip idles) and the attention's latency chain sits on the critical path; measured 25 of 75 us per layer.  Inside
-// one launch the weight stream of the NEXT stage is already in flight (four register batches per wave, 32 KiB) while the
-// vectors of the previous stage are handed over, so HBM stays busy across the dependency edges.
-//
-// Stages of a layer (all workgroups run all stages, SPMD):
-//   S0  gather the layer input x (granules published by the previous layer's mergers), LN1 / LN2
-//   P1  stream [QKV u FFN1] column groups -> qkv (no bias, like the reference's MMHA), mid = gelu(.+b)
-//   AT  split-KV attention of one (row, head, split) per workgroup -> ctx
-//   P3  stream [FFN2 pieces, then out-proj pieces] -> fp32 partials; the owner of a group's last out-proj piece merges
-//       them in fixed order, applies invokeAddBiasAttentionFfnResidual and publishes x' for the next layer
-// Every hand-off is made of 8-byte {tag, value} GRANULES (cdna_hip_programming.md G16 recipe R2): one relaxed agent-scope
-// (sc1, write-through) store per granule, consumers re-read until every tag matches -- no flag, fence, drain or counter
-// (a first version with drained counters spent 15 us per edge in the 256 -> 1 fan-in and its pollers).  A consumer only
-// sweeps the slice it needs: an attention workgroup its head's q/k/v (192 granules), a P3 workgroup the K range of its
-// pieces (mid: 1280, ctx: 640 granules at CodeFuse-13B), every workgroup the layer input x (2560).
-// Waves 0..1 are "control" waves: they do the latency-critical sweeps and therefore start their weight prefetch last;
-// a wave's memory returns are in order, so a sweep issued behind 32 KiB of prefetch would wait for all of it.  For the
-// same reason the per-layer constants (scales, biases, LayerNorm parameters) are fetched into registers one stage
-// ahead, before that stage's prefetch is issued.
-// The work split is static: a workgroup owns whole runs (a column group, or a K piece of one), its waves cut the runs'
-// tiles back to back into contiguous shares, and per-wave tile tables (built once per launch in LDS) drive the stream.
-// Every spin is bounded (PS_SPIN) and reports through PersistParams::err instead of hanging the GPU.
-#include <type_traits>
-
-#include "attn_device.cuh"
-#include "gemv_device.cuh"
+// Host side of the persistent decode layers (device code: persist_device.cuh): plan, residency check, launchers of the
+// TP = 1 instantiations.  The tensor-parallel instantiations live in kernels_persist_tp.hip (built in parallel).
+#include "persist_device.cuh"
 
 namespace ftcf {
-
-constexpr int PS_NW       = 8;           // waves per workgroup (2 per SIMD -> 256 VGPRs each)
-constexpr int PS_NT       = PS_NW * 64;
-constexpr int PS_NC       = 2;           // control waves
-constexpr int PS_U        = 8;           // tiles per register batch
-constexpr int PS_NBUF     = 4;           // register batches per wave (3 in flight while one is consumed)
-constexpr int PS_RMAX     = 24;          // runs per workgroup and stage
-constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
-constexpr int PS_MAXP     = 16;          // PA + PB
-constexpr int PS_SPIN     = 1 << 18;
-constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane (256 keys per workgroup) ...
-constexpr int PS_UK_LONG  = 12;          // ... or 12 (384 keys) for requests whose KV split does not fit 256: a second
-                                         // instantiation, because the 8-deep form scores 1 % better where both fit
-#ifndef PS_FULL_P1_V
-#define PS_FULL_P1_V false
-#endif
-#ifndef PS_FULL_P3_V
-#define PS_FULL_P3_V false
-#endif
-// streamer waves: issue the whole first rotation (32 KiB) before the hand-off instead of half of it
-constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
-constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
-
-typedef const PersistLayer PsLayerC;
-#define PS_LAYER(p, l) ((p).layers[l])
-#define PS_RLX __ATOMIC_RELAXED
-#define PS_AGT __HIP_MEMORY_SCOPE_AGENT
-// pointers that come out of the per-layer table in memory are GLOBAL: say so (a flat access also counts on lgkmcnt)
-#define PS_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
-
-// batch-table entry (one per PS_U tiles of ONE run, consecutive k): bit 0 valid, 1 flush after the batch, 2..6 run,
-// 8..24 LDS half offset of the first tile's x, 25 x stride select, 26 wait for the late x vector, 27..30 valid tiles
-constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25, PS_BT_WAIT = 1u << 26;
-
-struct RunRec {  // static per launch (LDS)
-    int tile0;  // first tile of the run inside its weight array
-    int sel;    // weight array of the stage (0 / 1)
-    int nt;     // tiles
-    int xoff;   // LDS half offset (inside the x region) of the run's first k
-    int xsel;   // x row stride select
-    int rid;    // stage specific id (P1: combined group, P3: global piece id)
-    int grp;    // 16-column group
-    int pad;
-};
-
-__device__ __forceinline__ int ps_rfl(int v)
-{
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ void st_granule_u32(u64* g, unsigned tag, unsigned v)
-{
-    __hip_atomic_store((gu64*)g, ((u64)tag << 32) | (u64)v, PS_RLX, PS_AGT);
-}
-__device__ __forceinline__ unsigned short f16_bits(f16 v)
-{
-    return __builtin_bit_cast(unsigned short, v);
-}
-__device__ __forceinline__ f16 bits_f16(unsigned v)
-{
-    return __builtin_bit_cast(f16, (unsigned short)(v & 0xffffu));
-}
-__device__ __forceinline__ bool ps_give_up(int& spins, int* err, const int code)
-{
-    if (++spins > PS_SPIN) {
-        __hip_atomic_store((__attribute__((address_space(1))) int*)err, code, PS_RLX, PS_AGT);
-        return true;
-    }
-    return (spins & 255) == 0 && __hip_atomic_load((__attribute__((address_space(1))) int*)err, PS_RLX, PS_AGT) != 0;
-}
-// `nthr` threads (whole waves, tid = 0..nthr-1) re-read granules [0, n) of `g` until every tag matches, NPER granules
-// per thread and pass, and hand the 32-bit payloads to sink(index, value)
-template<int NPER, typename F>
-__device__ __forceinline__ void ps_sweep(const u64* g, const int n, const int tid, const int nthr, const unsigned tag,
-                                         int* err, const int code, F&& sink)
-{
-    for (int base = 0; base < n; base += nthr * NPER) {
-        u64 gv[NPER];
-        int spins = 0;
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < NPER; k++) {
-                const int i = base + k * nthr + tid;
-                gv[k]       = ld_granule(&g[i < n ? i : n - 1]);
-            }
-#pragma unroll
-            for (int k = 0; k < NPER; k++) {
-                ok &= ((unsigned)(gv[k] >> 32) == tag);
-            }
-            if (__all(ok)) {
-                break;
-            }
-            if (ps_give_up(spins, err, code)) {
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int k = 0; k < NPER; k++) {
-            const int i = base + k * nthr + tid;
-            if (i < n) {
-                sink(i, (unsigned)gv[k]);
-            }
-        }
-    }
-}
-
-// wave w's share of T tiles: control waves get cs/16 of a streamer wave's share and sit at the END of the flat space
-// (P3 puts the out-proj pieces there: the control waves are the ones that wait for ctx anyway).  Shares start at whole
-// batches, so that with run lengths that are multiples of PS_U every batch lies inside one run.
-__host__ __device__ inline void ps_wave_range(const int T, const int w, const int cs, int& tb, int& te)
-{
-    const int total = PS_NC * cs + (PS_NW - PS_NC) * 16;
-    const int c0    = (w >= PS_NC) ? (w - PS_NC) * 16 : (PS_NW - PS_NC) * 16 + w * cs;
-    const int c1    = c0 + ((w < PS_NC) ? cs : 16);
-    tb              = (int)((long)T * c0 / total) / PS_U * PS_U;
-    te              = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
-}
-// table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
-template<typename NT>
-__host__ __device__ inline int ps_wave_entries(const int nruns, NT&& run_nt, const int tb, const int te)
-{
-    int e = 0, pre = 0;
-    for (int j = 0; j < nruns; j++) {
-        const int nt = run_nt(j);
-        const int a = tb > pre ? tb : pre, b = te < pre + nt ? te : pre + nt;
-        if (b > a) {
-            e += (b - a + PS_U - 1) / PS_U * PS_U;
-        }
-        pre += nt;
-    }
-    return e;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Weight stream of one wave over its share [tb, te) of the workgroup's flat tile space, driven by two per-wave LDS
-// tables: lt[i] = {weight array select, tile index}, ct[i] = {x offset, run, flush, valid}.  PS_NBUF register batches
-// of PS_U tiles rotate; the tables are padded to a whole number of rotations with entries that re-read tile 0 of the
-// stage (an L2 / MALL hit, never HBM) and are not consumed, so the loop has NO conditional load: the compiler counts
-// vmcnt exactly and three batches stay in flight while one is consumed.  The accumulator is flushed to
-// part[run][wave] after the last tile of the wave's piece of a run (a wave meets a run in ONE contiguous piece).
-// ---------------------------------------------------------------------------------------------------------------
-struct PsStage {
-    const unsigned *lt, *bt;  // per tile: {array select, tile index}; per batch: descriptor (see PS_BT_*)
-    int             nrot;  // rotations (PS_NBUF batches each), >= 1
-    const char *    w0, *w1;
-    int             xs0, xs1;
-};
-
-template<bool INT8, int M>
-struct PsStream {
-    static constexpr int TK = TileK<INT8>::value;
-    u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
-    f32x4      acc;
-    PsStage    g;
-    const f16* rsc;
-    const f16* xs;
-    float*     part;
-    const int* flag;    // LDS arrival counter of the second x vector
-    int        target;  // value it reaches when that vector is staged
-    int        lane, wid;
-
-    __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx,
-                                         const int* flag_ = nullptr, const int target_ = 0)
-    {
-        flag   = flag_;
-        target = target_;
-        g    = g_;
-        rsc  = rsc_;
-        xs   = xs_;
-        part = part_;
-        lane = tx & 63;
-        wid  = ps_rfl(tx >> 6);
-        acc  = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __device__ __forceinline__ void load(u32x4 (&r)[PS_U], const int i)
-    {
-#pragma unroll
-        for (int u = 0; u < PS_U; u++) {
-            const unsigned e    = g.lt[i * PS_U + u];
-            const char*    base = (e >> 31) ? g.w1 : g.w0;
-            r[u] = __builtin_nontemporal_load(
-                (const __attribute__((address_space(1))) u32x4*)(base + ((size_t)(e & 0x7fffffffu) * 64 + lane) * 16));
-        }
-    }
-    __device__ __forceinline__ void flush(const int j)
-    {
-        if (lane < 16) {
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                part[((size_t)j * PS_NW + wid) * (M * 16) + m * 16 + lane] = acc_row(acc, m);
-            }
-        }
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __device__ __forceinline__ void consume(const u32x4 (&r)[PS_U], const int i)
-    {
-        const unsigned bd = (unsigned)ps_rfl((int)g.bt[i]);
-        if (!(bd & PS_BT_FAST)) {
-            return;  // padding batch
-        }
-        if (bd & PS_BT_WAIT) {  // rare: only the first batch of a wave that touches the late vector actually spins
-            while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)flag) < target) {
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        const int  j   = (bd >> 2) & 31;
-        const int  cnt = (bd >> 27) & 15;
-        const f16* xr  = a_frag_ptr<INT8, M>(xs + ((bd >> 8) & 0x1ffffu), (bd & PS_BT_XSEL) ? g.xs1 : g.xs0, lane);
-        f16x2      sc2 = {(f16)1.0f, (f16)1.0f};
-        if constexpr (INT8) {
-            const f16 sc = rsc[j * 16 + (lane & 15)];
-            sc2          = f16x2{sc, sc};
-        }
-        if (cnt == PS_U) {  // straight-line code like the per-kernel GEMV stream
-#pragma unroll
-            for (int u = 0; u < PS_U; u++) {
-                consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
-            }
-        }
-        else {
-#pragma unroll
-            for (int u = 0; u < PS_U; u++) {
-                if (u < cnt) {
-                    consume_tile<INT8, M>(r[u], xr + u * TK, sc2, acc);
-                }
-            }
-        }
-        if (bd & PS_BT_FLUSH) {
-            flush(j);
-        }
-    }
-    // the first rotation: issued before the hand-off this stage waits for.  The streamer waves issue only half of it
-    // there and the rest when they start consuming: a 192 KiB burst per CU sits in FRONT of the control waves' sweeps in
-    // the CU's memory pipeline and stretched each hand-off hop to 6-7 us (measured)
-    __device__ __forceinline__ void prime_lo()
-    {
-        load(R0, 0);
-        load(R1, 1);
-    }
-    __device__ __forceinline__ void prime_hi()
-    {
-        load(R2, 2);
-        load(R3, 3);
-    }
-    __device__ __forceinline__ void prime()
-    {
-        prime_lo();
-        prime_hi();
-    }
-    // HI: the second half of the first rotation is still to be issued.  Compile time: a load under a run-time condition
-    // makes the compiler's vmcnt bookkeeping conservative for the whole stream (measured: 340 -> 192 tokens/s)
-    template<bool HI>
-    __device__ __forceinline__ void run()
-    {
-        if constexpr (HI) {
-            prime_hi();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int last = (g.nrot - 1) * PS_NBUF;
-        for (int i = 0; i < last; i += PS_NBUF) {
-            consume(R0, i);
-            __builtin_amdgcn_sched_barrier(0);
-            load(R0, i + 4);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(R1, i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            load(R1, i + 5);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(R2, i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            load(R2, i + 6);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(R3, i + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            load(R3, i + 7);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        consume(R0, last);
-        consume(R1, last + 1);
-        consume(R2, last + 2);
-        consume(R3, last + 3);
-    }
-};
-
-// One wave fills its tables for a stage from the workgroup's static run table: every piece of a run the wave owns is
-// padded to whole batches (padding tiles re-read the wave's own first tile -- one shared address would be a hot spot --
-// and are never consumed), so a batch never spans two runs.  One lane per batch.
-template<int TK>
-__device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
-                                                unsigned* lt, unsigned* bt, const int entries)
-{
-    const int lane = threadIdx.x & 63;
-    // the wave's first tile (padding address): uniform
-    unsigned pad = 0u;
-    {
-        int pre = 0;
-        for (int j = 0; j < nruns; j++) {
-            const int nt = rt[j].nt;
-            if (tb < te && tb >= pre && tb < pre + nt) {
-                pad = ((unsigned)rt[j].sel << 31) | (unsigned)(rt[j].tile0 + tb - pre);
-            }
-            pre += nt;
-        }
-    }
-    for (int bi = lane; bi < entries / PS_U; bi += 64) {
-        // locate batch bi: pieces of the runs intersecting [tb, te), each padded to whole batches
-        int      pre = 0, eb = 0;  // tiles before run j, batches before run j's piece
-        unsigned bd  = 0u;
-        int      first = 0, cnt = 0, sel = 0;
-        for (int j = 0; j < nruns; j++) {
-            const RunRec r  = rt[j];
-            const int    a  = tb > pre ? tb : pre, b = te < pre + r.nt ? te : pre + r.nt;
-            const int    nb = b > a ? (b - a + PS_U - 1) / PS_U : 0;
-            if (bi >= eb && bi < eb + nb) {
-                const int t   = a + (bi - eb) * PS_U;
-                const int off = t - pre;
-                cnt   = (b - t < PS_U) ? b - t : PS_U;
-                first = r.tile0 + off;
-                sel   = r.sel;
-                bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
-                     | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
-                     | ((unsigned)cnt << 27);
-            }
-            eb += nb;
-            pre += r.nt;
-        }
-        for (int u = 0; u < PS_U; u++) {
-            lt[bi * PS_U + u] = (u < cnt) ? (((unsigned)sel << 31) | (unsigned)(first + u)) : pad;
-        }
-        bt[bi] = bd;
-    }
-}
-
-struct PsSmem {
-    f16*      xraw;  // [M][H]
-    f16*      xs;    // x region (P1: LN1(x) | LN2(x) ; P3: mid | ctx)
-    float*    part;  // [RMAX][NW][M*16]
-    char*     att;   // attention scratch
-    RunRec*   rt1;   // [RMAX] P1 runs
-    RunRec*   rt3;   // [RMAX] P3 runs
-    f16*      rsc;   // [RMAX][16] scales of the current stage
-    float*    red;   // 64
-    int*      misc;  // 64: [0] nmerge, [1..8] merge groups
-    unsigned *lt1, *lt3;  // [NW][e1], [NW][e3]
-    unsigned *bt1, *bt3;  // [NW][e1 / PS_U], [NW][e3 / PS_U]
-};
-
-__host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
-{
-    const int chunk = ((((s_max + nsplit - 1) / nsplit) + 15) & ~15);
-    size_t    a     = (size_t)3 * dh * 2 + (size_t)(2 * PS_NW + PS_NW * dh) * 4 + (size_t)chunk * 4;
-    size_t    b     = (size_t)(nsplit * (dh + 2) + nsplit + 4) * 4;
-    return ((a > b ? a : b) + 15) & ~(size_t)15;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// attention of one (row b, head h, split sp) on the whole 8-wave workgroup
-// (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.cuh::mmha_partial)
-// ---------------------------------------------------------------------------------------------------------------
-template<int DH, int UK>
-struct PsAttn {
-    static constexpr int LPK = DH / 8;
-    static constexpr int KPI = 64 / LPK;
-    u32x4 kreg[UK], vreg[UK];
-    unsigned mask_bits, bias2;
-    int      tl, chunk, t_beg;
-    float    rot_cs, rot_sn;
-    bool     fin;
-
-    // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table
-    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx)
-    {
-        const int lane = tx & 63, wid = tx >> 6;
-        const int sub = lane % LPK, grp = lane / LPK;
-        chunk = (((p.s_max + p.plan.nsplit - 1) / p.plan.nsplit) + 15) & ~15;
-        t_beg = sp * chunk;
-        const auto* kc = PS_G(f16, lw.k_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
-        const auto* vc = PS_G(f16, lw.v_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
-        // rows past the end of this split's chunk (the register capacity covers UK * 32 keys, the chunk may be shorter)
-        // re-read its last row: a cache hit, not K/V traffic of the neighbouring split
-        int t_last = t_beg + chunk - 1;
-        t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
-#pragma unroll
-        for (int u = 0; u < UK; u++) {
-            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < t_last ? t : t_last;
-            kreg[u] = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < UK; u++) {
-            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < t_last ? t : t_last;
-            vreg[u] = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
-        }
-        mask_bits = 0u;
-        if (p.masked_tokens && sub == 0) {
-#pragma unroll
-            for (int u = 0; u < UK; u++) {
-                int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-                t     = t < t_last ? t : t_last;
-                mask_bits |= (p.masked_tokens[(size_t)b * p.s_max + t] ? 1u : 0u) << u;
-            }
-        }
-        rot_cs = 1.f;
-        rot_sn = 0.f;
-        if (p.rot > 0 && tx < p.rot / 2) {
-            rot_cs = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2];
-            rot_sn = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2 + 1];
-        }
-        bias2 = 0u;
-        if (tx < 3 * DH / 2) {  // this thread's pair of q / k / v bias values (sweep_qkv)
-            const int seg = tx / (DH / 2), i = tx % (DH / 2);
-            bias2 = *PS_G(unsigned, reinterpret_cast<const unsigned*>(lw.b_qkv + (size_t)seg * p.nh * DH + h * DH) + i);
-        }
-        fin = p.finished && p.finished[b];
-        tl  = p.seq_len[b];
-    }
-    // q/k/v of the current token: granules published by the QKV stage of THIS launch (pairs of halves); + bias -> LDS
-    __device__ __forceinline__ void sweep_qkv(const PersistParams& p, char* smem, const unsigned tag, int h, int b, const int tx)
-    {
-        if (fin) {
-            return;
-        }
-        f16* s_q = reinterpret_cast<f16*>(smem);  // [DH] q | [DH] k | [DH] v
-        if (tx < 3 * DH / 2) {
-            const int  seg = tx / (DH / 2), i = tx % (DH / 2);
-            const int  hl  = p.nh * DH;
-            const u64* g   = p.gq + ((size_t)b * 3 * hl + (size_t)seg * hl + h * DH) / 2 + i;
-            u64        v;
-            int        spins = 0;
-            for (;;) {
-                v = ld_granule(g);
-                if ((unsigned)(v >> 32) == tag) {
-                    break;
-                }
-                if (++spins > PS_SPIN) {
-                    __hip_atomic_store(p.err, 5, PS_RLX, PS_AGT);
-                    break;
-                }
-                if ((spins & 255) == 0 && __hip_atomic_load(p.err, PS_RLX, PS_AGT) != 0) {
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            const f16 x0 = bits_f16((unsigned)v), x1 = bits_f16((unsigned)v >> 16);
-            s_q[seg * DH + 2 * i]     = x0 + bits_f16(bias2);
-            s_q[seg * DH + 2 * i + 1] = x1 + bits_f16(bias2 >> 16);
-        }
-    }
-    // returns false when the row is finished (nothing published)
-    __device__ __forceinline__ bool compute(const PersistParams& p, PsLayerC& lw, char* smem, u64* gout,
-                                            const unsigned tag, int h, int b, const int tx)
-    {
-        const int lane = tx & 63, wid = tx >> 6;
-        const int sub = lane % LPK, grp = lane / LPK;
-        if (fin) {
-            return false;  // :1176
-        }
-        int t_end = t_beg + chunk;
-        if (t_end > tl + 1) {
-            t_end = tl + 1;
-        }
-        if (t_beg > tl) {  // empty split
-            if (tx < DH) {
-                st_granule(&gout[tx], tag, 0.f);
-            }
-            if (tx == 0) {
-                st_granule(&gout[DH], tag, -INFINITY);
-                st_granule(&gout[DH + 1], tag, 0.f);
-            }
-            return true;
-        }
-        const bool owns_cur     = (tl >= t_beg && tl < t_end);
-        const int  t_cached_end = owns_cur ? tl : t_end;
-        f16*   s_q   = reinterpret_cast<f16*>(smem);
-        f16*   s_k   = s_q + DH;
-        f16*   s_v   = s_k + DH;
-        float* s_red = reinterpret_cast<float*>(s_v + DH);  // [2*NW + NW*DH]
-        float* s_p   = s_red + 2 * PS_NW + PS_NW * DH;      // [chunk]
-        __syncthreads();  // q | k | v (+ bias) written by sweep_qkv
-        if (p.rot > 0 && tx < p.rot / 2) {
-            const int j = tx;
-            f16       a = s_q[j], c = s_q[j + p.rot / 2];
-            rotary_apply(a, c, rot_cs, rot_sn);
-            s_q[j]             = a;
-            s_q[j + p.rot / 2] = c;
-            if (owns_cur) {
-                f16 ka = s_k[j], kc2 = s_k[j + p.rot / 2];
-                rotary_apply(ka, kc2, rot_cs, rot_sn);
-                s_k[j]             = ka;
-                s_k[j + p.rot / 2] = kc2;
-            }
-        }
-        __syncthreads();
-        if (owns_cur && tx < DH) {  // append to the cache (:1397, :1837)
-            ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
-            ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
-        }
-        const float inv_sqrt_dh = rsqrtf((float)DH);
-        const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
-        float       lmax        = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < UK; u++) {
-            const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            const f16x8 kv = __builtin_bit_cast(f16x8, kreg[u]);
-            float       a  = 0.f;
-            a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
-            a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
-            a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
-            a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
-            a              = group_sum(a, LPK) * inv_sqrt_dh;
-            if (t < t_cached_end && sub == 0) {
-                const bool m   = ((mask_bits >> u) & 1u) != 0u;
-                s_p[t - t_beg] = m ? -INFINITY : a;
-                if (!m) {
-                    lmax = fmaxf(lmax, a);
-                }
-            }
-        }
-        if (owns_cur && wid == 0) {  // current token from LDS (:1407-1437)
-            float a = 0.f;
-            if (lane < LPK) {
-                const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
-                const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
-                a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
-                a              = dot2(f16x2{q8[2], q8[3]}, f16x2{kv[2], kv[3]}, a);
-                a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
-                a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
-            }
-            a = wave_sum(a) * inv_sqrt_dh;
-            if (lane == 0) {
-                s_p[tl - t_beg] = a;
-                lmax            = fmaxf(lmax, a);
-            }
-        }
-        lmax = wave_max(lmax);
-        if (lane == 0) {
-            s_red[wid] = lmax;
-        }
-        __syncthreads();
-        float m_loc = s_red[0];
-#pragma unroll
-        for (int w = 1; w < PS_NW; w++) {
-            m_loc = fmaxf(m_loc, s_red[w]);
-        }
-        float lsum = 0.f;
-        for (int i = tx; i < t_end - t_beg; i += PS_NT) {
-            const float e = (s_p[i] == -INFINITY) ? 0.f : __expf(s_p[i] - m_loc);
-            s_p[i]        = e;
-            lsum += e;
-        }
-        lsum = wave_sum(lsum);
-        __syncthreads();
-        if (lane == 0) {
-            s_red[PS_NW + wid] = lsum;
-        }
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            acc[j] = 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < UK; u++) {
-            const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
-                const float pt = s_p[t - t_beg];
-                const f16x8 vv = __builtin_bit_cast(f16x8, vreg[u]);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    acc[j] = fmaf(pt, (float)vv[j], acc[j]);
-                }
-            }
-        }
-        if (owns_cur && wid == 0 && grp == 0) {
-            const float pt = s_p[tl - t_beg];
-            const f16x8 vv = *reinterpret_cast<const f16x8*>(s_v + sub * 8);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                acc[j] = fmaf(pt, (float)vv[j], acc[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            for (int o = LPK; o < 64; o <<= 1) {
-                acc[j] += __shfl_xor(acc[j], o, 64);
-            }
-        }
-        float* s_o = s_red + 2 * PS_NW;  // [NW][DH]
-        if (grp == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                s_o[wid * DH + sub * 8 + j] = acc[j];
-            }
-        }
-        __syncthreads();
-        if (tx < DH) {
-            const int d = tx;
-            float     o = 0.f;
-#pragma unroll
-            for (int w = 0; w < PS_NW; w++) {
-                o += s_o[w * DH + d];
-            }
-            st_granule(&gout[d], tag, o);
-        }
-        if (tx == 0) {
-            float ls = 0.f;
-#pragma unroll
-            for (int w = 0; w < PS_NW; w++) {
-                ls += s_red[PS_NW + w];
-            }
-            st_granule(&gout[DH], tag, m_loc);
-            st_granule(&gout[DH + 1], tag, ls);
-        }
-        return true;
-    }
-};
-
-// split-0 workgroup of a (row, head): WAVE 0 alone sweeps the nsplit partials, merges them in split order and publishes
-// ctx as granules (one wave: no workgroup barrier, the other waves are already streaming the next stage)
-template<int DH>
-__device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem, u64* gall, const unsigned tag, int h,
-                                              int b, const int tx)
-{
-    const int ne = DH + 2, ns = p.plan.nsplit;
-    const int ng = ns * ne;
-    float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
-    ps_sweep<8>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
-    // weights (same wave: DS operations of one wave execute in order)
-    float ms = -INFINITY, ls = 0.f;
-    if (tx < ns) {
-        ms = sval[tx * ne + DH];
-        ls = sval[tx * ne + DH + 1];
-    }
-    const float m  = wave_max(ms);
-    const float w  = (ms == -INFINITY) ? 0.f : __expf(ms - m);
-    float*      sw = sval + ns * ne;
-    if (tx < ns) {
-        sw[tx] = w;
-    }
-    float L = 0.f;
-    for (int s2 = 0; s2 < ns; s2++) {
-        L += __shfl(w * ls, s2, 64);
-    }
-    const float inv = 1.f / (L + 1.e-6f);  // :1632
-    for (int d = tx; d < DH; d += 64) {
-        float o = 0.f;
-        for (int s2 = 0; s2 < ns; s2++) {
-            o += sw[s2] * sval[s2 * ne + d];
-        }
-        const unsigned b0 = f16_bits((f16)(o * inv));
-        const unsigned b1 = __shfl_down(b0, 1, 64);
-        if ((d & 1) == 0) {
-            st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
-        }
-    }
-}
-
-// finished row: its ctx is never consumed (:1176) but the out-proj stage still waits for the granules
-template<int DH>
-__device__ __forceinline__ void ps_attn_publish_zero(const PersistParams& p, const unsigned tag, int h, int b, const int tx)
-{
-    if (tx < DH / 2) {
-        st_granule_u32(&p.gc[(((size_t)b * p.nh * DH + h * DH) >> 1) + tx], tag, 0u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-template<bool INT8, int M, int DH, int UK>
-__global__ __launch_bounds__(PS_NT) void k_decode_persistent(const PersistParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TK = TileK<INT8>::value;
-    const int     H = p.H, Hl = p.Hl, Il = p.Il;
-    const int     NB = p.plan.NB, bid = blockIdx.x;
-    const int     wid = threadIdx.x >> 6;
-    const int     KT = H / TK, KT_a = Hl / TK, KT_b = Il / TK;
-    const int     NT0 = 3 * Hl / 16, NG = H / 16;
-    const int     PA = p.plan.PA, PB = p.plan.PB, RLa = p.plan.RLa, RLb = p.plan.RLb;
-    const int     E1 = p.plan.e1, E3 = p.plan.e3;
-
-    PsSmem s;
-    {
-        char* q = smem;
-        s.xraw  = reinterpret_cast<f16*>(q);
-        q += (size_t)M * H * 2;
-        s.xs = reinterpret_cast<f16*>(q);
-        q += (size_t)p.plan.xs_halves * 2;
-        s.part = reinterpret_cast<float*>(q);
-        q += (size_t)PS_RMAX * PS_NW * M * 16 * 4;
-        s.att = q;
-        q += ps_att_bytes(DH, p.s_max, p.plan.nsplit);
-        s.rt1 = reinterpret_cast<RunRec*>(q);
-        q += sizeof(RunRec) * PS_RMAX;
-        s.rt3 = reinterpret_cast<RunRec*>(q);
-        q += sizeof(RunRec) * PS_RMAX;
-        s.rsc = reinterpret_cast<f16*>(q);
-        q += PS_RMAX * 16 * 2;
-        s.red = reinterpret_cast<float*>(q);
-        q += 64 * 4;
-        s.misc = reinterpret_cast<int*>(q);
-        q += 64 * 4;
-        s.lt1 = reinterpret_cast<unsigned*>(q);
-        q += (size_t)PS_NW * E1 * 4;
-        s.lt3 = reinterpret_cast<unsigned*>(q);
-        q += (size_t)PS_NW * E3 * 4;
-        s.bt1 = reinterpret_cast<unsigned*>(q);
-        q += (size_t)PS_NW * (E1 / PS_U) * 4;
-        s.bt3 = reinterpret_cast<unsigned*>(q);
-    }
-    const int      step     = *p.d_step;
-    const unsigned tag_base = (unsigned)step * 256u + 1u;
-    if (p.ts && (threadIdx.x & 63) == 0) {  // kernel entry (slot 15 of the first layer)
-        p.ts[(((size_t)blockIdx.x * p.L + p.l_begin) * PS_NW + (threadIdx.x >> 6)) * 16 + 15] = wall_clock64();
-    }
-
-    // ---- the workgroup's static share of the streaming stages ----
-    // P1: every workgroup owns a range of QKV column groups AND a range of FFN1 column groups (QKV runs first in its run
-    // table: they are streamed first, so qkv is complete -- and published -- well before the stage ends)
-    const int NF  = Il / 16;
-    const int q0  = (int)((long)NT0 * bid / NB), q1 = (int)((long)NT0 * (bid + 1) / NB);
-    const int f0  = (int)((long)NF * bid / NB), f1 = (int)((long)NF * (bid + 1) / NB);
-    const int nq  = q1 - q0;
-    const int rB0 = (int)((long)NG * PB * bid / NB), rB1 = (int)((long)NG * PB * (bid + 1) / NB);
-    const int rA0 = (int)((long)NG * PA * bid / NB), rA1 = (int)((long)NG * PA * (bid + 1) / NB);
-    const int nB = rB1 - rB0, nA = rA1 - rA0;
-    const int nruns1 = nq + (f1 - f0), nruns3 = nB + nA;
-    const int n_items = p.B * p.nh * p.plan.nsplit;
-    if (threadIdx.x == 0) {
-        s.misc[0]  = 0;
-        s.misc[32] = 0;  // ctx arrival counter (+PS_NC per layer)
-        s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
-        const int  j   = threadIdx.x;
-        const bool seg = j >= nq;
-        const int  cg  = seg ? NT0 + f0 + (j - nq) : q0 + j;
-        const int  g   = seg ? cg - NT0 : cg;
-        RunRec     r;
-        r.tile0  = g * KT;
-        r.sel    = seg ? 1 : 0;
-        r.nt     = KT;
-        r.xoff   = seg ? M * (H + XPAD) : 0;
-        r.xsel   = 0;
-        r.rid    = cg;
-        r.grp    = g;
-        r.pad    = 0;
-        s.rt1[j] = r;
-    }
-    if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
-        const int  j     = threadIdx.x;
-        const bool isA   = j >= nB;
-        const int  idx   = isA ? rA0 + (j - nB) : rB0 + j;
-        const int  piece = idx / NG, g = idx % NG;
-        RunRec     r;
-        if (isA) {
-            const int t0 = piece * RLa;
-            r.tile0      = g * KT_a + t0;
-            r.sel        = 1;
-            r.nt         = (KT_a - t0 < RLa) ? KT_a - t0 : RLa;
-            r.xoff       = M * (Il + XPAD) + t0 * TK;
-            r.xsel       = 1;
-            r.rid        = NG * PB + idx;
-            if (piece == PA - 1) {  // owner of a group's last out-proj piece merges the group
-                const int k = atomicAdd(&s.misc[0], 1);
-                if (k < PS_MAXMERGE) {
-                    s.misc[1 + k] = g;
-                }
-            }
-        }
-        else {
-            const int t0 = piece * RLb;
-            r.tile0      = g * KT_b + t0;
-            r.sel        = 0;
-            r.nt         = (KT_b - t0 < RLb) ? KT_b - t0 : RLb;
-            r.xoff       = t0 * TK;
-            r.xsel       = 0;
-            r.rid        = idx;
-        }
-        r.grp    = g;
-        r.pad    = 0;
-        s.rt3[j] = r;
-    }
-    __syncthreads();
-    PsStage sg1{}, sg3{};
-    int     mid_lo = 0, mid_hi = 0, ctx_lo = 0, ctx_hi = 0;  // K ranges (halves) of mid / ctx this workgroup consumes
-    {
-        int T1 = 0, T3 = 0;
-        for (int j = 0; j < nruns1; j++) {
-            T1 += s.rt1[j].nt;
-        }
-        bool fb = true, fa = true;
-        for (int j = 0; j < nruns3; j++) {
-            const RunRec r = s.rt3[j];
-            T3 += r.nt;
-            if (r.sel == 0) {
-                const int lo = r.xoff, hi = r.xoff + r.nt * TK;
-                mid_lo = fb ? lo : (lo < mid_lo ? lo : mid_lo);
-                mid_hi = fb ? hi : (hi > mid_hi ? hi : mid_hi);
-                fb     = false;
-            }
-            else {
-                const int lo = r.xoff - M * (Il + XPAD), hi = lo + r.nt * TK;
-                ctx_lo = fa ? lo : (lo < ctx_lo ? lo : ctx_lo);
-                ctx_hi = fa ? hi : (hi > ctx_hi ? hi : ctx_hi);
-                fa     = false;
-            }
-        }
-        T1 = ps_rfl(T1);
-        T3 = ps_rfl(T3);
-        mid_lo = ps_rfl(mid_lo);
-        mid_hi = ps_rfl(mid_hi);
-        ctx_lo = ps_rfl(ctx_lo);
-        ctx_hi = ps_rfl(ctx_hi);
-        const int w = ps_rfl(wid);
-        int       tb, te;
-        ps_wave_range(T1, w, p.plan.cs1, tb, te);
-        int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
-        sg1.lt   = s.lt1 + (size_t)w * E1;
-        sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
-        sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
-        sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
-        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
-                            sg1.nrot * PS_U * PS_NBUF);
-        ps_wave_range(T3, w, p.plan.cs3, tb, te);
-        ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
-        sg3.lt   = s.lt3 + (size_t)w * E3;
-        sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
-        sg3.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
-        sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
-        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
-                            sg3.nrot * PS_U * PS_NBUF);
-        sg1.xs0 = sg1.xs1 = H + XPAD;  // LDS rows of x are padded: see XPAD
-        sg3.xs0 = Il + XPAD;
-        sg3.xs1 = Hl + XPAD;
-    }
-    __syncthreads();
-
-    // Control waves and streamer waves run SEPARATE instantiations of the layer loop (same barriers, in the same order):
-    // with a shared body the register batches of the role that primes early stay live, as far as the compiler can tell,
-    // through every section of the other role and spill.  Whole waves take one side, s_barrier only counts arrivals.
-    auto body = [&](auto role) {
-        constexpr bool    CTRL = decltype(role)::value;
-        int               tid  = threadIdx.x;
-        PsStream<INT8, M> st;
-        auto stamp = [&](const int l, const int k) {
-            const int lane = tid & 63, wid = tid >> 6;
-            if (p.ts && lane == 0) {
-                p.ts[(((size_t)bid * p.L + l) * PS_NW + wid) * 16 + k] = wall_clock64();
-            }
-        };
-        // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
-        f16   r_sc1 = (f16)1.f, r_sc3 = (f16)1.f;  // scale of (run tid/16, column tid%16) of P1 / P3
-        f16   r_b1[2], r_bres[2];                  // ffn1 bias of the P1 epilogue items / residual bias of the merge items
-        f16x8 r_ln[4][PS_NLN];                     // ln1_g, ln1_b, ln2_g, ln2_b vectors tid, tid + 512
-        auto  load_sc1 = [&](const int l) {
-            if constexpr (INT8) {
-                if (tid < nruns1 * 16) {
-                    PsLayerC& lw = PS_LAYER(p, l);
-                    const RunRec&       r  = s.rt1[tid >> 4];
-                    r_sc1 = PS_G(f16, r.sel ? lw.s_ffn1 : lw.s_qkv)[r.grp * 16 + (tid & 15)];
-                }
-            }
-        };
-        auto load_p1_consts = [&](const int l) {  // LN parameters, ffn1 bias, P3 scales of layer l
-            PsLayerC& lw = PS_LAYER(p, l);
-#pragma unroll
-            for (int k = 0; k < PS_NLN; k++) {
-                const int v = tid + k * PS_NT;
-                if (v * 8 < H) {
-                    r_ln[0][k] = *PS_G(f16x8, lw.ln1_g + v * 8);
-                    r_ln[1][k] = *PS_G(f16x8, lw.ln1_b + v * 8);
-                    r_ln[2][k] = *PS_G(f16x8, lw.ln2_g + v * 8);
-                    r_ln[3][k] = *PS_G(f16x8, lw.ln2_b + v * 8);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int idx = tid + k * PS_NT;
-                r_b1[k]       = (f16)0.f;
-                if (idx < nruns1 * M * 16) {
-                    const int cg = s.rt1[idx / (M * 16)].rid;
-                    if (cg >= NT0) {
-                        r_b1[k] = PS_G(f16, lw.b_ffn1)[(cg - NT0) * 16 + (idx & 15)];
-                    }
-                }
-            }
-            if constexpr (INT8) {
-                if (tid < nruns3 * 16) {
-                    const RunRec& r = s.rt3[tid >> 4];
-                    r_sc3 = PS_G(f16, r.sel ? lw.s_out : lw.s_ffn2)[r.grp * 16 + (tid & 15)];
-                }
-            }
-        };
-        auto load_p3_consts = [&](const int l) {  // residual bias of layer l, P1 scales of layer l + 1
-            if constexpr (CTRL) {
-                PsLayerC& lw = PS_LAYER(p, l);
-                const int           nm = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int t = tid + k * PS_NC * 64;
-                    r_bres[k]   = (f16)0.f;
-                    if (t < nm * M * 16) {
-                        r_bres[k] = PS_G(f16, lw.b_res)[s.misc[1 + t / (M * 16)] * 16 + (t & 15)];
-                    }
-                }
-            }
-            if (l + 1 < p.l_end) {
-                load_sc1(l + 1);
-            }
-        };
-        // per layer: scales of the stage's runs -> LDS, zero the partial buffer, bind the stream
-        auto setup_p1 = [&](const int l) {
-            PsLayerC& lw = PS_LAYER(p, l);
-            if constexpr (INT8) {
-                if (tid < nruns1 * 16) {
-                    s.rsc[tid] = r_sc1;
-                }
-            }
-            for (int i = tid; i < nruns1 * PS_NW * M * 16; i += PS_NT) {
-                s.part[i] = 0.f;
-            }
-            load_p1_consts(l);
-            sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
-            sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
-            st.bind(sg1, s.rsc, s.xs, s.part, tid);
-            if constexpr (!CTRL) {
-                st.prime_lo();
-                if constexpr (PS_FULL_P1) {
-                    st.prime_hi();
-                }
-            }
-        };
-        auto setup_p3 = [&](const int l) {
-            PsLayerC& lw = PS_LAYER(p, l);
-            if constexpr (INT8) {
-                if (tid < nruns3 * 16) {
-                    s.rsc[tid] = r_sc3;
-                }
-            }
-            for (int i = tid; i < nruns3 * PS_NW * M * 16; i += PS_NT) {
-                s.part[i] = 0.f;
-            }
-            sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
-            sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
-            st.bind(sg3, s.rsc, s.xs, s.part, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
-        };
-
-        load_sc1(p.l_begin);
-        setup_p1(p.l_begin);
-        for (int l = p.l_begin; l < p.l_end; l++) {
-            // opaque copies: keeps per-thread address arithmetic from being hoisted out of the layer loop, where it
-            // becomes dozens of long-lived VGPRs that spill around the register batches
-            asm volatile("" : "+v"(tid));
-            const int           lane = tid & 63, wid = tid >> 6;
-            PsLayerC& lw  = PS_LAYER(p, l);
-            const unsigned      tag = tag_base + (unsigned)l;
-            stamp(l, 0);
-            // =========================== S0: layer input -> xraw (control waves) =================================
-            if constexpr (CTRL) {
-                if (l == p.l_begin) {
-                    for (int i = tid * 8; i < M * H; i += PS_NC * 64 * 8) {
-                        *reinterpret_cast<f16x8*>(s.xraw + i) = *reinterpret_cast<const f16x8*>(p.x_in + i);
-                    }
-                }
-                else {
-                    ps_sweep<20>(p.gx, M * H / 2, tid, PS_NC * 64, tag_base + (unsigned)(l - 1), p.err, 3,
-                                [&](const int i, const unsigned v) { reinterpret_cast<unsigned*>(s.xraw)[i] = v; });
-                }
-            }
-            __syncthreads();
-            stamp(l, 1);
-            // =========================== P1: LN1 / LN2, [QKV u FFN1] ===============================================
-            {
-                // LayerNorm x2 (layernorm_kernels.cu:157-286 arithmetic: fp32 statistics, var = E[x^2] - mean^2, half
-                // normalise); both norms share the statistics of x
-                float s0[M], s1[M];
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    s0[m] = 0.f;
-                    s1[m] = 0.f;
-#pragma unroll
-                    for (int k = 0; k < PS_NLN; k++) {
-                        const int v = tid + k * PS_NT;
-                        if (v * 8 < H) {
-                            const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const float f = (float)x8[e];
-                                s0[m] += f;
-                                s1[m] += f * f;
-                            }
-                        }
-                    }
-                    s0[m] = wave_sum(s0[m]);
-                    s1[m] = wave_sum(s1[m]);
-                    if (lane == 0) {
-                        s.red[(m * PS_NW + wid) * 2]     = s0[m];
-                        s.red[(m * PS_NW + wid) * 2 + 1] = s1[m];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                    for (int w = 0; w < PS_NW; w++) {
-                        a0 += s.red[(m * PS_NW + w) * 2];
-                        a1 += s.red[(m * PS_NW + w) * 2 + 1];
-                    }
-                    const float mean = a0 / (float)H;
-                    const float rstd = rsqrtf(a1 / (float)H - mean * mean + p.eps);
-                    const f16   mh = (f16)mean, rh = (f16)rstd;
-#pragma unroll
-                    for (int k = 0; k < PS_NLN; k++) {
-                        const int v = tid + k * PS_NT;
-                        if (v * 8 < H) {
-                            const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
-                            f16x8       o1, o2;
-#pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                const f16 nrm = (x8[e] - mh) * rh;
-                                o1[e]         = (nrm * r_ln[0][k][e]) + r_ln[1][k][e];
-                                o2[e]         = (nrm * r_ln[2][k][e]) + r_ln[3][k][e];
-                            }
-                            *reinterpret_cast<f16x8*>(s.xs + (size_t)m * (H + XPAD) + v * 8)       = o1;
-                            *reinterpret_cast<f16x8*>(s.xs + (size_t)(M + m) * (H + XPAD) + v * 8) = o2;
-                        }
-                    }
-                }
-                if constexpr (CTRL) {
-                    st.prime_lo();
-                }
-                stamp(l, 2);
-                __syncthreads();
-                st.template run<CTRL || !PS_FULL_P1>();
-                stamp(l, 3);
-                __syncthreads();
-                // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int idx = tid + k * PS_NT;
-                    if (idx < nruns1 * M * 16) {
-                        const int j = idx / (M * 16), r = idx % (M * 16), m = r >> 4, c = r & 15;
-                        float     v = 0.f;
-#pragma unroll
-                        for (int w = 0; w < PS_NW; w++) {
-                            v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
-                        }
-                        const int cg = s.rt1[j].rid;
-                        f16       o;
-                        if (cg < NT0) {
-                            o = (f16)v;
-                        }
-                        else {
-                            if constexpr (INT8) {
-                                o = (f16)gelu_f32(v + (float)r_b1[k]);  // epilogue_helpers.h:52-62
-                            }
-                            else {
-                                o = gelu_f16((f16)v + r_b1[k]);  // activation_kernels.cu:401-426
-                            }
-                        }
-                        const unsigned b0 = f16_bits(o);
-                        const unsigned b1 = __shfl_down(b0, 1, 64);
-                        if ((c & 1) == 0) {
-                            // (two stores, not one through a selected pointer: the compiler turns that select into a
-                            // table in scratch memory, and a kernel that uses scratch pays for it at every dispatch)
-                            if (cg < NT0) {
-                                st_granule_u32(p.gq + (((size_t)m * 3 * Hl + cg * 16 + c) >> 1), tag, b0 | (b1 << 16));
-                            }
-                            else {
-                                st_granule_u32(p.gm + (((size_t)m * Il + (cg - NT0) * 16 + c) >> 1), tag, b0 | (b1 << 16));
-                            }
-                        }
-                    }
-                }
-                stamp(l, 4);
-            }
-
-            // =========================== attention ===============================================================
-            asm volatile("" : "+v"(tid));
-            PsAttn<DH, UK> at;
-            const bool has_item = bid < n_items;
-            int        a_sp = 0, a_h = 0, a_b = 0;
-            if (has_item) {
-                a_sp         = bid % p.plan.nsplit;
-                const int hb = bid / p.plan.nsplit;
-                a_h          = hb % p.nh;
-                a_b          = hb / p.nh;
-            }
-            __syncthreads();  // part / scales reuse
-            setup_p3(l);
-            stamp(l, 5);
-            bool live = false;
-            u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
-            if (has_item) {
-                // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
-                at.issue(p, lw, a_h, a_b, a_sp, tid);
-                at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
-                stamp(l, 6);
-                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid);
-            }
-            if constexpr (CTRL) {
-                // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there).
-                // Before the barrier, i.e. before the streamer waves' prefetch burst (a sweep queued behind the burst
-                // took 5 us), and after the attention (ahead of it, it made the attention wait for the slowest FFN1)
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
-                                 p.err, 6, [&](const int i, const unsigned v) {
-                                     reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
-                                 });
-                }
-            }
-            stamp(l, 7);
-            __syncthreads();  // mid staged, attention scratch free
-            stamp(l, 8);
-            if constexpr (!CTRL) {
-                // (the constants of the layer's end -- residual bias, next layer's scales -- are fetched HERE and not in
-                // the P3 set-up: their table reads are synchronous round trips, and the set-up sits on the attention's
-                // critical path, ahead of the K/V request)
-                load_p3_consts(l);
-                // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
-                // and the control waves, which carry the attention's critical path, must not wait for it
-                st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
-                if constexpr (PS_FULL_P3) {
-                    st.prime_hi();
-                }
-            }
-            // =========================== P3: [FFN2 u out-proj] -> residual ========================================
-            // The streamer waves start on the FFN2 pieces at once; the control waves finish the attention (merge of the
-            // split partials by wave 0 of the split-0 workgroups), stage the K range of ctx the out-proj pieces read and
-            // announce it through an LDS counter that gates every batch touching ctx; their own share is the END of the
-            // workgroup's tile space, i.e. the out-proj pieces.
-            if constexpr (CTRL) {
-                if (has_item && a_sp == 0 && wid == 0) {
-                    if (live) {
-                        ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
-                    }
-                    else {
-                        ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
-                    }
-                    stamp(l, 13);
-                }
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    ps_sweep<5>(p.gc + (((size_t)m * Hl + ctx_lo) >> 1), (ctx_hi - ctx_lo) >> 1, tid, PS_NC * 64, tag,
-                                p.err, 7, [&](const int i, const unsigned v) {
-                                    reinterpret_cast<unsigned*>(s.xs + (size_t)M * (Il + XPAD) + (size_t)m * (Hl + XPAD) + ctx_lo)[i] = v;
-                                });
-                }
-                stamp(l, 14);
-                if (lane == 0) {
-                    atomicAdd(&s.misc[32], 1);  // DS operations of a wave execute in order: the writes above are visible
-                }
-                load_p3_consts(l);
-                st.prime_lo();
-            }
-            stamp(l, 9);
-            st.template run<CTRL || !PS_FULL_P3>();
-            stamp(l, 10);
-            __syncthreads();
-            asm volatile("" : "+v"(tid));
-            // K pieces -> granules
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int idx = tid + k * PS_NT;
-                if (idx < nruns3 * M * 16) {
-                    const int j = idx / (M * 16), r = idx % (M * 16);
-                    float     v = 0.f;
-#pragma unroll
-                    for (int w = 0; w < PS_NW; w++) {
-                        v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
-                    }
-                    st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
-                }
-            }
-            const int  nmerge = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
-            const bool last   = (l == p.l_end - 1);
-            // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
-            const int inplace = (l > 0 && l < p.L - 1) ? 1 : 0;
-            __syncthreads();  // part / scales are free: the streamer waves start the next layer's weight stream now
-            // (the control waves carry the layer boundary's critical path -- pieces -> merge -> x' -> gather: they merge
-            // FIRST and fetch the next layer's constants afterwards, under the gather's wait)
-            if constexpr (!CTRL) {
-                if (l + 1 < p.l_end) {
-                    setup_p1(l + 1);
-                }
-            }
-            stamp(l, 11);
-            // merge the groups this workgroup owns (control waves) -> x'
-            if constexpr (CTRL) {
-#pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) {
-                    const int t = tid + k2 * PS_NC * 64;
-                    if (t < nmerge * M * 16) {
-                        const int k = t / (M * 16), r = t % (M * 16), m = r >> 4, c = r & 15;
-                        const int g = s.misc[1 + k];
-                        u64       gv[PS_MAXP];
-                        int       spins = 0;
-                        for (;;) {
-                            bool ok = true;
-#pragma unroll
-                            for (int q = 0; q < PS_MAXP; q++) {
-                                if (q < PA + PB) {
-                                    const int rid = (q < PA) ? NG * PB + q * NG + g : (q - PA) * NG + g;
-                                    gv[q]         = ld_granule(&p.gp[(size_t)rid * (M * 16) + r]);
-                                }
-                            }
-#pragma unroll
-                            for (int q = 0; q < PS_MAXP; q++) {
-                                if (q < PA + PB) {
-                                    ok &= ((unsigned)(gv[q] >> 32) == tag);
-                                }
-                            }
-                            if (ok || ps_give_up(spins, p.err, 4)) {
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        float sa = 0.f, sb = 0.f;
-#pragma unroll
-                        for (int q = 0; q < PS_MAXP; q++) {  // piece order: deterministic
-                            if (q < PA) {
-                                sa += __uint_as_float((unsigned)gv[q]);
-                            }
-                            else if (q < PA + PB) {
-                                sb += __uint_as_float((unsigned)gv[q]);
-                            }
-                        }
-                        const int    n    = g * 16 + c;
-                        const size_t oidx = (size_t)m * H + n;
-                        const f16    attn = (f16)sa, ffn = (f16)sb;
-                        const f16    xin  = (f16)((float)s.xraw[oidx] / (float)p.tp);
-                        const f16    bb   = r_bres[k2];
-                        f16          o;
-                        if (inplace) {
-                            o = (f16)((float)xin + (float)ffn + (float)attn + (float)bb);  // add_residual_kernels.cu:116-152
-                        }
-                        else {
-                            o = ((ffn + attn) + bb) + xin;
-                        }
-                        if (last) {
-                            p.x_out[oidx] = o;
-                        }
-                        else {
-                            const unsigned b0 = f16_bits(o);
-                            const unsigned b1 = __shfl_down(b0, 1, 64);
-                            if ((c & 1) == 0) {
-                                st_granule_u32(&p.gx[oidx >> 1], tag, b0 | (b1 << 16));
-                            }
-                        }
-                    }
-                }
-            }
-            if constexpr (CTRL) {
-                if (l + 1 < p.l_end) {
-                    setup_p1(l + 1);
-                }
-            }
-            stamp(l, 12);
-            // xraw is rewritten by the next layer's gather: only the two control waves touch it between here and the
-            // barrier after that gather, so they synchronise among themselves (the streamer waves are busy issuing
-            // their prefetch; a workgroup barrier here would make the gather wait for that)
-            if constexpr (CTRL) {
-                if (lane == 0) {
-                    atomicAdd(&s.misc[33], 1);
-                }
-                const int want = (l - p.l_begin + 1) * PS_NC;
-                while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[33]) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-        }
-    };
-    if (wid < PS_NC) {
-        body(std::true_type{});
-    }
-    else {
-        body(std::false_type{});
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
@@ -1457,7 +147,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
 template<bool INT8, int M, int DH, int UK>
 static const void* ps_kernel()
 {
-    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK>);
+    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false>);
 }
 static const void* ps_kernel_for(bool int8, int M, int dh, int uk)
 {
@@ -1484,9 +174,8 @@ static const void* ps_kernel_for(bool int8, int M, int dh, int uk)
 // THIS device (the attribute is per device, and launches of a multi-device process must not race on a static flag), and
 // the occupancy query must admit the grid.  A cooperative launch would add the same check at every launch for +15-19 us
 // per token (MI355X_MICROARCH.md "coop-launch"); checking once per plan is free.
-bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu)
+static bool ps_kernel_resident(const void* k, const PersistPlan& pl, int num_cu, long grid)
 {
-    const void* k = ps_kernel_for(int8, M, dh, pl.uk);
     if (!pl.ok || !k) {
         return false;
     }
@@ -1499,7 +188,18 @@ bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_c
         (void)hipGetLastError();
         return false;
     }
-    return per_cu >= 1 && (long)per_cu * num_cu >= pl.NB;
+    return per_cu >= 1 && (long)per_cu * num_cu >= grid;
+}
+bool persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world)
+{
+    return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, true), pl, num_cu, (long)pl.NB * world);
+}
+bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp)
+{
+    if (tp > 1) {
+        return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
+    }
+    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk), pl, num_cu, pl.NB);
 }
 
 void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
@@ -1508,11 +208,23 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = ps_kernel_for(int8, p.B, p.dh, p.plan.uk);
+    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk);
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
+    FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;
     void*         args[] = {&pp};
     FTCF_HIP_CHECK(hipLaunchKernel(k, dim3(p.plan.NB), dim3(PS_NT), args, p.plan.smem, s));
+}
+
+void launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipStream_t s)
+{
+    FTCF_CHECK_ARG(g.world >= 2 && g.world <= PERSIST_MAX_TP && g.nb >= 1, "bad local group");
+    const PersistParams& p = g.p[0];
+    const void*          k = persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
+    FTCF_CHECK_ARG(k != nullptr && p.plan.ok && p.plan.NB == g.nb, "persistent decode: no group kernel for this shape");
+    PersistGroupParams gg     = g;
+    void*              args[] = {&gg};
+    FTCF_HIP_CHECK(hipLaunchKernel(k, dim3(g.nb * g.world), dim3(PS_NT), args, p.plan.smem, s));
 }
 
 }  // namespace ftcf

@@ -19,6 +19,16 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 MID = dict(head_num=8, size_per_head=64, inter_size=2048, num_layer=3, vocab_size=2048, rotary_dim=16, start_id=0, end_id=2)
 
 
+@pytest.fixture(params=["in-kernel", "rccl-shaped"], autouse=True)
+def tp_decode_path(request, monkeypatch):
+    """Every test runs twice: with the product default for one or two rows -- the persistent decode kernel with the
+    all-reduce INSIDE the launch (exchange windows; in a local group all ranks run in one launch) -- and with
+    FTCF_TP_PERSIST=0, i.e. the per-stage launches + one all-reduce per layer that RCCL ranks fall back to when the
+    windows are unavailable.  Batches above two rows take the general path either way."""
+    monkeypatch.setenv("FTCF_TP_PERSIST", "1" if request.param == "in-kernel" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gh():
     from tests import gpu_helpers
@@ -65,7 +75,7 @@ def check_against(ref_tokens, ref_logits, got, S, what, frac=5e-3):
 
 
 @pytest.mark.parametrize("tp", [2, 4])
-def test_tiny_model_tensor_parallel_matches_tp1_and_oracle(gh, tp):
+def test_tiny_model_tensor_parallel_matches_tp1_and_oracle(gh, tp, tp_decode_path):
     cfg, w, z = load_tiny()
     layers, glob = weight_list_to_layers(cfg, w)
     ids = np.full((3, 16), cfg["end_id"], dtype=np.int32)
@@ -74,10 +84,10 @@ def test_tiny_model_tensor_parallel_matches_tp1_and_oracle(gh, tp):
     ids[2, :5] = z["prompt"][:5]
     lens = [16, 11, 5]
     o = orc.Model(dict(cfg, fp16=1), layers, glob).generate(ids, lens, 8, return_logits=True)
-    # one row: the per-stage launches (what a single row runs under tensor parallelism)
+    # one row: the persistent kernel with the in-launch all-reduce, or the per-stage launches
     res = run_tp(gh, cfg, w, tp, 0, ids[:1], lens[:1], 8, top_k=1)
     for r in range(tp):
-        assert res[r]["decode_path"] == 0
+        assert res[r]["decode_path"] == (1 if tp_decode_path == "in-kernel" else 0)
         assert res[r]["output_ids"].tolist() == res[0]["output_ids"].tolist()  # every rank holds the same tokens
         np.testing.assert_array_equal(res[r]["logits"], res[0]["logits"])      # ... and bit-identical gathered logits
     assert res[0]["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
@@ -93,7 +103,7 @@ def test_tiny_model_tensor_parallel_matches_tp1_and_oracle(gh, tp):
 
 @pytest.mark.parametrize("int8_mode", [0, 1])
 @pytest.mark.parametrize("tp", [2, 8])
-def test_mid_model_tensor_parallel(gh, tp, int8_mode):
+def test_mid_model_tensor_parallel(gh, tp, int8_mode, tp_decode_path):
     """8 heads x 64, H = 512, inter 2048, V = 2048: every TP degree the reference supports for it (heads % tp == 0)."""
     cfg = MID
     w = random_model(cfg, seed=11)
@@ -109,9 +119,10 @@ def test_mid_model_tensor_parallel(gh, tp, int8_mode):
     # TP = 1 engine on the same weights (its own quantisation of the full matrices)
     op1 = gh.make_op(cfg, w, int8_mode=int8_mode)
     r1 = gh.run_op(op1, ids, lens, out, cfg["vocab_size"], top_k=1)
-    for B in (1, 4):
+    for B in (1, 2, 4):
         res = run_tp(gh, cfg, w, tp, int8_mode, ids[:B], lens[:B], out, top_k=1)
-        assert res[0]["decode_path"] == (0 if B == 1 else 2)
+        assert res[0]["decode_path"] == (2 if B == 4 or (B == 2 and tp_decode_path != "in-kernel") else
+                                         (1 if tp_decode_path == "in-kernel" else 0))
         for r in range(1, tp):
             assert res[r]["output_ids"].tolist() == res[0]["output_ids"].tolist()
         # int8: a rank quantises its own shard -- per-column scales of column shards are the full matrix's, row shards
