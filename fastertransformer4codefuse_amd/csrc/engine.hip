@@ -257,6 +257,29 @@ static int comm_agree(ftcf_comm* c, int flag, hipStream_t s, int* d_scratch)
     return out;
 }
 
+// all-reduce (max) of a host int (local group: through the group's slots)
+static int comm_max(ftcf_comm* c, int v, hipStream_t s, int* d_scratch)
+{
+    if (c->local) {
+        LocalGroup& g = *c->local;
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        g.slot[c->rank] = reinterpret_cast<void*>((intptr_t)v);
+        g.barrier();
+        int m = v;
+        for (int r = 0; r < g.world; r++) {
+            m = std::max(m, (int)(intptr_t)g.slot[r]);
+        }
+        g.barrier();
+        return m;
+    }
+    FTCF_HIP_CHECK(hipMemcpyAsync(d_scratch, &v, sizeof(int), hipMemcpyHostToDevice, s));
+    FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMax, c->comm, s));
+    int out = 0;
+    FTCF_HIP_CHECK(hipMemcpyAsync(&out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    return out;
+}
+
 static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
 {
     bytes = (bytes + 4095) & ~(size_t)4095;
@@ -800,6 +823,9 @@ struct ftcf_gptneox {
         for (void* p : owned) {
             (void)hipFree(p);
         }
+        if (ses.graph_exec) {
+            (void)hipGraphExecDestroy(ses.graph_exec);
+        }
         if (tp_scratch) {
             (void)hipFree(tp_scratch);
         }
@@ -1064,6 +1090,15 @@ struct ftcf_gptneox {
         for (int r = 0; r < PERSIST_MAX_TP; r++) {
             pp.xw[r] = (cfg.tensor_para_size > 1 && cfg.comm && r < (int)cfg.comm->win.size())
                            ? static_cast<unsigned long long*>(cfg.comm->win[r]) : nullptr;
+        }
+        if (cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->world == 1 && !cfg.comm->win.empty()) {
+            // timing aid (bench.py --fake-tp N: ONE rank of a TP = N job without its peers): the rank plays every peer --
+            // "slot [rank] of rank r's window" is made to land in slot [r] of its own -- so that the kernel's exchange
+            // completes (the sums are meaningless, the work and the waits of a rank are all there)
+            for (int r = 0; r < cfg.tensor_para_size && r < PERSIST_MAX_TP; r++) {
+                pp.xw[r] = static_cast<unsigned long long*>(cfg.comm->win[0])
+                           + (ptrdiff_t)(r - cfg.tensor_para_rank) * ((ptrdiff_t)B * H / 2);
+            }
         }
         pp.plan = pplan;
         pp.d_step = &state->step;
@@ -1358,15 +1393,59 @@ struct ftcf_gptneox {
         hipGraphExec_t    graph_exec = nullptr;
     } ses;
     bool use_graph = true;
+    // drops whatever an unfinished request left behind: the captured graph holds the OLD arena pointers, shapes and sampling
+    // flags, and plan() may free that arena -- replaying it for the next request would corrupt memory silently
+    void abandon_session()
+    {
+        if (!ses.active && !ses.graph_exec) {
+            return;
+        }
+        (void)hipStreamSynchronize(stream);
+        if (ses.graph_exec) {
+            (void)hipGraphExecDestroy(ses.graph_exec);
+            ses.graph_exec = nullptr;
+        }
+        if (ses.e0) {
+            event_pool.push_back(ses.e0);
+            ses.e0 = nullptr;
+        }
+        if (ses.e1) {
+            event_pool.push_back(ses.e1);
+            ses.e1 = nullptr;
+        }
+        drain_events();
+        ses.active = false;
+    }
     void begin(const ftcf_forward_args& a);
     void enqueue_step(bool with_decoder);
     int  step(int max_steps);
     void finish();
+    bool persist_failed = false;  // the persistent kernel gave up on a hand-off during the last request
+    int  persist_fail_once = 0;
     void forward(const ftcf_forward_args& a)
     {
         begin(a);
         step(a.output_len);
-        finish();
+        try {
+            finish();
+        }
+        catch (const Error&) {
+            if (!persist_failed) {
+                throw;
+            }
+            // The persistent kernel's hand-offs need every workgroup resident; the plan checks that, but compute units can
+            // still be taken away (another process, a masked CU) after the check.  Its spins are bounded and report through
+            // a sticky error word instead of hanging the GPU; the request is then replayed from the start on the
+            // per-stage / general path (tensor parallel: every rank takes this branch -- finish() agrees on the error
+            // word across the ranks) and the engine stays off the persistent path.
+            persist_failed = false;
+            persist        = 0;
+            fprintf(stderr, "[ftcf] persistent decode kernel gave up on a hand-off: replaying the request on the "
+                            "per-stage path (this engine stays there)\n");
+            begin(a);
+            step(a.output_len);
+            finish();
+        }
     }
 };
 
@@ -1405,6 +1484,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     const int K = a.beam_width, batch = a.batch_size;
     FTCF_CHECK_ARG(K >= 1 && K <= BEAM_MAX_K, "beam_width must be in [1, 64]");
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
+    abandon_session();  // (a request left open -- begin / step without finish, or a step that threw -- must not leak its graph)
     // everything the caller enqueued on its stream (input tensors) happens-before the engine's work
     FTCF_HIP_CHECK(hipEventRecord(ev_user, user_stream));
     FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_user, 0));
@@ -1727,7 +1807,7 @@ int ftcf_gptneox::step(int max_steps)
         // token is launched first and the host only waits for the PREVIOUS token's event: the GPU never idles for the
         // host round trip (~25 us per token).  `finished` is sticky on the device, so the one speculative step that may
         // run after every row has finished only rewrites end_id / leaves the lengths alone.
-        if (graph_ok && !a.callback) {
+        if (graph_ok && !a.callback && tp == 1) {  // (tp > 1: every rank must leave the loop at the SAME token -> synchronous)
             hipEvent_t& ev = tok_ev[done & 1];
             if (!ev) {
                 FTCF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1796,6 +1876,7 @@ void ftcf_gptneox::finish()
     stats.decode_steps = ses.steps;
     event_pool.push_back(ses.e0);
     event_pool.push_back(ses.e1);
+    ses.e0 = ses.e1 = nullptr;
     ses.active = false;
     if (ses.graph_exec) {
         (void)hipGraphExecDestroy(ses.graph_exec);
@@ -1812,7 +1893,15 @@ void ftcf_gptneox::finish()
             fclose(f);
         }
     }
+    if (pplan.ok && persist_fail_once) {  // test hook (FTCF_PERSIST_FAIL_ONCE=1): pretend the kernel gave up once
+        persist_fail_once = 0;
+        ps_error          = 99;
+    }
+    if (pplan.ok && cfg.tensor_para_size > 1) {
+        ps_error = comm_max(cfg.comm, ps_error, stream, tp_scratch);  // every rank learns of any rank's failure
+    }
     if (ps_error != 0) {
+        persist_failed = true;
         throw Error(-2, "persistent decode kernel gave up waiting for a hand-off (code " + std::to_string(ps_error)
                             + "): not every workgroup was resident");
     }
@@ -1849,6 +1938,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->user_stream = (hipStream_t)cfg->stream;
         FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_user, hipEventDisableTiming));
+        // weights still being uploaded / produced on the caller's stream happen-before the re-tiling below
+        FTCF_HIP_CHECK(hipEventRecord(e->ev_user, e->user_stream));
+        FTCF_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_user, 0));
         FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
         FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
                        "hidden, local hidden and local inter sizes must be multiples of 64");
@@ -1928,6 +2020,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_PERSIST")) {
             e->persist = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_PERSIST_FAIL_ONCE")) {
+            e->persist_fail_once = atoi(m);
         }
         if (const char* m = getenv("FTCF_TP_PERSIST")) {
             e->persist_tp = atoi(m);

@@ -34,9 +34,15 @@ def tiny():
     return cfg, w, layers, glob, z
 
 
-def _logit_close(got, ref, frac=0.02):
+# End-to-end bound on |GPU logits - oracle logits| / max|logit|.  The engine reproduces the oracle's elementwise rounding
+# points and differs only by fp32 accumulation order and the three documented attention differences:
+# measured 1.2e-3 .. 1.3e-3 on the golden model; 5e-3 leaves room for longer contexts and int8, not for a lost rounding point.
+LOGIT_FRAC = 5e-3
+
+
+def _logit_close(got, ref, frac=LOGIT_FRAC):
     scale = np.abs(ref).max()
-    assert np.abs(got - ref).max() <= frac * scale, (np.abs(got - ref).max(), scale)
+    assert np.abs(got - ref).max() <= frac * scale, (np.abs(got - ref).max() / scale, frac)
 
 
 def test_tiny_fp16_greedy_is_token_exact_vs_hf_golden_and_oracle(gh, tiny, decode_path):
@@ -45,6 +51,10 @@ def test_tiny_fp16_greedy_is_token_exact_vs_hf_golden_and_oracle(gh, tiny, decod
     r = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
     assert op.stats()["decode_path"] == (1 if decode_path == "persistent" else 0)  # the path under test really ran
     assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
+    # directly against HF's fp32 logits (tests/golden/make_golden.py): the fp16 engine's distance from the fp32 model is the
+    # half rounding of activations and KV cache -- 1.0e-3 .. 1.5e-3 of max|logit| in the oracle's fp16 mode; bound 4e-3
+    hf = z["hf_logits"]
+    assert np.abs(r["logits"][:, 0, :] - hf).max() <= 4e-3 * np.abs(hf).max(), np.abs(r["logits"][:, 0, :] - hf).max() / np.abs(hf).max()
     o = orc.Model(dict(cfg, fp16=1), layers, glob).generate(z["prompt"][None, :], [16], 8, return_logits=True)
     assert r["output_ids"].tolist() == o["output_ids"].tolist()
     _logit_close(r["logits"], o["logits"])
@@ -109,11 +119,11 @@ def test_mid_model_fused_and_general_decode_paths(gh, B, int8_mode):
         gen_o = o["output_ids"][b, lens[b]:lens[b] + out]
         for t in range(out):
             ref = o["logits"][t, b]
-            _logit_close(r["logits"][t, b], ref, frac=0.03)
+            _logit_close(r["logits"][t, b], ref)
             total_checked += 1
             if gen_r[t] != gen_o[t]:
                 top2 = np.sort(ref)[-2:]
-                assert top2[1] - top2[0] < 0.03 * np.abs(ref).max(), "token flip without a near tie"
+                assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(ref).max(), "token flip without a near tie"
                 break
     assert total_checked >= B * 2
 
@@ -199,7 +209,7 @@ def test_persistent_kernel_variants_agree(gh, monkeypatch, decode_path, variant,
     else:
         for t in range(out):
             for b in range(B):
-                _logit_close(got["logits"][t, b], ref["logits"][t, b], frac=0.02)
+                _logit_close(got["logits"][t, b], ref["logits"][t, b])
                 if got["output_ids"][b, lens[b] + t] != ref["output_ids"][b, lens[b] + t]:
                     break
 
@@ -219,7 +229,7 @@ def test_long_sequences_leave_the_single_pass_attention_forms(gh, tiny):
         _logit_close(r["logits"][t, 0], o["logits"][t, 0])
         if gen_r[t] != gen_o[t]:
             top2 = np.sort(o["logits"][t, 0])[-2:]
-            assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
+            assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
             break
     assert r["sequence_lengths"].tolist() == o["sequence_lengths"].tolist()
 
@@ -246,7 +256,7 @@ def test_sequential_residual_layers_follow_hf_and_oracle(gh, tiny, int8_mode):
             _logit_close(r["logits"][t, b], o["logits"][t, b])
             if r["output_ids"][b, 16 + t] != o["output_ids"][b, 16 + t]:
                 top2 = np.sort(o["logits"][t, b])[-2:]
-                assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
+                assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
                 break
     if not int8_mode:
         assert r["output_ids"][0, 16:].tolist() == s["hf_tokens"].tolist()
@@ -281,7 +291,7 @@ def test_one_engine_serves_requests_of_changing_shape(gh, tiny):
         o = m.generate(ids, lens, out, return_logits=True)
         for b in range(B):
             for t in range(out):
-                _logit_close(r["logits"][t, b], o["logits"][t, b], frac=0.03)
+                _logit_close(r["logits"][t, b], o["logits"][t, b])
                 if o["output_ids"][b, lens[b] + t] == cfg["end_id"] or \
                         r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
                     break
@@ -308,7 +318,7 @@ def test_persistent_kernel_long_key_ranges(gh, tiny, monkeypatch, decode_path):
         _logit_close(r["logits"][t, 0], o["logits"][t, 0])
         if r["output_ids"][0, S + t] != o["output_ids"][0, S + t]:
             top2 = np.sort(o["logits"][t, 0])[-2:]
-            assert top2[1] - top2[0] < 0.02 * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
+            assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(o["logits"][t, 0]).max(), "token flip without a near tie"
             break
 
 
@@ -429,8 +439,49 @@ def test_mid_model_long_ragged_prefill(gh, int8_mode):
     o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode), layers, glob).generate(ids, lens, out, return_logits=True)
     for b in range(2):
         for t in range(out):
-            _logit_close(r["logits"][t, b], o["logits"][t, b], frac=0.03)
+            _logit_close(r["logits"][t, b], o["logits"][t, b])
             if r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
                 top2 = np.sort(o["logits"][t, b])[-2:]
-                assert top2[1] - top2[0] < 0.03 * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
+                assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
                 break
+
+
+def test_request_is_replayed_off_the_persistent_path_when_its_kernel_gives_up(gh, tiny, monkeypatch, decode_path):
+    """The persistent kernel reports a hand-off it gave up on through a sticky error word (bounded spins, no hang);
+    forward() then replays the request on the per-stage path and the engine stays there (FTCF_PERSIST_FAIL_ONCE is the
+    test hook that raises the error word once)."""
+    if decode_path != "persistent":
+        pytest.skip("persistent path only")
+    cfg, w, layers, glob, z = tiny
+    monkeypatch.setenv("FTCF_PERSIST_FAIL_ONCE", "1")
+    op = gh.make_op(cfg, w)
+    r = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 0  # the replay ran the per-stage launches
+    assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
+    r2 = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 0 and r2["output_ids"].tolist() == r["output_ids"].tolist()
+
+
+def test_begin_without_finish_then_a_new_request(gh, tiny):
+    """A request left open (begin + step, no finish) must not leak its captured graph into the next request."""
+    import ctypes as C
+    import torch
+    from fastertransformer4codefuse_amd import capi
+    cfg, w, layers, glob, z = tiny
+    op = gh.make_op(cfg, w)
+    ref = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
+    ids = torch.from_numpy(np.ascontiguousarray(z["prompt"][None, :], dtype=np.int32)).cuda()
+    lens = torch.tensor([16], dtype=torch.int32).cuda()
+    out_ids = torch.empty((1, 1, 40), dtype=torch.int32, device="cuda")
+    seq = torch.empty((1, 1), dtype=torch.int32, device="cuda")
+    top_k = np.array([1], np.int32)
+    fa = capi.ForwardArgs()
+    fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+    fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = 1, 16, 24, 1  # a different total length
+    fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+    fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+    capi.check(capi.lib().ftcf_gptneox_begin(op._h, C.byref(fa)))
+    capi.check(capi.lib().ftcf_gptneox_step(op._h, 5, None))  # ... and never finished
+    again = gh.run_op(op, z["prompt"][None, :], [16], 8, cfg["vocab_size"], top_k=1)
+    assert again["output_ids"].tolist() == ref["output_ids"].tolist()
+    np.testing.assert_array_equal(again["logits"], ref["logits"])

@@ -55,7 +55,7 @@ def test_full_size_properties(full, monkeypatch):
     assert np.array_equal(tb[0], tb[1]) and np.array_equal(lb[:, 0], lb[:, 1])
     scale = np.abs(l1).max()
     for t in range(out):
-        assert np.abs(lb[t, 0] - l1[t, 0]).max() <= 0.03 * scale
+        assert np.abs(lb[t, 0] - l1[t, 0]).max() <= 5e-3 * scale
         if tb[0, S + t] != t1[0, S + t]:
             break
     del op
@@ -65,10 +65,10 @@ def test_full_size_properties(full, monkeypatch):
     t0, l0 = _run(op0, ids1, out, V)
     assert op0.stats()["decode_path"] == 0
     for t in range(out):
-        assert np.abs(l0[t, 0] - l1[t, 0]).max() <= 0.03 * scale
+        assert np.abs(l0[t, 0] - l1[t, 0]).max() <= 5e-3 * scale
         if t0[0, S + t] != t1[0, S + t]:
             top2 = np.sort(l1[t, 0])[-2:]
-            assert top2[1] - top2[0] <= 0.03 * scale, "paths disagree without a near tie"
+            assert top2[1] - top2[0] <= 5e-3 * scale, "paths disagree without a near tie"
             break
     # prompt tokens come back unchanged, generated ids are in range
     assert np.array_equal(t1[0, :S], ids1.cpu().numpy()[0]) and (t1[0, S:] >= 0).all() and (t1[0, S:] < V).all()

@@ -64,10 +64,10 @@ def test_random_configuration_follows_the_oracle(gh, seed):
         for t in range(out):
             ref = o["logits"][t, b]
             scale = np.abs(ref).max()
-            assert np.abs(r["logits"][t, b] - ref).max() <= 0.04 * scale, (what, b, t)
+            assert np.abs(r["logits"][t, b] - ref).max() <= 5e-3 * scale, (what, b, t, np.abs(r["logits"][t, b] - ref).max() / scale)
             if o["output_ids"][b, lens[b] + t] == cfg["end_id"]:
                 break  # the row finished: later logits are not consumed
             if r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
                 top2 = np.sort(ref)[-2:]
-                assert top2[1] - top2[0] <= 0.04 * scale, ("token flip without a near tie", what, b, t)
+                assert top2[1] - top2[0] <= 1e-2 * scale, ("token flip without a near tie", what, b, t)
                 break

@@ -55,27 +55,37 @@ def test_fp32_single_token_prompt_skips_prefill(tiny):
     np.testing.assert_allclose(r["logits"][:, 0, :], z["hf_logits_1"], atol=2e-4, rtol=1e-4)
 
 
-def test_fp16_emulation_stays_close_to_fp32(tiny):
+@pytest.mark.parametrize("which", ["", "_b", "_1"])
+def test_fp16_emulation_stays_close_to_fp32(tiny, which):
+    """The oracle's fp16 mode (binary16 at every point the reference stores `half`) against HF's fp32 logits, all three
+    golden prompts.  Measured 0.9e-3 .. 1.5e-3 of max|logit| per step (the half rounding of activations and of the
+    KV cache); the bound is 2x that -- a rounding point restated wrongly (e.g. LayerNorm output kept in fp32, or the
+    attention probabilities rounded to half) moves the error outside it or flips tokens."""
     cfg, layers, glob, z = tiny
     m = _model(cfg, layers, glob, fp16=1)
-    prompt = z["prompt"][None, :]
-    r = m.generate(prompt, [16], 8, return_logits=True)
-    ref = z["hf_logits"]
-    err = np.abs(r["logits"][:, 0, :] - ref)
-    assert err.max() < 0.08 * np.abs(ref).max()
-    assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
+    prompt = z["prompt" + which][None, :]
+    n = prompt.shape[1]
+    ref = z["hf_logits" + which]
+    r = m.generate(prompt, [n], ref.shape[0], return_logits=True)
+    err = np.abs(r["logits"][:, 0, :] - ref).max(axis=1) / np.abs(ref).max()
+    assert err.max() < 3e-3, err
+    assert err.min() > 1e-4, "suspiciously exact: is the fp16 mode on?"
+    assert r["output_ids"][0, n:].tolist() == z["hf_tokens" + which].tolist()
 
 
-def test_int8_weight_only_stays_close(tiny):
+@pytest.mark.parametrize("which", ["", "_b", "_1"])
+def test_int8_weight_only_stays_close(tiny, which):
+    """Weight-only int8 (per-column symmetric scales) against HF's fp32 logits: the quantisation error itself, measured
+    1.0e-2 .. 2.0e-2 of max|logit| on this model; bound 3e-2, tokens equal on all three golden prompts."""
     cfg, layers, glob, z = tiny
     m = _model(cfg, quantize_layers(layers), glob, fp16=1, int8_mode=1)
-    prompt = z["prompt"][None, :]
-    r = m.generate(prompt, [16], 8, return_logits=True)
-    ref = z["hf_logits"]
-    rel = np.abs(r["logits"][:, 0, :] - ref).max() / np.abs(ref).max()
-    assert rel < 0.15
-    # first token has a comfortable margin in this fixture
-    assert r["output_ids"][0, 16] == z["hf_tokens"][0]
+    prompt = z["prompt" + which][None, :]
+    n = prompt.shape[1]
+    ref = z["hf_logits" + which]
+    r = m.generate(prompt, [n], ref.shape[0], return_logits=True)
+    rel = np.abs(r["logits"][:, 0, :] - ref).max(axis=1) / np.abs(ref).max()
+    assert rel.max() < 3e-2, rel
+    assert r["output_ids"][0, n:].tolist() == z["hf_tokens" + which].tolist()
 
 
 def test_end_id_finishes_row_and_fills(tiny):
