@@ -42,8 +42,11 @@ constexpr int PS_MAXMERGE = 8;           // groups merged per workgroup
 constexpr int PS_MAXP     = 16;          // PA + PB
 constexpr int PS_SPIN     = 1 << 18;
 constexpr int PS_UK       = 8;           // attention: K (and V) wave-loads per lane (256 keys per workgroup) ...
-constexpr int PS_UK_LONG  = 12;          // ... or 12 (384 keys) for requests whose KV split does not fit 256: a second
-                                         // instantiation, because the 8-deep form scores 1 % better where both fit
+constexpr int PS_UK_LONG  = 16;          // ... or 16 (512 keys: 3072 tokens of context at six splits) for requests whose KV
+                                         // split does not fit 256.  A second instantiation: 128 VGPRs of rows do not fit beside
+                                         // the weight stream's register batches, so the long form keeps its rows IN those
+                                         // batches (idle between the two streams) -- and the short form, the headline's, keeps
+                                         // the code it was tuned with
 #ifndef PS_FULL_P1_V
 #define PS_FULL_P1_V false
 #endif
@@ -395,14 +398,37 @@ template<int DH, int UK>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
     static constexpr int KPI = 64 / LPK;
-    u32x4 kreg[UK], vreg[UK];
+    static constexpr bool ALIAS = UK > PS_U;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
+    static_assert(UK <= 2 * PS_U, "K rows live in R0|R1, V rows in R2|R3");
+    u32x4 kreg[ALIAS ? 1 : UK], vreg[ALIAS ? 1 : UK];
+    template<typename ST>
+    __device__ __forceinline__ u32x4& kr(ST& st, const int u)
+    {
+        if constexpr (ALIAS) {
+            return u < PS_U ? st.R0[u % PS_U] : st.R1[u % PS_U];
+        }
+        else {
+            return kreg[u];
+        }
+    }
+    template<typename ST>
+    __device__ __forceinline__ u32x4& vr(ST& st, const int u)
+    {
+        if constexpr (ALIAS) {
+            return u < PS_U ? st.R2[u % PS_U] : st.R3[u % PS_U];
+        }
+        else {
+            return vreg[u];
+        }
+    }
     unsigned mask_bits, bias2;
     int      tl, chunk, t_beg;
     float    rot_cs, rot_sn;
     bool     fin;
 
     // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table
-    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx)
+    template<typename ST>
+    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st)
     {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
@@ -418,13 +444,13 @@ struct PsAttn {
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             t       = t < t_last ? t : t_last;
-            kreg[u] = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
+            kr(st, u) = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
         }
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             t       = t < t_last ? t : t_last;
-            vreg[u] = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+            vr(st, u) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
         }
         mask_bits = 0u;
         if (p.masked_tokens && sub == 0) {
@@ -482,8 +508,9 @@ struct PsAttn {
         }
     }
     // returns false when the row is finished (nothing published)
+    template<typename ST>
     __device__ __forceinline__ bool compute(const PersistParams& p, PsLayerC& lw, char* smem, u64* gout,
-                                            const unsigned tag, int h, int b, const int tx)
+                                            const unsigned tag, int h, int b, const int tx, ST& st)
     {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
@@ -536,7 +563,7 @@ struct PsAttn {
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            const f16x8 kv = __builtin_bit_cast(f16x8, kreg[u]);
+            const f16x8 kv = __builtin_bit_cast(f16x8, kr(st, u));
             float       a  = 0.f;
             a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
             a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
@@ -598,7 +625,7 @@ struct PsAttn {
             const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
                 const float pt = s_p[t - t_beg];
-                const f16x8 vv = __builtin_bit_cast(f16x8, vreg[u]);
+                const f16x8 vv = __builtin_bit_cast(f16x8, vr(st, u));
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     acc[j] = fmaf(pt, (float)vv[j], acc[j]);
@@ -768,6 +795,13 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         }
     }();
     constexpr int TK = TileK<INT8>::value;
+    // Values assigned under a condition inside the layer loop (the LayerNorm parameters of the NEXT layer, fetched under
+    // `l + 1 < l_end`) are carried around the loop by the compiler: 32 VGPRs live through both weight streams.  The long
+    // attention form needs them back, so it makes those assignments unconditional (clamped; after the last layer the
+    // loads are harmless re-reads); so do the two-row and tensor-parallel forms, which spilled 35-41 VGPRs without it.
+    // The short one-row form -- the headline's -- keeps the code it was tuned with: the same change
+    // there measured -0.7 % (profiles/r02_notes.md: hipcc's allocation of this kernel moves +-2 % with anything).
+    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB;
     const int     wid = threadIdx.x >> 6;
@@ -967,7 +1001,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
 #pragma unroll
             for (int k = 0; k < PS_NLN; k++) {
                 const int v = tid + k * PS_NT;
-                if (v * 8 < H) {
+                if constexpr (NOCARRY) {  // unconditional, clamped (see NOCARRY)
+                    const int o = (v * 8 < H) ? v * 8 : 0;
+                    r_ln[0][k]  = *PS_G(f16x8, lw.ln1_g + o);
+                    r_ln[1][k]  = *PS_G(f16x8, lw.ln1_b + o);
+                    r_ln[2][k]  = *PS_G(f16x8, lw.ln2_g + o);
+                    r_ln[3][k]  = *PS_G(f16x8, lw.ln2_b + o);
+                }
+                else if (v * 8 < H) {
                     r_ln[0][k] = *PS_G(f16x8, lw.ln1_g + v * 8);
                     r_ln[1][k] = *PS_G(f16x8, lw.ln1_b + v * 8);
                     r_ln[2][k] = *PS_G(f16x8, lw.ln2_g + v * 8);
@@ -1005,7 +1046,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     }
                 }
             }
-            if (l + 1 < p.l_end) {
+            if constexpr (NOCARRY) {
+                load_sc1(l + 1 < p.l_end ? l + 1 : l);
+            }
+            else if (l + 1 < p.l_end) {
                 load_sc1(l + 1);
             }
         };
@@ -1193,12 +1237,20 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             stamp(l, 5);
             bool live = false;
             u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
+            if constexpr (PsAttn<DH, UK>::ALIAS) {
+                // (rows in the stream's register batches: requested UNCONDITIONALLY -- a workgroup without an item reads
+                // item 0's rows for nothing -- because registers assigned under a condition carry their previous contents,
+                // here all four weight batches, around the layer loop: 30 spilled VGPRs)
+                at.issue(p, lw, a_h, a_b, a_sp, tid, st);
+            }
             if (has_item) {
                 // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
-                at.issue(p, lw, a_h, a_b, a_sp, tid);
+                if constexpr (!PsAttn<DH, UK>::ALIAS) {
+                    at.issue(p, lw, a_h, a_b, a_sp, tid, st);
+                }
                 at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
                 stamp(l, 6);
-                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid);
+                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
             }
             if constexpr (CTRL) {
                 // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there).
@@ -1283,7 +1335,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             // (the control waves carry the layer boundary's critical path -- pieces -> merge -> x' -> gather: they merge
             // FIRST and fetch the next layer's constants afterwards, under the gather's wait)
             if constexpr (!CTRL) {
-                if (l + 1 < p.l_end) {
+                if constexpr (NOCARRY) {
+                    setup_p1(l + 1 < p.l_end ? l + 1 : l);
+                }
+                else if (l + 1 < p.l_end) {
                     setup_p1(l + 1);
                 }
             }
@@ -1357,7 +1412,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 }
             }
             if constexpr (CTRL) {
-                if (l + 1 < p.l_end) {
+                if constexpr (NOCARRY) {
+                    setup_p1(l + 1 < p.l_end ? l + 1 : l);
+                }
+                else if (l + 1 < p.l_end) {
                     setup_p1(l + 1);
                 }
             }

@@ -302,8 +302,9 @@ def test_one_engine_serves_requests_of_changing_shape(gh, tiny):
 
 
 def test_persistent_kernel_long_key_ranges(gh, tiny, monkeypatch, decode_path):
-    """KV splits of more than 256 keys per 8 wave-loads (here 704 keys at size_per_head 64 with 24 workgroups, 6 splits)
-    select the 12-deep instantiation of the persistent kernel's attention; logits follow the oracle."""
+    """KV splits of more than 8 wave-loads of keys per lane (here 704 keys at size_per_head 64 with 24 workgroups, 6 splits)
+    select the 16-deep instantiation of the persistent kernel's attention (rows held in the weight stream's register
+    batches); logits follow the oracle.  (The 13B shape takes that form on the full grid: tests/test_gpu_fullsize.py.)"""
     if decode_path != "persistent":
         pytest.skip("persistent path only")
     monkeypatch.setenv("FTCF_PERSIST_NB", "24")

@@ -74,6 +74,51 @@ def test_full_size_properties(full, monkeypatch):
     assert np.array_equal(t1[0, :S], ids1.cpu().numpy()[0]) and (t1[0, S:] >= 0).all() and (t1[0, S:] < V).all()
 
 
+def test_full_size_long_context_stays_on_the_persistent_kernel(full, monkeypatch):
+    """2560-token prompt + generation up to 3072 tokens of context: KV splits of 512 keys select the 16-deep attention form
+    of the persistent kernel (round 1 fell to the per-stage launches beyond 2304 tokens); against the per-stage path."""
+    a = full[0]
+    V, S, out = a.vocab, 2560, 4
+    g = torch.Generator().manual_seed(46)
+    ids = torch.randint(3, V, (1, S), generator=g, dtype=torch.int32).cuda()
+    lens = torch.full((1,), S, dtype=torch.int32, device="cuda")
+
+    def run(op):
+        dbg = torch.zeros((out, 1, V), dtype=torch.float32, device="cuda")
+        # (output_len 512: the request is planned for 3072 tokens of context; four steps of it run)
+        from fastertransformer4codefuse_amd import capi
+        import ctypes as C
+        out_ids = torch.empty((1, 1, S + 512), dtype=torch.int32, device="cuda")
+        seq = torch.empty((1, 1), dtype=torch.int32, device="cuda")
+        top_k = np.array([1], np.int32)
+        fa = capi.ForwardArgs()
+        fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+        fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = 1, S, 512, 1
+        fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+        fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+        fa.debug_logits = dbg.data_ptr()
+        capi.check(capi.lib().ftcf_gptneox_begin(op._h, C.byref(fa)))
+        capi.check(capi.lib().ftcf_gptneox_step(op._h, out, None))
+        capi.check(capi.lib().ftcf_gptneox_finish(op._h))
+        torch.cuda.synchronize()
+        return out_ids[0, 0].cpu().numpy(), dbg.cpu().numpy(), op.stats()["decode_path"]
+
+    op = _op(full)
+    t1, l1, path1 = run(op)
+    assert path1 == 1
+    del op
+    monkeypatch.setenv("FTCF_PERSIST", "0")
+    t0, l0, path0 = run(_op(full))
+    assert path0 == 0
+    scale = np.abs(l0).max()
+    for t in range(out):
+        assert np.abs(l0[t, 0] - l1[t, 0]).max() <= 5e-3 * scale, (t, np.abs(l0[t, 0] - l1[t, 0]).max() / scale)
+        if t0[S + t] != t1[S + t]:
+            top2 = np.sort(l0[t, 0])[-2:]
+            assert top2[1] - top2[0] <= 1e-2 * scale
+            break
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE config 2: CodeFuse-13B fp16, TP=1, bs=1, 1024-in (25 GB of fp16 weights + their tiled copies)
 # ---------------------------------------------------------------------------------------------------------------------
