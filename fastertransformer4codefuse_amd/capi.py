@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("FTCF_LIB_NAME", "libftcf.so"))  # env: kernel-variant experiments
 
 UNIQUE_ID_BYTES = 128
-FP32, FP16 = 0, 1
+FP32, FP16, BF16 = 0, 1, 2
 ACT_NONE, ACT_GELU = 0, 1
 
 

@@ -536,7 +536,7 @@ extern "C" int ftcf_comm_allgather(ftcf_comm_t c, void* buf, size_t count_per_ra
 extern "C" int ftcf_symmetric_quantize_int8(const void* weight, ftcf_dtype dtype, size_t E, size_t K, size_t N,
                                             int8_t* out_q, void* out_scale)
 {
-    return guarded([&] { host_symmetric_quantize_int8(weight, dtype == FTCF_FP16, E, K, N, out_q, out_scale); });
+    return guarded([&] { host_symmetric_quantize_int8(weight, (int)dtype, E, K, N, out_q, out_scale); });
 }
 extern "C" int ftcf_int8_rowmajor_to_tiled(const int8_t* q, size_t K, size_t N, int8_t* out)
 {

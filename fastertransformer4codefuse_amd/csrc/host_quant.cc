@@ -53,6 +53,32 @@ void host_int8_tiled_to_rowmajor(const int8_t* q, size_t K, size_t N, int8_t* ou
     }
 }
 
+// bfloat16 as the reference's __nv_bfloat16 instantiation sees it (WeightOnlyQuantOps.cc:205,
+// symmetric_quantize<__nv_bfloat16, __nv_bfloat16>): float(x) is exact, T(float) rounds to nearest even
+struct bf16_t {
+    uint16_t bits;
+    bf16_t() = default;
+    explicit bf16_t(float f)
+    {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) {
+            bits = (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
+        }
+        else {
+            u += 0x7fffu + ((u >> 16) & 1u);
+            bits = (uint16_t)(u >> 16);
+        }
+    }
+    explicit operator float() const
+    {
+        const uint32_t u = (uint32_t)bits << 16;
+        float          f;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+};
+
 template<typename T>
 static void quantize_one(const T* w, size_t K, size_t N, int8_t* q_rowmajor, T* scale)
 {
@@ -84,18 +110,23 @@ static void quantize_one(const T* w, size_t K, size_t N, int8_t* q_rowmajor, T* 
     }
 }
 
-void host_symmetric_quantize_int8(const void* weight, bool is_half, size_t E, size_t K, size_t N, int8_t* out_q,
+void host_symmetric_quantize_int8(const void* weight, int dtype, size_t E, size_t K, size_t N, int8_t* out_q,
                                   void* out_scale)
 {
+    FTCF_CHECK_ARG(dtype >= 0 && dtype <= 2, "weight dtype must be fp32 (0), fp16 (1) or bf16 (2)");
     FTCF_CHECK_ARG(weight && out_q && out_scale, "NULL tensor");
     FTCF_CHECK_ARG(E >= 1 && K >= 1 && N >= 1, "empty weight");
     FTCF_CHECK_ARG(K % TILE_K_I8 == 0 && N % TILE_N == 0,
                    "weight-only int8 needs K % 64 == 0 (as the reference, fpA_intB_gemm_template.h:159-163) and N % 16 == 0");
     std::vector<int8_t> tmp(K * N);
     for (size_t e = 0; e < E; e++) {
-        if (is_half) {
+        if (dtype == 1) {
             quantize_one<f16>(reinterpret_cast<const f16*>(weight) + e * K * N, K, N, tmp.data(),
                               reinterpret_cast<f16*>(out_scale) + e * N);
+        }
+        else if (dtype == 2) {
+            quantize_one<bf16_t>(reinterpret_cast<const bf16_t*>(weight) + e * K * N, K, N, tmp.data(),
+                                 reinterpret_cast<bf16_t*>(out_scale) + e * N);
         }
         else {
             quantize_one<float>(reinterpret_cast<const float*>(weight) + e * K * N, K, N, tmp.data(),

@@ -153,9 +153,24 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
         __syncthreads();
     }
     if (need_sm) {  // addBiasSoftMax (sampling_topp_kernels.cu:1296-1345)
-        float mx = -FLT_MAX;
-        for (int i = tid; i < V; i += nt) {
-            mx = fmaxf(mx, l[i]);
+        // One workgroup per row, three passes (max ; sum of exp ; exp / sum).  Every pass keeps 16 loads per thread in
+        // flight (a plain `for (i = tid; i < V; i += nt)` loop is ~99 DEPENDENT round trips per pass at V = 100864: 62 us per
+        // token with return_cum_log_probs, which the reference harness always sets -- codefuse_example.py:745) and the
+        // un-normalised exponentials are not written back in between.  Element -> thread assignment and summation order
+        // are those of the plain loop: bit-identical probabilities.
+        constexpr int UNR = 16;
+        float         mx  = -FLT_MAX;
+        for (int i0 = tid; i0 < V; i0 += nt * UNR) {
+            float t[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * nt;
+                t[u]        = i < V ? l[i] : -FLT_MAX;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                mx = fmaxf(mx, t[u]);
+            }
         }
         mx = wave_max(mx);
         if ((tid & 63) == 0) {
@@ -168,10 +183,19 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
         }
         __syncthreads();
         float sum = 0.f;
-        for (int i = tid; i < V; i += nt) {
-            const float e = __expf(l[i] - mx);
-            l[i]          = e;
-            sum += e;
+        for (int i0 = tid; i0 < V; i0 += nt * UNR) {
+            float t[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * nt;
+                t[u]        = i < V ? l[i] : -FLT_MAX;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                if (i0 + u * nt < V) {
+                    sum += __expf(t[u] - mx);
+                }
+            }
         }
         sum = wave_sum(sum);
         if ((tid & 63) == 0) {
@@ -183,8 +207,20 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
             tot += red[w];
         }
         const float den = tot + 1e-6f;
-        for (int i = tid; i < V; i += nt) {
-            l[i] = l[i] / den;
+        for (int i0 = tid; i0 < V; i0 += nt * UNR) {
+            float t[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * nt;
+                t[u]        = i < V ? l[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u * nt;
+                if (i < V) {
+                    l[i] = __expf(t[u] - mx) / den;
+                }
+            }
         }
     }
 }

@@ -223,15 +223,14 @@ def symmetric_quantize_last_axis_of_batched_matrix_int8(weight):
         raise RuntimeError("weight should not be empty tensor")
     if weight.dim() not in (2, 3):
         raise RuntimeError("Invalid dim. The dim of weight should be 2 or 3")
-    if weight.dtype == torch.bfloat16:
-        raise RuntimeError("bf16 weights are not supported by the MI355X quantiser yet")
-    if weight.dtype not in (torch.float32, torch.float16):
+    if weight.dtype not in (torch.float32, torch.float16, torch.bfloat16):
         raise RuntimeError("Invalid datatype. Weight must be FP16 or BF16")
     E = 1 if weight.dim() == 2 else int(weight.size(0))
     K, N = int(weight.size(-2)), int(weight.size(-1))
     q = torch.empty(weight.shape, dtype=torch.int8)
     scales = torch.empty((N,) if weight.dim() == 2 else (E, N), dtype=weight.dtype)
     capi.check(capi.lib().ftcf_symmetric_quantize_int8(
-        C.c_void_p(weight.data_ptr()), capi.FP16 if weight.dtype == torch.float16 else capi.FP32, C.c_size_t(E),
+        C.c_void_p(weight.data_ptr()),
+        {torch.float16: capi.FP16, torch.bfloat16: capi.BF16, torch.float32: capi.FP32}[weight.dtype], C.c_size_t(E),
         C.c_size_t(K), C.c_size_t(N), C.c_void_p(q.data_ptr()), C.c_void_p(scales.data_ptr())))
     return [q, scales]

@@ -32,7 +32,7 @@ typedef enum {
     FTCF_ERR_NO_DEVICE   = -5
 } ftcf_status;
 
-typedef enum { FTCF_FP32 = 0, FTCF_FP16 = 1 } ftcf_dtype;
+typedef enum { FTCF_FP32 = 0, FTCF_FP16 = 1, FTCF_BF16 = 2 /* host quantiser input only */ } ftcf_dtype;
 typedef enum { FTCF_ACT_NONE = 0, FTCF_ACT_GELU = 1 } ftcf_act;
 
 const char* ftcf_last_error(void);
@@ -47,7 +47,8 @@ int ftcf_device_count(void);
  *             kernels/cutlass_kernels/cutlass_preprocessors.cc:576-673 (symmetric_quantize) +
  *             :500-539 (preprocess_weights_for_mixed_gemm -- here: the gfx950 tile layout)
  * ================================================================================================ */
-/* weight: host [E, K, N] row major (E = 1 for a 2-D matrix), dtype FTCF_FP32 or FTCF_FP16.
+/* weight: host [E, K, N] row major (E = 1 for a 2-D matrix), dtype FTCF_FP32, FTCF_FP16 or FTCF_BF16
+ * (WeightOnlyQuantOps.cc:149,205).
  * out_q : host int8 [E, K, N] bytes, ENGINE-PRIVATE gfx950 tile layout (opaque, like the reference's).
  * out_scale: host [E, N] in the weight dtype.  Requires K % 64 == 0 and N % 16 == 0. */
 int ftcf_symmetric_quantize_int8(const void* weight, ftcf_dtype dtype, size_t E, size_t K, size_t N, int8_t* out_q,

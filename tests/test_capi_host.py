@@ -104,3 +104,28 @@ def test_full_size_quantize_and_layout_round_trips():
     err = (q_rm.float() * s.float()[None, :] - w.float()).abs()
     lim = torch.where(q_rm == 127, s.float()[None, :] * 1.0, s.float()[None, :] * 0.5) + 1e-6
     assert bool((err <= lim).all())
+
+
+def test_quantiser_accepts_bf16_like_the_reference():
+    """WeightOnlyQuantOps.cc:149,205: bf16 weights go through symmetric_quantize<__nv_bfloat16, __nv_bfloat16> -- float(x)
+    of every element, fp32 column maxima, int8 = round(w / (max / 128)) with the UNROUNDED scale, scales stored as bf16."""
+    import torch
+    from fastertransformer4codefuse_amd.gptneox_op import symmetric_quantize_last_axis_of_batched_matrix_int8 as qf
+    from fastertransformer4codefuse_amd import capi
+    import ctypes as C
+    torch.manual_seed(3)
+    K, N = 128, 48
+    w = (torch.randn(K, N) * 0.05).to(torch.bfloat16).contiguous()
+    q, s = qf(w)
+    assert q.dtype == torch.int8 and s.dtype == torch.bfloat16 and tuple(s.shape) == (N,)
+    wf = w.float()
+    col = wf.abs().max(dim=0).values / 128.0
+    assert torch.equal(s, col.to(torch.bfloat16))  # round-to-nearest-even of the fp32 scale
+    quo = wf / col
+    ref = torch.clamp(torch.sign(quo) * torch.floor(quo.abs() + 0.5), -128, 127).to(torch.int8)  # std::round: half away from 0
+    q_rm = torch.empty((K, N), dtype=torch.int8)
+    capi.check(capi.lib().ftcf_int8_tiled_to_rowmajor(capi.vp(q), C.c_size_t(K), C.c_size_t(N), capi.vp(q_rm)))
+    assert torch.equal(q_rm, ref)
+    # the same values as fp32 input: identical integers, fp32 scales
+    q32, s32 = qf(wf.contiguous())
+    assert torch.equal(q32, q) and torch.equal(s32, col)
