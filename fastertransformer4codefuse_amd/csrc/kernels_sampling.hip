@@ -145,7 +145,10 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
     __syncthreads();
     const bool fin      = p.finished[b];
     const bool is_topp  = p.top_k[b] == 0;
-    const bool need_sm  = is_topp || p.return_cum_log_probs;
+    // (top-k rows with cum_log_probs: the reference runs the same softmax over the whole row and samples from the
+    // probabilities -- here the row's max and sum of exponentials fall out of the stage-1 slice scans and only the k
+    // candidates are turned into probabilities, in k_sample: no extra pass over the vocabulary)
+    const bool need_sm  = is_topp;
     if (fin) {  // addBiasEndMask (sampling_topk_kernels.cu:67-110)
         for (int i = tid; i < V; i += nt) {
             l[i] = (i == p.end_id) ? FLT_MAX : -FLT_MAX;
@@ -244,10 +247,37 @@ __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, flo
     const int    i0 = blk * slice;
     const int    n  = max(0, min(slice, V - i0));
     const float* l  = p.logits + (size_t)b * V + i0;
+    float lmax = -FLT_MAX;
     for (int i = threadIdx.x; i < n; i += 256) {
-        sv[i] = l[i];
+        const float v = l[i];
+        sv[i]         = v;
+        lmax          = fmaxf(lmax, v);
     }
     __syncthreads();
+    if (p.return_cum_log_probs && p.top_k[b] > 0) {  // softmax statistics of the slice: {max, sum of exp(v - max)}
+        lmax = wave_max(lmax);
+        if ((threadIdx.x & 63) == 0) {
+            redv[threadIdx.x >> 6] = lmax;
+        }
+        __syncthreads();
+        const float m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+        __syncthreads();
+        float se = 0.f;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            se += __expf(sv[i] - m);
+        }
+        se = wave_sum(se);
+        if ((threadIdx.x & 63) == 0) {
+            redv[threadIdx.x >> 6] = se;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* st = reinterpret_cast<float*>(cand_i + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX) + ((size_t)b * TOPK_BLOCKS + blk) * 2;
+            st[0]     = n > 0 ? m : -FLT_MAX;
+            st[1]     = n > 0 ? ((redv[0] + redv[1]) + (redv[2] + redv[3])) : 0.f;
+        }
+        __syncthreads();
+    }
     float* ov = cand_v + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
     int*   oi = cand_i + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
     uint32_t* taken = reinterpret_cast<uint32_t*>(sv + slice);  // [ceil(slice/32)]
@@ -333,10 +363,26 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
         if (threadIdx.x == 0) {
             const float smax = sv[0];
             float       ssum = 0.f;
+            float       row_max = 0.f, row_den = 1.f;
+            if (p.return_cum_log_probs) {  // addBiasSoftMax of the row (sampling_topp_kernels.cu:1296-1345) from the slice statistics
+                const float* st = reinterpret_cast<const float*>(cand_i + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX) + (size_t)b * TOPK_BLOCKS * 2;
+                row_max         = -FLT_MAX;
+                for (int q = 0; q < TOPK_BLOCKS; q++) {
+                    row_max = fmaxf(row_max, st[2 * q]);
+                }
+                float tot = 0.f;
+                for (int q = 0; q < TOPK_BLOCKS; q++) {
+                    tot += st[2 * q + 1] * __expf(st[2 * q] - row_max);
+                }
+                row_den = tot + 1e-6f;
+            }
             for (int i = 0; i < k; i++) {
                 float u = sv[i];
                 if (!p.return_cum_log_probs) {
                     u = __expf(u - smax);  // :271-275
+                }
+                else {
+                    u = __expf(u - row_max) / row_den;  // the probability the reference's in-place softmax leaves there
                 }
                 sv[i] = u;
                 ssum += u;
@@ -487,7 +533,8 @@ void launch_decode_finish(const SamplingParams& p, hipStream_t s)
 size_t sampling_workspace_bytes(int B, int V)
 {
     (void)V;
-    return (size_t)B * TOPK_BLOCKS * TOPK_MAX * (sizeof(float) + sizeof(int));
+    // candidate values + ids of the stage-1 slices, then {max, sum of exp} per slice
+    return (size_t)B * TOPK_BLOCKS * TOPK_MAX * (sizeof(float) + sizeof(int)) + (size_t)B * TOPK_BLOCKS * 2 * sizeof(float);
 }
 
 void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
