@@ -7,12 +7,15 @@
 //   GptNeoXDecoder        <- models/gptneox/GptNeoXDecoder.cc:197-389 (one token through L layers)
 //   DecoderSelfAttentionLayer / FfnLayer / DynamicDecodeLayer are the launch helpers used by those.
 #include <rccl/rccl.h>
+#include <roctracer/roctx.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/ftcf.h"
@@ -124,6 +127,96 @@ struct ftcf_comm {
             throw Error(FTCF_ERR_COMM, std::string("RCCL error ") + ncclGetErrorString(_r) + " (" #expr ")");          \
         }                                                                                                              \
     } while (0)
+
+// Host wait on a stream that carries RCCL work (utils/nccl_utils.cc:215-272, ftNcclStreamSynchronize): instead of blocking
+// in hipStreamSynchronize -- where a dead or hung peer hangs this rank for good -- poll the stream and the communicator's
+// asynchronous error state; an asynchronous error or FTCF_COMM_TIMEOUT_S seconds without progress (default 600, 0 = wait for
+// ever) aborts the communicator and raises FTCF_ERR_COMM.  Single-rank and local-group communicators block plainly.
+static double comm_timeout_s()
+{
+    static const double t = [] {
+        const char* e = getenv("FTCF_COMM_TIMEOUT_S");
+        return e ? atof(e) : 600.0;
+    }();
+    return t;
+}
+template<typename Query>
+static void comm_wait(ftcf_comm* c, Query&& query, const char* what)
+{
+    const auto   t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_s();
+    for (long spin = 0;; spin++) {
+        const hipError_t e = query();
+        if (e == hipSuccess) {
+            return;
+        }
+        if (e != hipErrorNotReady) {
+            throw Error(FTCF_ERR_HIP, std::string("HIP error while waiting for ") + what + ": " + hipGetErrorString(e));
+        }
+        if ((spin & 63) == 63) {
+            ncclResult_t async = ncclSuccess;
+            FTCF_NCCL_CHECK(ncclCommGetAsyncError(c->comm, &async));
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const bool   late = limit > 0 && waited > limit;
+            if (async != ncclSuccess || late) {
+                (void)ncclCommAbort(c->comm);  // the reference does the same and leaves the communicator unusable
+                c->comm = nullptr;
+                throw Error(FTCF_ERR_COMM,
+                            late ? std::string("tensor-parallel peer made no progress for ") + std::to_string((int)waited)
+                                       + " s while waiting for " + what + " (FTCF_COMM_TIMEOUT_S); communicator aborted" :
+                                   std::string("RCCL asynchronous error ") + ncclGetErrorString(async) + " while waiting for "
+                                       + what + "; communicator aborted");
+            }
+            if (waited > 1e-3) {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    }
+}
+static void comm_stream_sync(ftcf_comm* c, hipStream_t s, const char* what = "the engine stream")
+{
+    if (!c || c->local || c->world == 1 || !c->comm) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
+    comm_wait(c, [&] { return hipStreamQuery(s); }, what);
+}
+static void comm_event_sync(ftcf_comm* c, hipEvent_t ev, const char* what = "a recorded event")
+{
+    if (!c || c->local || c->world == 1 || !c->comm) {
+        FTCF_HIP_CHECK(hipEventSynchronize(ev));
+        return;
+    }
+    comm_wait(c, [&] { return hipEventQuery(ev); }, what);
+}
+
+// roctx ranges around the host-side phases (utils/nvtx_utils.cc:59-87: FT_NVTX=ON there, FTCF_ROCTX=ON here; rocprofv3
+// --marker-trace shows them).  The per-token kernels inside a replayed hipGraph carry no ranges: the range is the token.
+static bool roctx_on()
+{
+    static const bool on = [] {
+        const char* e = getenv("FTCF_ROCTX");
+        return e && (std::string(e) == "ON" || std::string(e) == "1");
+    }();
+    return on;
+}
+struct Range {
+    bool on;
+    explicit Range(const char* name): on(roctx_on())
+    {
+        if (on) {
+            roctxRangePushA(name);
+        }
+    }
+    ~Range()
+    {
+        if (on) {
+            roctxRangePop();
+        }
+    }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 
 // ---- local group collectives (test infrastructure, see above) ----
 __global__ void k_local_allreduce_f16(f16* out, const f16* const* src, int world, size_t n)
@@ -243,7 +336,7 @@ static void comm_barrier(ftcf_comm* c, hipStream_t s, int* d_scratch)
         return;
     }
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
-    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    comm_stream_sync(c, s, "a tensor-parallel collective");
 }
 
 // all-reduce (min) of a host flag over the communicator
@@ -253,7 +346,7 @@ static int comm_agree(ftcf_comm* c, int flag, hipStream_t s, int* d_scratch)
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
     int out = 0;
     FTCF_HIP_CHECK(hipMemcpyAsync(&out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, s));
-    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    comm_stream_sync(c, s, "a tensor-parallel collective");
     return out;
 }
 
@@ -276,7 +369,7 @@ static int comm_max(ftcf_comm* c, int v, hipStream_t s, int* d_scratch)
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMax, c->comm, s));
     int out = 0;
     FTCF_HIP_CHECK(hipMemcpyAsync(&out, d_scratch, sizeof(int), hipMemcpyDeviceToHost, s));
-    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    comm_stream_sync(c, s, "a tensor-parallel collective");
     return out;
 }
 
@@ -345,7 +438,7 @@ static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
     FTCF_HIP_CHECK(hipMemcpyAsync(d_recs + c->rank, &me, sizeof(Rec), hipMemcpyHostToDevice, s));
     FTCF_NCCL_CHECK(ncclAllGather(d_recs + c->rank, d_recs, sizeof(Rec), ncclChar, c->comm, s));
     FTCF_HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs, sizeof(Rec) * c->world, hipMemcpyDeviceToHost, s));
-    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    comm_stream_sync(c, s, "a tensor-parallel collective");
     int ok = 1;
     for (int r = 0; r < c->world; r++) {
         ok &= recs[r].ok;
@@ -382,7 +475,7 @@ static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
                            0x5eedu, d_res, (long long)200000000);  // 100 MHz ticks: 2 s
         int res = 0;
         FTCF_HIP_CHECK(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, s));
-        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        comm_stream_sync(c, s, "a tensor-parallel collective");
         (void)hipFree(d_win);
         ok = comm_agree(c, res, s, d_scratch);
         if (ok) {
@@ -1000,6 +1093,7 @@ struct ftcf_gptneox {
     void allreduce(f16* buf, size_t count)
     {
         if (cfg.tensor_para_size > 1) {
+            Range r("ftcf.allreduce");
             FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local), "tensor_para_size > 1 needs a communicator");
             if (cfg.comm->local) {
                 local_allreduce(cfg.comm, buf, count, true, stream);
@@ -1013,6 +1107,7 @@ struct ftcf_gptneox {
     // B prompt rows; their K/V go to cache rows b * tile of a cache with B * tile rows (beam search: tile = beam_width)
     void context_decoder(int B, int S, const int* input_lengths, int s_max, int tile)
     {
+        Range r("ftcf.GptNeoXContextDecoder");
         const int    M       = B * S;
         const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;
         // parallel-residual layers: both LayerNorms in one pass, fused with the previous layer's residual when no collective
@@ -1115,6 +1210,7 @@ struct ftcf_gptneox {
     // GptNeoXDecoder::forward (GptNeoXDecoder.cc:245-384)
     void decoder(int B, int s_max)
     {
+        Range r("ftcf.GptNeoXDecoder");
         const double wbytes  = int8 ? 1.0 : 2.0;
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
         const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual;
@@ -1477,6 +1573,7 @@ static std::vector<T> broadcast_arg(const T* p, int n, int B, T dflt, const char
 
 void ftcf_gptneox::begin(const ftcf_forward_args& a)
 {
+    Range r("ftcf.begin");
     const int B = a.batch_size * (a.beam_width > 0 ? a.beam_width : 1);  // rows
     const int S = a.max_input_len, out_len = a.output_len;
     FTCF_CHECK_ARG(a.batch_size >= 1 && S >= 1 && out_len >= 1, "batch_size, max_input_len and output_len must be >= 1");
@@ -1552,7 +1649,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         FTCF_HIP_CHECK(hipMemcpyAsync(d_div, divr.data(), batch * 4, hipMemcpyHostToDevice, stream));
         FTCF_HIP_CHECK(hipMemcpyAsync(d_lenpen, lenp.data(), batch * 4, hipMemcpyHostToDevice, stream));
     }
-    FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // the host vectors die at scope exit
+    comm_stream_sync(cfg.comm, stream);  // the host vectors die at scope exit
 
     hipEvent_t e0 = get_event(), e1 = get_event();
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
@@ -1588,7 +1685,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         }
         FTCF_HIP_CHECK(hipMemcpyAsync(d_players, pl.data(), sizeof(PersistLayer) * L, hipMemcpyHostToDevice, stream));
         FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
-        FTCF_HIP_CHECK(hipStreamSynchronize(stream));  // `pl` dies at scope exit
+        comm_stream_sync(cfg.comm, stream);  // `pl` dies at scope exit
     }
     // beam search: the reference tiles the inputs K times and runs the context phase on all batch * K rows
     // (GptNeoX.cc:560-574, 640-735).  Every beam reads the prompt K/V of beam 0 anyway (the cache indirection starts at 0),
@@ -1755,6 +1852,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
 // the token loop of GptNeoX<T>::forward (GptNeoX.cc:776-1048); returns the number of iterations executed
 int ftcf_gptneox::step(int max_steps)
 {
+    Range r("ftcf.step");
     FTCF_CHECK_ARG(ses.active, "no request in flight: call ftcf_gptneox_begin first");
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
     const ftcf_forward_args& a = ses.a;
@@ -1814,14 +1912,14 @@ int ftcf_gptneox::step(int max_steps)
             }
             FTCF_HIP_CHECK(hipEventRecord(ev, stream));
             if (lagging) {
-                FTCF_HIP_CHECK(hipEventSynchronize(tok_ev[(done - 1) & 1]));
+                comm_event_sync(cfg.comm, tok_ev[(done - 1) & 1]);
                 ses.all_finished = h_flags[0] != 0;
             }
             lagging = true;
             continue;
         }
         lagging = false;
-        FTCF_HIP_CHECK(hipStreamSynchronize(stream));
+        comm_stream_sync(cfg.comm, stream);
         ses.all_finished = h_flags[0] != 0;
         if (a.callback && step + 1 < total && cfg.tensor_para_rank == 0) {
             // pybind_callback_utils.cc:22-103: last token of every row; a row that did not advance reports end_id
@@ -1837,7 +1935,7 @@ int ftcf_gptneox::step(int max_steps)
         }
     }
     FTCF_HIP_CHECK(hipEventRecord(eb, stream));
-    FTCF_HIP_CHECK(hipEventSynchronize(eb));
+    comm_event_sync(cfg.comm, eb, "the prefill");
     if (lagging) {
         ses.all_finished = h_flags[0] != 0;
     }
@@ -1851,6 +1949,7 @@ int ftcf_gptneox::step(int max_steps)
 
 void ftcf_gptneox::finish()
 {
+    Range r("ftcf.finish");
     FTCF_CHECK_ARG(ses.active, "no request in flight");
     const ftcf_forward_args& a = ses.a;
     // setOutputTensors (GptNeoX.cc:1090-1181)
@@ -1869,7 +1968,7 @@ void ftcf_gptneox::finish()
     if (pplan.ok) {
         FTCF_HIP_CHECK(hipMemcpyAsync(&ps_error, ps_err, sizeof(int), hipMemcpyDeviceToHost, stream));
     }
-    FTCF_HIP_CHECK(hipStreamSynchronize(stream));
+    comm_stream_sync(cfg.comm, stream);
     float ms = 0.f;
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ses.e0, ses.e1));
     stats.prefill_ms   = ms;

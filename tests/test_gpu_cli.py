@@ -110,3 +110,38 @@ def test_cli_example_beam_search_matches_the_hf_beams(tmp_path):
     for k in range(3):
         assert rows[k][:16] == g["ids_a"][0].tolist()
         assert rows[k][16:] == g["hf_beam_tokens_a"][0, k].tolist()
+
+
+def test_roctx_ranges_show_up_in_a_marker_trace(tmp_path):
+    """FTCF_ROCTX=ON (the counterpart of FT_NVTX=ON, utils/nvtx_utils.cc:59-87): the host phases of a request are bracketed
+    by roctx ranges that `rocprofv3 --marker-trace` records; without the variable nothing is emitted and tokens are the same."""
+    import glob
+    import shutil
+    from fastertransformer4codefuse_amd import capi
+    capi.require_gpu()
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        pytest.skip("rocprofv3 not installed")
+    cfg, w, z = load_tiny()
+    mdir = tmp_path / "1-gpu"
+    mdir.mkdir()
+    write_checkpoint(str(mdir), cfg, w, 0)
+    ini = tmp_path / "gptneox_config.ini"
+    ini.write_text("[ft_instance_hyperparameter]\ndata_type=fp16\ntensor_para_size=1\npipeline_para_size=1\nint8_mode=0\n"
+                   "model_name=tiny\nmodel_dir=%s\n\n[request]\nbeam_width=1\ntop_k=1\ntop_p=0.0\n"
+                   "temperature=1.0\nrepetition_penalty=1.0\nrequest_batch_size=1\nrequest_output_len=8\n" % mdir)
+    ids = tmp_path / "start_ids.csv"
+    ids.write_text(", ".join(map(str, z["prompt"].tolist())) + "\n")
+    out = tmp_path / "out"
+    env = dict(os.environ, FTCF_ROCTX="ON", TMPDIR=str(tmp_path))
+    r = subprocess.run([prof, "--marker-trace", "--output-format", "csv", "-d", str(tmp_path / "prof"), "--",
+                        EXE, str(ini), "--start_ids", str(ids), "--out", str(out)],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [list(map(int, line.split())) for line in out.read_text().strip().splitlines()]
+    assert rows[0][16:] == z["hf_tokens"].tolist()
+    traces = glob.glob(str(tmp_path / "prof" / "**" / "*marker*trace*.csv"), recursive=True)
+    assert traces, "no marker trace written: %s" % r.stderr[-1000:]
+    text = "".join(open(t).read() for t in traces)
+    for name in ("ftcf.begin", "ftcf.GptNeoXContextDecoder", "ftcf.GptNeoXDecoder", "ftcf.finish"):
+        assert name in text, name
