@@ -666,7 +666,7 @@ extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, vo
 // ---------------------------------------------------------------------------------------------------------------
 static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m,
                           int n, int k, bool int8, hipStream_t s, float* smallm_ws = nullptr, size_t smallm_partial = 0,
-                          int num_cu = 256)
+                          int num_cu = 256, const int* d_step = nullptr, unsigned* smallm_seq = nullptr)
 {
     if (m <= 4) {
         SplitKParams p{};
@@ -684,7 +684,8 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
         launch_gemv_splitk(p, int8, m, EPI_PLAIN, s);
     }
     else if (m <= 16) {
-        launch_gemm_smallm(A, W, scale, bias, act, C, smallm_ws, smallm_partial, m, n, k, int8, num_cu, s);
+        launch_gemm_smallm(A, W, scale, bias, act, C, smallm_ws, smallm_partial, m, n, k, int8, num_cu, s, d_step,
+                           smallm_seq);
     }
     else {
         launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s);
@@ -884,6 +885,7 @@ struct ftcf_gptneox {
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
     size_t    smallm_partial = 0;
+    unsigned  smallm_seq = 0;       // launch counter: part of the granule tag of its in-launch reduction
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
     int *  tiled_ids = nullptr, *tiled_len = nullptr, *parent_ids = nullptr, *cache_indir = nullptr;
     void*  beam_ws = nullptr;
@@ -1087,7 +1089,7 @@ struct ftcf_gptneox {
         // (the split-K workspace is sized for the decode rows; a short prefill may bring more rows than that)
         const bool ws_ok = smallm_ws && m <= 16 && gemm_smallm_workspace_bytes(m, n, k, int8) <= smallm_partial;
         gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, ws_ok ? smallm_ws : nullptr, smallm_partial,
-                      num_cu);
+                      num_cu, &state->step, &smallm_seq);
     }
 
     void allreduce(f16* buf, size_t count)
@@ -1304,12 +1306,12 @@ struct ftcf_gptneox {
                     const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
                                               {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
                     timed(KIND_SMALLM, wbytes * H * (3.0 * hl + il),
-                          [&] { launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, stream); });
+                          [&] { launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, stream, &state->step, &smallm_seq); });
                     launch_mmha(mp, stream);
                     const SmallmDesc p3[2] = {{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl},
                                               {mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}};
                     timed(KIND_SMALLM, wbytes * H * ((double)hl + il),
-                          [&] { launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream); });
+                          [&] { launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream, &state->step, &smallm_seq); });
                 }
                 else {
                     gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
@@ -1656,8 +1658,8 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
     FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, std::min(B, 4), 8), stream));
     if (smallm_ws) {
-        FTCF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(smallm_ws) + smallm_partial, 0, gemm_smallm_ticket_bytes(),
-                                      stream));
+        // granules of the batched-decode GEMMs' in-launch reduction: their tags repeat from request to request
+        FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), stream));
     }
     if (pplan.ok) {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
@@ -1964,9 +1966,13 @@ void ftcf_gptneox::finish()
     if (a.cum_log_probs) {
         FTCF_HIP_CHECK(hipMemcpyAsync(a.cum_log_probs, cum, (size_t)ses.B * 4, hipMemcpyDeviceToDevice, stream));
     }
-    int ps_error = 0;
+    int ps_error = 0, smallm_error = 0;
     if (pplan.ok) {
         FTCF_HIP_CHECK(hipMemcpyAsync(&ps_error, ps_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    }
+    if (smallm_ws) {
+        FTCF_HIP_CHECK(hipMemcpyAsync(&smallm_error, reinterpret_cast<char*>(smallm_ws) + smallm_partial, sizeof(int),
+                                      hipMemcpyDeviceToHost, stream));
     }
     comm_stream_sync(cfg.comm, stream);
     float ms = 0.f;
@@ -1998,6 +2004,9 @@ void ftcf_gptneox::finish()
     }
     if (pplan.ok && cfg.tensor_para_size > 1) {
         ps_error = comm_max(cfg.comm, ps_error, stream, tp_scratch);  // every rank learns of any rank's failure
+    }
+    if (smallm_error != 0) {
+        throw Error(-2, "batched decode GEMM: a split-K reducer gave up waiting for its sibling workgroups' partial sums");
     }
     if (ps_error != 0) {
         persist_failed = true;

@@ -85,10 +85,13 @@ struct SmallmDesc {  // C[m, n] = epilogue(A[m, k] x W[k, n]); act 1 = bias + ge
     int         n, k;
 };
 // one launch for up to two independent GEMMs with the same m (partial_bytes >= the SUM of their workspace bytes)
+// d_step: device-resident decode step (part of the launch's granule tag, a replayed hipGraph freezes scalars) or NULL;
+// seq: the workspace's launch counter (host).  The granules must be zero when a request begins.
 void   launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
-                                hipStream_t s);
+                                hipStream_t s, const int* d_step, unsigned* seq);
 void   launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
-                          size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s);
+                          size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s,
+                          const int* d_step = nullptr, unsigned* seq = nullptr);
 // logits_f32[m, n] = A[m,k] x W[n,k]^T (row major fp16 weights, m > 4)
 void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s);
 

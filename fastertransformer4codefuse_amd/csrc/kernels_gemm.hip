@@ -51,10 +51,11 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 // MFMA peak at m = 1024); NG = 2 halves that.  Block tile: (RG*16) x (WAVES * NG * 16); the waves of a workgroup share the A
 // tile in LDS, so WAVES = 8 halves the number of workgroups re-reading A from L2 (prefill is L2-traffic bound: at m = 1024
 // a 128 x 128 tile moves 1.2 GB of A and 0.6 GB of weights through the L2 for the QKV GEMM).
-template<bool INT8, int RG, int NG, int WAVES>
+template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false>
 __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
-                                                    int act, f16* __restrict__ C, int m, int n, int k)
+                                                    int act, f16* __restrict__ C, int m, int n, int k, int gx = 0,
+                                                    int gy = 0)
 {
     constexpr int BM   = RG * 16;
     constexpr int NTHR = 64 * WAVES;
@@ -62,8 +63,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * BM;
-    const int nt0 = (blockIdx.x * WAVES + wid) * NG;  // first column group of this wave
+    int bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (XCD) {
+        // 1-D grid; workgroup b runs on XCD b % 8.  The gy row blocks of one weight panel go to ONE XCD, in consecutive
+        // slots (they run together and share the panel through that XCD's L2 instead of fetching it 8 times over the fabric)
+        const int b = blockIdx.x, c = b & 7, sl = b >> 3;
+        bx          = (sl / gy) * 8 + c;
+        by          = sl % gy;
+        if (bx >= gx) {
+            return;
+        }
+    }
+    const int m0 = by * BM;
+    const int nt0 = (bx * WAVES + wid) * NG;  // first column group of this wave
     const int NT = n / 16;
     const int  ksteps = k / GEMM_KSTEP;
 
@@ -128,11 +140,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if constexpr (INT8) {
-                br[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)ks * 64);
+                br[j][0] = NT_W ? __builtin_nontemporal_load(wp[j] + (size_t)ks * 64) : wp[j][(size_t)ks * 64];
             }
             else {
-                br[j][0] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks) * 64);
-                br[j][1] = __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks + 1) * 64);
+                br[j][0] = NT_W ? __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks) * 64) : wp[j][(size_t)(2 * ks) * 64];
+                br[j][1] = NT_W ? __builtin_nontemporal_load(wp[j] + (size_t)(2 * ks + 1) * 64) : wp[j][(size_t)(2 * ks + 1) * 64];
             }
         }
     };
@@ -246,27 +258,32 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         }
     }
     else {
-        // (RG, NG) = (8, 2) measured best on the 13B prefill: 50.7 ms vs 57.8 (8, 1), 61.0 (8, 4: one wave per SIMD),
-        // 53.4 (4, 4), 53.8 (4, 2)
+        // Block tile 128 x 256 (RG, NG, WAVES) = (8, 2, 8).  Measured on the 13B layer at m = 1024 (tools/bench_gemm.py, us per
+        // layer of four GEMMs): 128 x 512 tiles 1006, 64 x 256 tiles 857, this 760; with `nt` weight loads and the plain
+        // 2-D grid 791 (int8) / 932 (fp16 weights).  hipBLASLt on the same fp16 shapes: 651-762 depending on the layout.
+        // Two things matter more than the tile: (1) the weight panel of a column block is read by every row block, so it is
+        // loaded with the default cache policy (the decode kernels' `nt` would drop it from the L2), and (2) the row blocks
+        // of one panel are placed on ONE XCD, next to each other in time (1-D grid, workgroup b runs on XCD b % 8): the panel
+        // crosses the fabric once instead of once per XCD.  Few tiles (m <= 512 with n = 5120: < 160 workgroups for 256
+        // CUs) -> 64-row tiles.
         constexpr int NG = 2;
-        static const int waves = getenv("FTCF_GEMM_WAVES") ? atoi(getenv("FTCF_GEMM_WAVES")) : 8;
-        if (waves == 8) {
-            dim3 grid((NT + 8 * NG - 1) / (8 * NG), (m + 127) / 128);
+        const int     gx = (NT + 8 * NG - 1) / (8 * NG);
+        const bool    small = (long)gx * ((m + 127) / 128) < 160;
+        const int     gy = small ? (m + 63) / 64 : (m + 127) / 128;
+        dim3          grid(8 * ((gx + 7) / 8) * gy);
+        if (small) {
             if (int8) {
-                hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 8>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k);
+                hipLaunchKernelGGL((k_gemm_tiled<true, 4, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
             }
             else {
-                hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 8>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k);
+                hipLaunchKernelGGL((k_gemm_tiled<false, 4, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
             }
-            FTCF_HIP_CHECK(hipGetLastError());
-            return;
         }
-        dim3          grid((NT + 4 * NG - 1) / (4 * NG), (m + 127) / 128);
-        if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+        else if (int8) {
+            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 4>), grid, dim3(256), 0, s, A, W, scale, bias, act, C, m, n, k);
+            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());
@@ -435,10 +452,21 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, 
 // latency bound: a workgroup lives for three dependent memory round trips to move 20 KiB per wave.  Here K is cut into
 // slices of <= SMB_T tiles and every wave requests its WHOLE slice (20 KiB, 80 VGPRs) in one go, together with the
 // workgroup's x slice (16 rows x slice_k, through LDS once): one round trip per workgroup, the whole matrix is in flight
-// at once and the launch lasts about bytes / HBM rate.  Partial sums [ks][m][n] are reduced inside the launch (tickets).
+// at once and the launch lasts about bytes / HBM rate -- IF a workgroup's slot (registers, LDS) is handed to the next
+// workgroup as soon as its weights have arrived.  Hence the shape of the split-K reduction: partial sums travel as 8-byte
+// {tag, value} granules (attn_device.cuh; one relaxed agent-scope store each, the data is its own flag), every workgroup
+// but the one that owns the LAST slice of a column block leaves right after issuing its stores, and that last one --
+// dispatched after all of its siblings -- polls their granules, adds them in slice order (deterministic) and applies the
+// epilogue.  (The first version took a ticket per workgroup after waiting for its stores to complete: two more memory
+// round trips per workgroup; 40.2 -> 38.7 us per launch of the 13B layer's GEMM pairs at 16 rows.  What bounds the launch
+// is that a slot streams nothing while its workgroup computes, leaves and is replaced: ~60 % of the in-flight capacity.)
+// tag = f(decode step, launch) is unique per launch within a request; the engine zeroes the granules when a request begins.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SMB_T       = 20;    // tiles per wave and slice
-constexpr int SMB_TICKETS = 4096;  // column blocks; zero before the first launch
+constexpr int SMB_T     = 20;       // tiles per wave and slice
+constexpr int SMB_WAVES = 4;        // waves (16-column groups) per workgroup: they share the x slice
+constexpr int SMB_SPINS = 1 << 22;  // bounded: a protocol bug must not hang the GPU
+typedef unsigned long long                          smb_u64;
+typedef __attribute__((address_space(1))) smb_u64   smb_gu64;
 
 template<bool INT8>
 __device__ __forceinline__ f16 smallm_epilogue(float v, const f16* __restrict__ bias, const int col, const int act)
@@ -465,63 +493,82 @@ __device__ __forceinline__ f16 smallm_epilogue(float v, const f16* __restrict__ 
 
 // One launch runs up to two independent GEMMs with the same m ("group": QKV with FFN1, out-proj with FFN2): a dependent
 // launch costs ~8 us of dispatch latency however little it computes, which is most of a layer at tensor-parallel shard
-// sizes.  blockIdx.x selects the problem, blockIdx.y the K slice (workgroups beyond a problem's slice count exit).
+// sizes.  1-D grid: problem 0's workgroups first; within a problem workgroup i = column block i / ks, slice i % ks.
 struct SmallmProblem {
     const f16*  A;
     const void* W;
     const f16*  scale;
     const f16*  bias;
     f16*        C;
-    float*      partial;  // [ks][m][n]
-    unsigned*   tickets;  // [bx]
+    smb_u64*    partial;  // granules [ks - 1][m][n]
     int         act, n, k, ks, bx;
 };
 struct SmallmGroup {
     SmallmProblem p[2];
     int           np, m;
+    const int*    d_step;  // device-resident decode step (a replayed hipGraph freezes every scalar argument), or NULL
+    unsigned      seq;     // launch counter of the owning workspace
+    int*          err;     // sticky: a reducer gave up waiting
 };
 // (pointers that come out of the argument struct are global: the explicit address space keeps the accesses from
 // becoming FLAT, which would also count on lgkmcnt and serialise with the LDS waits)
 #define SMB_G(T, ptr) ((const __attribute__((address_space(1))) T*)(ptr))
 
-template<bool INT8>
-__global__ __launch_bounds__(256) void k_gemm_smallm_burst(const SmallmGroup G)
+template<bool INT8, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemm_smallm_burst(const SmallmGroup G)
 {
-    int bxl = blockIdx.x, pi = 0;
-    if (G.np > 1 && bxl >= G.p[0].bx) {
+    constexpr int TK   = INT8 ? TILE_K_I8 : TILE_K_F16;
+    constexpr int KMAX = SMB_T * TK;  // k per slice
+    constexpr int LDA  = KMAX + 8;    // halves per LDS row: rows start in different banks
+    constexpr int NTHR = 64 * WAVES;
+    constexpr int BC   = 16 * WAVES;              // columns per workgroup
+    constexpr int XP   = (16 * KMAX / 8 + NTHR - 1) / NTHR;  // 16-byte pieces of x per thread
+    __shared__ __attribute__((aligned(16))) f16 As[16 * LDA];
+    static_assert(sizeof(As) >= 16 * BC * sizeof(float), "the reducer parks its own partial sums in the x tile");
+    const unsigned tag = ((G.d_step ? (unsigned)*SMB_G(int, G.d_step) : 0u) << 12) + (G.seq & 0xfffu) + 1u;
+    int idx = blockIdx.x, pi = 0;
+    if (G.np > 1 && idx >= G.p[0].bx * G.p[0].ks) {
         pi = 1;
-        bxl -= G.p[0].bx;
+        idx -= G.p[0].bx * G.p[0].ks;
     }
     const SmallmProblem& P = G.p[pi];
-    if ((int)blockIdx.y >= P.ks) {
-        return;
-    }
+    const int      ks = P.ks;
+    // slice major: the workgroups in flight at any moment read 20 KiB pieces spread over the whole matrix (measured: a
+    // column block's slices as dispatch neighbours -- one contiguous region in flight -- is 12 % slower, an XCD-contiguous
+    // walk 4 %); the owner of the last slice is dispatched after all its siblings
+    const int bxl = idx % P.bx, sl = idx / P.bx;
     const int      m = G.m, n = P.n, k = P.k, act = P.act;
     const f16*     A = P.A;
     const f16*     bias = P.bias;
     f16*           C = P.C;
-    float*         partial = P.partial;
-    unsigned*      tickets = P.tickets;
-    constexpr int TK   = INT8 ? TILE_K_I8 : TILE_K_F16;
-    constexpr int KMAX = SMB_T * TK;  // k per slice
-    __shared__ int s_last;
-    constexpr int LDA  = KMAX + 8;    // halves per LDS row: rows start in different banks
-    constexpr int XP   = 16 * KMAX / 8 / 256;  // 16-byte pieces of x per thread: 10 (int8) / 5 (fp16)
-    __shared__ __attribute__((aligned(16))) f16 As[16 * LDA];
+    smb_u64*       partial = P.partial;
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int NT = n / 16, KT = k / TK, ks = P.ks;
-    const int nt = bxl * 4 + wid;
+    const int NT = n / 16, KT = k / TK;
+    const int nt = bxl * WAVES + wid;
     const bool active = nt < NT;
-    const int t0 = (int)((long)KT * blockIdx.y / ks), t1 = (int)((long)KT * (blockIdx.y + 1) / ks);
+    const int t0 = (int)((long)KT * sl / ks), t1 = (int)((long)KT * (sl + 1) / ks);
     const int nts = t1 - t0;  // <= SMB_T
 
+    // x first (L2 hits: they are back long before the weights and go to LDS while those are in flight), then the weights;
+    // the tiles are consumed in request order as they land
+    u32x4     xr[XP];
+    const int ppr = nts * TK / 8;  // pieces per row of this slice
+#pragma unroll
+    for (int i = 0; i < XP; i++) {
+        const int pc  = threadIdx.x + i * NTHR;
+        int       row = pc / (KMAX / 8), p8 = pc % (KMAX / 8);
+        row           = row < m ? row : m - 1;  // (also covers pc past the tile when XP rounds up)
+        p8            = p8 < ppr ? p8 : ppr - 1;
+        xr[i]         = *SMB_G(u32x4, reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)t0 * TK + p8 * 8));
+    }
     f16x2 scale2 = {(f16)1.f, (f16)1.f};
     if constexpr (INT8) {
         const f16 sc = *SMB_G(f16, P.scale + (active ? nt : 0) * 16 + c);
         scale2       = f16x2{sc, sc};
     }
+    __builtin_amdgcn_sched_barrier(0);
     const u32x4* wp = reinterpret_cast<const u32x4*>(P.W) + ((size_t)(active ? nt : 0) * KT + t0) * 64 + lane;
     u32x4        wr[SMB_T];
 #pragma unroll
@@ -529,20 +576,13 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const SmallmGroup G)
         const int t = u < nts ? u : nts - 1;  // clamped, never conditional
         wr[u]       = __builtin_nontemporal_load(SMB_G(u32x4, wp + (size_t)t * 64));
     }
-    u32x4     xr[XP];
-    const int ppr = nts * TK / 8;  // pieces per row of this slice
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < XP; i++) {
-        const int pc  = threadIdx.x + i * 256;
-        int       row = pc / (KMAX / 8), p8 = pc % (KMAX / 8);
-        row           = row < m ? row : m - 1;
-        p8            = p8 < ppr ? p8 : ppr - 1;
-        xr[i]         = *SMB_G(u32x4, reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)t0 * TK + p8 * 8));
-    }
-#pragma unroll
-    for (int i = 0; i < XP; i++) {
-        const int pc = threadIdx.x + i * 256;
-        *reinterpret_cast<u32x4*>(&As[(pc / (KMAX / 8)) * LDA + (pc % (KMAX / 8)) * 8]) = xr[i];
+        const int pc = threadIdx.x + i * NTHR;
+        if (pc < 16 * KMAX / 8) {
+            *reinterpret_cast<u32x4*>(&As[(pc / (KMAX / 8)) * LDA + (pc % (KMAX / 8)) * 8]) = xr[i];
+        }
     }
     __syncthreads();
     f32x4      acc = {0.f, 0.f, 0.f, 0.f};
@@ -554,82 +594,96 @@ __global__ __launch_bounds__(256) void k_gemm_smallm_burst(const SmallmGroup G)
         }
     }
     const int col = nt * 16 + c;
-    if (ks > 1) {
+    if (ks == 1) {
         if (active) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = g * 4 + j;
                 if (row < m) {
-                    __hip_atomic_store(&partial[((size_t)blockIdx.y * m + row) * n + col], acc[j], __ATOMIC_RELAXED,
+                    C[(size_t)row * n + col] = smallm_epilogue<INT8>(acc[j], bias, col, act);
+                }
+            }
+        }
+        return;
+    }
+    if (sl < ks - 1) {  // publish and leave: nothing waits for these stores
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = g * 4 + j;
+                if (row < m) {
+                    __hip_atomic_store((smb_gu64*)&partial[((size_t)sl * m + row) * n + col],
+                                       ((smb_u64)tag << 32) | (smb_u64)__float_as_uint(acc[j]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
-        // The slice workgroup of this column block that takes the last ticket adds the partials in slice order
-        // (deterministic) and applies the epilogue: no reduction launch (a dependent launch costs more than it computes
-        // here).  The partials are write-through (agent scope) stores read back with agent-scope loads, so ordering them
-        // before the ticket only needs the stores to have completed (vmcnt); an agent-scope release fence would write back
-        // the whole L2 (measured: 20 -> 140 us per launch).  The ticket resets itself for the next launch on the stream.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned t = __hip_atomic_fetch_add(&tickets[bxl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last           = (t == (unsigned)ks - 1u);
-            if (s_last) {
-                __hip_atomic_store(&tickets[bxl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        if (!s_last) {
-            return;
-        }
-        // 64 columns x m rows: 4 outputs per thread, RS slices of each requested together (an agent-scope load is a memory
-        // round trip)
-        constexpr int RS = 4;
-        const int     cc = bxl * 64 + (threadIdx.x & 63);
-        float         v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cc < n) {
-            for (int s0 = 0; s0 < ks; s0 += RS) {
-                float pv[4][RS];
-#pragma unroll
-                for (int j = 0; j < RS; j++) {
-                    const int s2 = s0 + j < ks ? s0 + j : ks - 1;
-#pragma unroll
-                    for (int o = 0; o < 4; o++) {
-                        int row  = (threadIdx.x >> 6) + o * 4;
-                        row      = row < m ? row : m - 1;
-                        pv[o][j] = __hip_atomic_load(&partial[((size_t)s2 * m + row) * n + cc], __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < RS; j++) {
-                    if (s0 + j < ks) {
-#pragma unroll
-                        for (int o = 0; o < 4; o++) {
-                            v[o] += pv[o][j];
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const int row = (threadIdx.x >> 6) + o * 4;
-                if (row < m) {
-                    C[(size_t)row * n + cc] = smallm_epilogue<INT8>(v[o], bias, cc, act);
-                }
-            }
-        }
         return;
     }
-    if (!active) {
-        return;
-    }
+    // owner of the last slice: its own sums through LDS (the x tile is dead), the siblings' from their granules
+    __syncthreads();
+    float* own = reinterpret_cast<float*>(As);  // [16 rows][BC columns]
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int row = g * 4 + j;
+        own[(g * 4 + j) * BC + wid * 16 + c] = acc[j];
+    }
+    __syncthreads();
+    // BC columns x m rows: 4 outputs per thread, RS slices of each requested together (an agent-scope load is a memory
+    // round trip)
+    constexpr int RS = 5;
+    const int     cl = threadIdx.x % BC, r0 = threadIdx.x / BC;  // rows r0, r0 + 4, r0 + 8, r0 + 12
+    const int     cc = bxl * BC + cl;
+    if (cc >= n) {
+        return;
+    }
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int   spins = 0;
+    for (int s0 = 0; s0 < ks - 1; s0 += RS) {
+        smb_u64 pv[4][RS];
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+                const int s2 = s0 + j < ks - 1 ? s0 + j : ks - 2;
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    int row  = r0 + o * 4;
+                    row      = row < m ? row : m - 1;
+                    pv[o][j] = __hip_atomic_load((const smb_gu64*)&partial[((size_t)s2 * m + row) * n + cc], __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RS; j++) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    ok &= (unsigned)(pv[o][j] >> 32) == tag;
+                }
+            }
+            if (ok) {
+                break;
+            }
+            if (++spins > SMB_SPINS) {
+                *G.err = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int j = 0; j < RS; j++) {
+            if (s0 + j < ks - 1) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    v[o] += __uint_as_float((unsigned)pv[o][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int row = r0 + o * 4;
         if (row < m) {
-            C[(size_t)row * n + col] = smallm_epilogue<INT8>(acc[j], bias, col, act);
+            C[(size_t)row * n + cc] = smallm_epilogue<INT8>(v[o] + own[row * BC + cl], bias, cc, act);
         }
     }
 }
@@ -643,24 +697,27 @@ static int smallm_burst_slices(int k, bool int8)
 // split-K partials [slices][m][n] of ONE GEMM; take the maximum over the GEMMs that share the workspace
 size_t gemm_smallm_workspace_bytes(int m, int n, int k, bool int8)
 {
-    return (size_t)std::max(8, smallm_burst_slices(k, int8)) * m * n * sizeof(float);
+    return (size_t)std::max(8, smallm_burst_slices(k, int8)) * m * n * sizeof(smb_u64);  // {tag, value} granules
 }
 size_t gemm_smallm_ticket_bytes()
 {
-    return SMB_TICKETS * sizeof(unsigned);
+    return 256;  // [0] sticky error flag of the in-launch reduction, [1] launch counter (host side mirror: SmallmState)
 }
 
 // burst form of one or two GEMMs in one launch; `workspace` = [partial_bytes of partial sums][ticket table]
 void launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
-                              hipStream_t s)
+                              hipStream_t s, const int* d_step, unsigned* seq)
 {
-    FTCF_CHECK_ARG(np >= 1 && np <= 2 && m >= 1 && m <= 16 && workspace != nullptr, "small-m GEMM group: bad arguments");
+    FTCF_CHECK_ARG(np >= 1 && np <= 2 && m >= 1 && m <= 16 && workspace != nullptr && seq != nullptr,
+                   "small-m GEMM group: bad arguments");
     SmallmGroup G{};
-    G.np = np;
-    G.m  = m;
-    size_t    poff = 0;
-    int       toff = 0, ks_max = 1, bx_sum = 0;
-    unsigned* tickets = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + partial_bytes);
+    G.np     = np;
+    G.m      = m;
+    G.d_step = d_step;
+    G.seq    = (*seq)++;
+    G.err    = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + partial_bytes);
+    size_t poff = 0;
+    long   wgs  = 0;
     for (int i = 0; i < np; i++) {
         FTCF_CHECK_ARG(d[i].k % GEMM_KSTEP == 0 && d[i].n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
         SmallmProblem& P = G.p[i];
@@ -673,27 +730,25 @@ void launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, siz
         P.n = d[i].n;
         P.k = d[i].k;
         P.ks = smallm_burst_slices(d[i].k, int8);
-        P.bx = (d[i].n / 16 + 3) / 4;
-        P.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + poff);
-        P.tickets = tickets + toff;
+        P.bx = (d[i].n / 16 + SMB_WAVES - 1) / SMB_WAVES;
+        P.partial = reinterpret_cast<smb_u64*>(reinterpret_cast<char*>(workspace) + poff);
         poff += gemm_smallm_workspace_bytes(m, d[i].n, d[i].k, int8);
-        toff += P.bx;
-        bx_sum += P.bx;
-        ks_max = std::max(ks_max, P.ks);
+        wgs += (long)P.bx * P.ks;
     }
-    FTCF_CHECK_ARG(poff <= partial_bytes && toff <= SMB_TICKETS, "small-m GEMM: split-K workspace too small");
-    dim3 grid(bx_sum, ks_max);
+    FTCF_CHECK_ARG(poff <= partial_bytes, "small-m GEMM: split-K workspace too small");
+    dim3 grid((unsigned)wgs);
     if (int8) {
-        hipLaunchKernelGGL((k_gemm_smallm_burst<true>), grid, dim3(256), 0, s, G);
+        hipLaunchKernelGGL((k_gemm_smallm_burst<true, SMB_WAVES>), grid, dim3(64 * SMB_WAVES), 0, s, G);
     }
     else {
-        hipLaunchKernelGGL((k_gemm_smallm_burst<false>), grid, dim3(256), 0, s, G);
+        hipLaunchKernelGGL((k_gemm_smallm_burst<false, SMB_WAVES>), grid, dim3(64 * SMB_WAVES), 0, s, G);
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
-                        size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s)
+                        size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s, const int* d_step,
+                        unsigned* seq)
 {
     FTCF_CHECK_ARG(m >= 1 && m <= 16, "small-m GEMM handles 1..16 rows");
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0 && n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
@@ -701,7 +756,7 @@ void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16
     (void)num_cu;
     if (workspace != nullptr) {
         const SmallmDesc d{A, W, scale, bias, act, C, n, k};
-        launch_gemm_smallm_group(&d, 1, workspace, partial_bytes, m, int8, s);
+        launch_gemm_smallm_group(&d, 1, workspace, partial_bytes, m, int8, s, d_step, seq);
         return;
     }
     // no workspace (kernel-level entry points): the chunked form over the whole K extent
@@ -717,58 +772,70 @@ void launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16
 
 // logits_f32[m, n] = A[m,k] x W[n,k]^T for m > 4 (batched decode LM head).  W rows are k-contiguous, which is the
 // B-operand order of the MFMA directly: lane (col = lane&15, kgroup = lane>>4) reads 16 B of row n0+col.
-// Each wave takes TWO groups of 16 vocabulary rows: an A fragment (from L2) feeds two weight fragments (from HBM).
-__global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ A, const f16* __restrict__ W,
+// Each wave takes NGR groups of 16 vocabulary rows: an A fragment (from L2) feeds NGR weight fragments (from HBM).
+template<int NGR, int WPB, int UK>
+__global__ __launch_bounds__(64 * WPB) void k_gemm_nk_f32out(const f16* __restrict__ A, const f16* __restrict__ W,
                                                         float* __restrict__ C, int m, int n, int k, int ldc)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = (blockIdx.x * 4 + wid) * 32;
+    const int n0 = (blockIdx.x * WPB + wid) * (16 * NGR);
     const int m0 = blockIdx.y * 16;
     if (n0 >= n) {
         return;
     }
-    const int  wrow0 = (n0 + c < n) ? n0 + c : n - 1;
-    const int  wrow1 = (n0 + 16 + c < n) ? n0 + 16 + c : n - 1;
-    const int  arow  = (m0 + c < m) ? m0 + c : m - 1;
-    f32x4      acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const f16* wp0 = W + (size_t)wrow0 * k + g * 8;
-    const f16* wp1 = W + (size_t)wrow1 * k + g * 8;
-    const f16* ap  = A + (size_t)arow * k + g * 8;
-    int k0 = 0;
-    for (; k0 + 256 <= k; k0 += 256) {  // 16 weight fragments (16 KiB per wave) in flight: the loop is HBM-latency bound
-        f16x8 b0[8], b1[8], a[8];
+    const int  arow = (m0 + c < m) ? m0 + c : m - 1;
+    const f16* ap   = A + (size_t)arow * k + g * 8;
+    const f16* wp[NGR];
+    f32x4      acc[NGR];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            b0[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp0 + k0 + u * 32));
-            b1[u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp1 + k0 + u * 32));
+    for (int j = 0; j < NGR; j++) {
+        const int r = n0 + j * 16 + c;
+        wp[j]       = W + (size_t)(r < n ? r : n - 1) * k + g * 8;
+        acc[j]      = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // 16 weight fragments (16 KiB per wave) in flight per trip: the loop is HBM-latency bound.  The x fragments come from
+    // the L2 through the same per-CU load path as the weights: one of them feeds NGR weight fragments (NGR = 2 made the
+    // path carry 1 byte of x per 2 of weights: 2.9 TB/s on the 100864 x 5120 head)
+    int           k0 = 0;
+    for (; k0 + UK * 32 <= k; k0 += UK * 32) {
+        f16x8 bw[NGR][UK], a[UK];
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+#pragma unroll
+            for (int j = 0; j < NGR; j++) {
+                bw[j][u] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(wp[j] + k0 + u * 32));
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < UK; u++) {
             a[u] = *reinterpret_cast<const f16x8*>(ap + k0 + u * 32);
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b0[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b1[u], acc1, 0, 0, 0);
+        for (int u = 0; u < UK; u++) {
+#pragma unroll
+            for (int j = 0; j < NGR; j++) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], bw[j][u], acc[j], 0, 0, 0);
+            }
         }
     }
     for (; k0 < k; k0 += 32) {
-        const f16x8 b0 = *reinterpret_cast<const f16x8*>(wp0 + k0);
-        const f16x8 b1 = *reinterpret_cast<const f16x8*>(wp1 + k0);
-        const f16x8 a  = *reinterpret_cast<const f16x8*>(ap + k0);
-        acc0           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b0, acc0, 0, 0, 0);
-        acc1           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, acc1, 0, 0, 0);
+        const f16x8 a = *reinterpret_cast<const f16x8*>(ap + k0);
+#pragma unroll
+        for (int j = 0; j < NGR; j++) {
+            const f16x8 bw = *reinterpret_cast<const f16x8*>(wp[j] + k0);
+            acc[j]         = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bw, acc[j], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int row = m0 + g * 4 + j;
+    for (int q = 0; q < 4; q++) {
+        const int row = m0 + g * 4 + q;
         if (row < m) {
-            if (n0 + c < n) {
-                C[(size_t)row * ldc + n0 + c] = acc0[j];
-            }
-            if (n0 + 16 + c < n) {
-                C[(size_t)row * ldc + n0 + 16 + c] = acc1[j];
+#pragma unroll
+            for (int j = 0; j < NGR; j++) {
+                if (n0 + j * 16 + c < n) {
+                    C[(size_t)row * ldc + n0 + j * 16 + c] = acc[j][q];
+                }
             }
         }
     }
@@ -777,8 +844,12 @@ __global__ __launch_bounds__(256) void k_gemm_nk_f32out(const f16* __restrict__ 
 void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s)
 {
     FTCF_CHECK_ARG(k % 32 == 0, "k must be a multiple of 32");
-    dim3 grid((n + 127) / 128, (m + 15) / 16);
-    hipLaunchKernelGGL(k_gemm_nk_f32out, grid, dim3(256), 0, s, A, W_nk, C, m, n, k, ldc);
+    // (NGR, waves per workgroup, 32-k steps per trip) = (8, 2, 2): 289 us on the 100864 x 5120 head at 16 rows (3.6 TB/s);
+    // (2, 4, 8) 353, (4, 4, 4) 328, (8, 2, 4) 320, (16, 2, 1) 307.  More fragments in flight do not help: the row-major
+    // [V, H] image (the caller's buffer, not re-tiled) is read in 64-byte pieces of 16 rows per wave-load.
+    constexpr int NGR = 8, WPB = 2;
+    dim3          grid((n + 16 * NGR * WPB - 1) / (16 * NGR * WPB), (m + 15) / 16);
+    hipLaunchKernelGGL((k_gemm_nk_f32out<NGR, WPB, 2>), grid, dim3(64 * WPB), 0, s, A, W_nk, C, m, n, k, ldc);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
