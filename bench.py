@@ -276,7 +276,8 @@ def main():
     KIND_NAMES = {0: "k_ln_gemv_group (LN1 -> QKV weight stream)", 1: "k_gemv_chunked (out-proj + FFN2 weight stream)",
                   2: "k_lm_head", 3: "k_mmha_ln_gemv (attention || LN2 -> FFN1 weight stream)",
                   4: "k_decode_persistent (all layers of one token: weights + KV cache)",
-                  5: "k_gemm_smallm_burst (batched decode: two weight matrices per launch, read once for all rows)"}
+                  5: "k_gemm_smallm_burst (batched decode: one weight matrix per launch, read once for all rows; the attention branch "
+                     "and the FFN branch of a layer run on two streams, so a launch shares the HBM with its neighbour)"}
     roof = None
     if a.profile_steps > 0:
         # the profiled steps sit at the same place of the request as the timed window (same KV lengths)

@@ -859,6 +859,11 @@ struct ftcf_gptneox {
     // `stream` is the engine's own work stream (capturable, unlike the legacy null stream torch usually hands over);
     // it is ordered after `user_stream` at begin() and drained before forward()/finish() return
     hipStream_t               stream = nullptr, user_stream = nullptr;
+    // second stream of the batched decode layer: [QKV -> MMHA -> out-proj] on `stream`, [FFN1 -> FFN2] here (fork / join by
+    // events; under capture the branch becomes a parallel branch of the token's hipGraph)
+    hipStream_t               side = nullptr;
+    hipEvent_t                ev_fork = nullptr, ev_join = nullptr;
+    int                       decode_branches = 1;  // FTCF_DECODE_BRANCHES=0: one stream, GEMMs paired per launch
     hipEvent_t                ev_user = nullptr;
     hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
     bool                      tp_graph = false;
@@ -926,6 +931,11 @@ struct ftcf_gptneox {
         }
         if (stream) {
             (void)hipStreamDestroy(stream);
+            if (side) {
+                (void)hipStreamDestroy(side);
+                (void)hipEventDestroy(ev_fork);
+                (void)hipEventDestroy(ev_join);
+            }
         }
         if (ev_user) {
             (void)hipEventDestroy(ev_user);
@@ -956,16 +966,16 @@ struct ftcf_gptneox {
     }
 
     template<typename F>
-    void timed(int kind, double bytes, F&& f)
+    void timed(int kind, double bytes, F&& f, hipStream_t on = nullptr)
     {
         if (!profiling) {
             f();
             return;
         }
         hipEvent_t a = get_event(), b = get_event();
-        FTCF_HIP_CHECK(hipEventRecord(a, stream));
+        FTCF_HIP_CHECK(hipEventRecord(a, on ? on : stream));
         f();
-        FTCF_HIP_CHECK(hipEventRecord(b, stream));
+        FTCF_HIP_CHECK(hipEventRecord(b, on ? on : stream));
         pending.emplace_back(a, b, kind, bytes);
     }
     void drain_events()
@@ -1038,9 +1048,9 @@ struct ftcf_gptneox {
                 d_players   = c.take<PersistLayer>(L);
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
-            smallm_partial = std::max(
-                gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8),
-                gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8));
+            // (the four GEMMs of a layer may be in flight together: one region each)
+            smallm_partial = gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8)
+                             + gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8);
             smallm_ws = (B > STAGE_MAX_ROWS && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
@@ -1300,7 +1310,30 @@ struct ftcf_gptneox {
                     launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
                                             nrm2, B, H, 1e-5f, stream);
                 }
-                if (B <= 16 && smallm_ws) {
+                if (B <= 16 && smallm_ws && decode_branches && side) {
+                    // The attention branch [QKV -> MMHA -> out-proj] (78.6 + K/V + 26.2 MB at 13B int8) and the FFN branch
+                    // [FFN1 -> FFN2] (2 x 104.9 MB) of a parallel-residual layer are independent: two streams.  Every one
+                    // of these launches is a short burst -- the whole matrix requested at once, gone in ~30 us -- whose
+                    // ramp-up and drain leave the HBM idle; the other branch's launch fills those gaps.
+                    const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(B, 3 * hl, H, int8),
+                                 o_out = o_f1 + gemm_smallm_workspace_bytes(B, il, H, int8),
+                                 o_f2  = o_out + gemm_smallm_workspace_bytes(B, H, hl, int8);
+                    auto one = [&](const SmallmDesc& d, size_t off, hipStream_t s) {
+                        timed(KIND_SMALLM, wbytes * (double)d.n * d.k, [&] {
+                            launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, B, int8, s, &state->step, &smallm_seq, off);
+                        }, s);
+                    };
+                    FTCF_HIP_CHECK(hipEventRecord(ev_fork, stream));
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+                    one(SmallmDesc{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H}, o_qkv, stream);
+                    one(SmallmDesc{nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}, o_f1, side);
+                    launch_mmha(mp, stream);
+                    one(SmallmDesc{mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}, o_f2, side);
+                    one(SmallmDesc{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl}, o_out, stream);
+                    FTCF_HIP_CHECK(hipEventRecord(ev_join, side));
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
+                }
+                else if (B <= 16 && smallm_ws) {
                     // independent GEMMs share a launch (a dependent launch costs ~8 us of dispatch latency, most of a layer
                     // at tensor-parallel shard sizes): [QKV, FFN1] -> MMHA -> [out-proj, FFN2]
                     const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
@@ -2045,6 +2078,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->int8  = cfg->int8_mode == 1;
         e->user_stream = (hipStream_t)cfg->stream;
         FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         FTCF_HIP_CHECK(hipEventCreateWithFlags(&e->ev_user, hipEventDisableTiming));
         // weights still being uploaded / produced on the caller's stream happen-before the re-tiling below
         FTCF_HIP_CHECK(hipEventRecord(e->ev_user, e->user_stream));
@@ -2146,6 +2182,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_PERSIST_CS3")) {
             e->persist_cs3 = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_DECODE_BRANCHES")) {
+            e->decode_branches = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_TP_GRAPH")) {

@@ -88,7 +88,7 @@ struct SmallmDesc {  // C[m, n] = epilogue(A[m, k] x W[k, n]); act 1 = bias + ge
 // d_step: device-resident decode step (part of the launch's granule tag, a replayed hipGraph freezes scalars) or NULL;
 // seq: the workspace's launch counter (host).  The granules must be zero when a request begins.
 void   launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
-                                hipStream_t s, const int* d_step, unsigned* seq);
+                                hipStream_t s, const int* d_step, unsigned* seq, size_t partial_offset = 0);
 void   launch_gemm_smallm(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, float* workspace,
                           size_t partial_bytes, int m, int n, int k, bool int8, int num_cu, hipStream_t s,
                           const int* d_step = nullptr, unsigned* seq = nullptr);

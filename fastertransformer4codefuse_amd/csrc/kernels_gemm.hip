@@ -706,7 +706,7 @@ size_t gemm_smallm_ticket_bytes()
 
 // burst form of one or two GEMMs in one launch; `workspace` = [partial_bytes of partial sums][ticket table]
 void launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, size_t partial_bytes, int m, bool int8,
-                              hipStream_t s, const int* d_step, unsigned* seq)
+                              hipStream_t s, const int* d_step, unsigned* seq, size_t partial_offset)
 {
     FTCF_CHECK_ARG(np >= 1 && np <= 2 && m >= 1 && m <= 16 && workspace != nullptr && seq != nullptr,
                    "small-m GEMM group: bad arguments");
@@ -716,7 +716,7 @@ void launch_gemm_smallm_group(const SmallmDesc* d, int np, float* workspace, siz
     G.d_step = d_step;
     G.seq    = (*seq)++;
     G.err    = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + partial_bytes);
-    size_t poff = 0;
+    size_t poff = partial_offset;  // launches that may run concurrently use disjoint parts of the workspace
     long   wgs  = 0;
     for (int i = 0; i < np; i++) {
         FTCF_CHECK_ARG(d[i].k % GEMM_KSTEP == 0 && d[i].n % 16 == 0, "GEMM needs k % 64 == 0 and n % 16 == 0");
