@@ -347,6 +347,14 @@ def main():
         # whole-step HBM roofline (8 TB/s), incl. KV + fp16 LM head: bytes of one step x steps per second
         "path_roofline_frac": bpt * (tok_s / B) / 8e12,
         "roofline": roof,
+        # which decode path the timed steps took on rank 0 and how the per-layer all-reduce travelled (the driver's SCALE run
+        # reads this to confirm that N ranks were up and whether the in-kernel xGMI exchange or the RCCL fallback ran)
+        "tensor_parallel": {"ranks": world if a.fake_tp <= 1 else a.fake_tp, "backend": "rccl" if world > 1 else "none",
+                            "decode_path": {0: "per-stage launches", 1: "persistent kernel", 2: "general path"}.get(
+                                st["decode_path"], str(st["decode_path"])),
+                            "layer_allreduce": ("none" if tp == 1 else
+                                                "in-kernel exchange windows (peer-mapped, xGMI stores)"
+                                                if st["decode_path"] == 1 else "ncclAllReduce per layer")},
     }
     if a.fake_tp > 1:
         res["invalid"] = f"--fake-tp {a.fake_tp}: one rank of a TP={a.fake_tp} job without its peers (timing aid only)"
