@@ -230,29 +230,52 @@ def main():
             capi.check(L.ftcf_gptneox_step(op._h, n, C.byref(done)))
             assert done.value == n, f"only {done.value} of {n} steps ran"
 
+    # A tensor-parallel decode that cannot complete its in-kernel exchange on this box (every spin is bounded) makes
+    # finish() raise on EVERY rank and pins the engines to the RCCL path: the request is then simply run again.
+    fallback_note = None
+
+    def with_fallback(fn):
+        nonlocal fallback_note
+        try:
+            return fn()
+        except capi.FtcfError as e:
+            if "gave up" not in str(e):
+                raise
+            fallback_note = str(e)
+            return fn()
+
     # ---- untimed: one short request to warm every kernel / allocation ----
     fa = make_args(out_len)
-    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))
-    capi.check(L.ftcf_gptneox_step(op._h, 2, None))
-    capi.check(L.ftcf_gptneox_finish(op._h))
+
+    def warm_request():
+        capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))
+        capi.check(L.ftcf_gptneox_step(op._h, 2, None))
+        capi.check(L.ftcf_gptneox_finish(op._h))
+
+    with_fallback(warm_request)
+
     # ---- the measured request ----
-    torch.cuda.synchronize()
-    barrier()
-    tp0 = time.perf_counter()
-    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))  # 1024-token prefill through the real context path
-    torch.cuda.synchronize()
-    prefill_wall_ms = (time.perf_counter() - tp0) * 1e3
-    run_steps(pre)
-    run_steps(warmup)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(steps)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    run_steps(post)
-    capi.check(L.ftcf_gptneox_finish(op._h))
+    def measured_request():
+        torch.cuda.synchronize()
+        barrier()
+        tp0 = time.perf_counter()
+        capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))  # 1024-token prefill through the real context path
+        torch.cuda.synchronize()
+        pw = (time.perf_counter() - tp0) * 1e3
+        run_steps(pre)
+        run_steps(warmup)
+        torch.cuda.synchronize()
+        barrier()
+        ta = time.perf_counter()
+        run_steps(steps)
+        torch.cuda.synchronize()
+        barrier()
+        tb = time.perf_counter()
+        run_steps(post)
+        capi.check(L.ftcf_gptneox_finish(op._h))
+        return pw, ta, tb
+
+    prefill_wall_ms, t0, t1 = with_fallback(measured_request)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -354,7 +377,8 @@ def main():
                                 st["decode_path"], str(st["decode_path"])),
                             "layer_allreduce": ("none" if tp == 1 else
                                                 "in-kernel exchange windows (peer-mapped, xGMI stores)"
-                                                if st["decode_path"] == 1 else "ncclAllReduce per layer")},
+                                                if st["decode_path"] == 1 else "ncclAllReduce per layer"),
+                            "fallback": fallback_note},
     }
     if a.fake_tp > 1:
         res["invalid"] = f"--fake-tp {a.fake_tp}: one rank of a TP={a.fake_tp} job without its peers (timing aid only)"

@@ -2043,6 +2043,7 @@ void ftcf_gptneox::finish()
     }
     if (ps_error != 0) {
         persist_failed = true;
+        persist        = 0;  // whoever drives begin / step / finish: the next request is planned off the persistent path
         throw Error(-2, "persistent decode kernel gave up waiting for a hand-off (code " + std::to_string(ps_error)
                             + "): not every workgroup was resident");
     }
