@@ -181,6 +181,7 @@ struct PersistPlan {
     int    xs_halves; // LDS x region
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
+    int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
     size_t smem;
 };
 struct PersistParams {

@@ -140,6 +140,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (pl.smem > 160 * 1024) {
         return pl;
     }
+    static const int qrot = getenv("FTCF_PERSIST_QROT") ? atoi(getenv("FTCF_PERSIST_QROT")) : 0;
+    pl.qrot = ((qrot % NB) + NB) % NB;
     pl.ok = 1;
     return pl;
 }

@@ -851,7 +851,12 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     // P1: every workgroup owns a range of QKV column groups AND a range of FFN1 column groups (QKV runs first in its run
     // table: they are streamed first, so qkv is complete -- and published -- well before the stage ends)
     const int NF  = Il / 16;
-    const int q0  = (int)((long)NT0 * bid / NB), q1 = (int)((long)NT0 * (bid + 1) / NB);
+    // (NT0 / NB is not whole at 13B: 3.75 -> three of four workgroups stream 4 QKV groups, one streams 3, i.e. 720 vs 640
+    // tiles.  plan.qrot (FTCF_PERSIST_QROT, default 0) rotates WHICH workgroups get the light share: workgroup b runs on XCD
+    // b % 8 and the stamps show XCDs 2 / 6 ending P1 1.3 us after the others on equal shares; moving the light share onto
+    // them measured +-0.3 %: whoever is last, the next hand-off waits for it)
+    const int qb  = (bid + p.plan.qrot) % NB;
+    const int q0  = (int)((long)NT0 * qb / NB), q1 = (int)((long)NT0 * (qb + 1) / NB);
     const int f0  = (int)((long)NF * bid / NB), f1 = (int)((long)NF * (bid + 1) / NB);
     const int nq  = q1 - q0;
     const int rB0 = (int)((long)NG * PB * bid / NB), rB1 = (int)((long)NG * PB * (bid + 1) / NB);
