@@ -856,6 +856,7 @@ struct ftcf_gptneox {
     ftcf_gptneox_config       cfg{};
     int                       H = 0, nhl = 0, hl = 0, il = 0, L = 0, V = 0, vl = 0, dh = 0;
     bool                      int8 = false;
+    bool                      fp32 = false;  // FTGptNeoX<float> (GptNeoXOp.cc:56-70): fp32 weights, activations and K/V; general path only
     // `stream` is the engine's own work stream (capturable, unlike the legacy null stream torch usually hands over);
     // it is ordered after `user_stream` at begin() and drained before forward()/finish() return
     hipStream_t               stream = nullptr, user_stream = nullptr;
@@ -1001,17 +1002,18 @@ struct ftcf_gptneox {
         nsplit          = mmha_pick_nsplit(B, nhl, s_max);
         for (int pass = 0; pass < 2; pass++) {
             Carver c(pass == 0 ? nullptr : arena.ptr);
-            const size_t cache = (size_t)L * B * nhl * s_max * dh;
+            const size_t es    = fp32 ? 2 : 1;  // fp32 engine: the same views hold floats
+            const size_t cache = (size_t)L * B * nhl * s_max * dh * es;
             k_cache            = c.take<f16>(cache);
             v_cache            = c.take<f16>(cache);
-            x                  = c.take<f16>((size_t)B * H);
-            nrm                = c.take<f16>((size_t)B * H);
-            nrm2               = c.take<f16>((size_t)B * H);
-            qkv                = c.take<f16>((size_t)B * 3 * hl);
-            ctx                = c.take<f16>((size_t)B * hl);
-            att                = c.take<f16>((size_t)B * H);
-            mid                = c.take<f16>((size_t)B * il);
-            ffn                = c.take<f16>((size_t)B * H);
+            x                  = c.take<f16>((size_t)B * H * es);
+            nrm                = c.take<f16>((size_t)B * H * es);
+            nrm2               = c.take<f16>((size_t)B * H * es);
+            qkv                = c.take<f16>((size_t)B * 3 * hl * es);
+            ctx                = c.take<f16>((size_t)B * hl * es);
+            att                = c.take<f16>((size_t)B * H * es);
+            mid                = c.take<f16>((size_t)B * il * es);
+            ffn                = c.take<f16>((size_t)B * H * es);
             logits             = c.take<float>((size_t)B * V);
             gather             = c.take<float>((size_t)B * V);
             mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
@@ -1024,7 +1026,7 @@ struct ftcf_gptneox {
             // hand-shake failed, FTCF_TP_PERSIST=0) the per-stage launches + RCCL all-reduce stay in charge.
             const int  tpn      = cfg.tensor_para_size;
             const bool tp_local = tpn > 1 && cfg.comm && cfg.comm->local;
-            if (persist && K == 1 && B <= 2 && cfg.use_gptj_residual && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
+            if (persist && !fp32 && K == 1 && B <= 2 && cfg.use_gptj_residual && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3);
@@ -1051,7 +1053,7 @@ struct ftcf_gptneox {
             // (the four GEMMs of a layer may be in flight together: one region each)
             smallm_partial = gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8)
                              + gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8);
-            smallm_ws = (B > STAGE_MAX_ROWS && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
+            smallm_ws = (!fp32 && B > STAGE_MAX_ROWS && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -1078,14 +1080,14 @@ struct ftcf_gptneox {
             }
             if (S > 1) {
                 const size_t M = (size_t)(B / K) * S;  // beam search prefills one row per request
-                px             = c.take<f16>(M * H);
-                pnrm           = c.take<f16>(M * H);
-                pnrm2          = c.take<f16>(M * H);
-                pqkv           = c.take<f16>(M * 3 * hl);
-                pctx           = c.take<f16>(M * hl);
-                patt           = c.take<f16>(M * H);
-                pmid           = c.take<f16>(M * il);
-                pffn           = c.take<f16>(M * H);
+                px             = c.take<f16>(M * H * (fp32 ? 2 : 1));
+                pnrm           = c.take<f16>(M * H * (fp32 ? 2 : 1));
+                pnrm2          = c.take<f16>(M * H * (fp32 ? 2 : 1));
+                pqkv           = c.take<f16>(M * 3 * hl * (fp32 ? 2 : 1));
+                pctx           = c.take<f16>(M * hl * (fp32 ? 2 : 1));
+                patt           = c.take<f16>(M * H * (fp32 ? 2 : 1));
+                pmid           = c.take<f16>(M * il * (fp32 ? 2 : 1));
+                pffn           = c.take<f16>(M * H * (fp32 ? 2 : 1));
             }
             if (pass == 0) {
                 arena.reserve(c.off + 4096);
@@ -1112,6 +1114,104 @@ struct ftcf_gptneox {
                 return;
             }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, stream));
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------
+    // fp32 instantiation (kernels_fp32.hip): the arena views (x, nrm, qkv, ..., the caches, the prefill buffers) hold floats
+    // ---------------------------------------------------------------------------------------------------------------
+    static float*       F(f16* p) { return reinterpret_cast<float*>(p); }
+    static const float* F(const f16* p) { return reinterpret_cast<const float*>(p); }
+    static const float* F(const void* p) { return reinterpret_cast<const float*>(p); }
+    void allreduce32(float* buf, size_t count)
+    {
+        if (cfg.tensor_para_size > 1) {
+            Range r("ftcf.allreduce");
+            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local), "tensor_para_size > 1 needs a communicator");
+            if (cfg.comm->local) {
+                local_allreduce(cfg.comm, buf, count, false, stream);
+                return;
+            }
+            FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, cfg.comm->comm, stream));
+        }
+    }
+    // one layer's GEMMs / residual on M rows, shared by the context phase and the decode step
+    // (GptNeoXContextDecoder.cc:283-507, GptNeoXDecoder.cc:245-384 with T = float)
+    template<typename Attn>
+    void layer32(const LayerWeights& w, float* X, float* N1, float* Q, float* C, float* A, float* MID, float* FF, int M,
+                 bool first_or_last_inplace_variant, Attn&& attention)
+    {
+        launch_layernorm(X, w.ln1_g, w.ln1_b, N1, M, H, 1e-5f, false, stream);
+        launch32_gemm(N1, F(w.qkv.kernel), nullptr, 0, Q, M, 3 * hl, H, stream);
+        attention();
+        launch32_gemm(C, F(w.attn_out.kernel), nullptr, 0, A, M, H, hl, stream);
+        if (!cfg.use_gptj_residual) {
+            // sequential residual (GptNeoXDecoder.cc:313-331,362-367): h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h
+            allreduce32(A, (size_t)M * H);
+            launch32_add_bias_residual(A, X, A, F(w.attn_out.bias), M, H, stream);
+            launch_layernorm(A, w.ln2_g, w.ln2_b, N1, M, H, 1e-5f, false, stream);
+            launch32_gemm(N1, F(w.ffn1.kernel), F(w.ffn1.bias), 1, MID, M, il, H, stream);
+            launch32_gemm(MID, F(w.ffn2.kernel), nullptr, 0, FF, M, H, il, stream);
+            allreduce32(FF, (size_t)M * H);
+            launch32_add_bias_residual(X, FF, A, F(w.ffn2.bias), M, H, stream);
+            return;
+        }
+        launch_layernorm(X, w.ln2_g, w.ln2_b, N1, M, H, 1e-5f, false, stream);
+        launch32_gemm(N1, F(w.ffn1.kernel), F(w.ffn1.bias), 1, MID, M, il, H, stream);
+        launch32_gemm(MID, F(w.ffn2.kernel), nullptr, 0, FF, M, H, il, stream);
+        launch_add_bias_attn_ffn_residual(X, FF, A, X, w.ffn2.bias, M, H, cfg.tensor_para_size,
+                                          first_or_last_inplace_variant ? 0 : 1, false, stream);
+        allreduce32(X, (size_t)M * H);
+    }
+    void context_decoder32(int B, int S, const int* input_lengths, int s_max, int tile)
+    {
+        Range        r("ftcf.GptNeoXContextDecoder");
+        const int    M       = B * S;
+        const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            // (the context decoder's layer_input == layer_output for every layer with padding removal: the fp32-sum variant)
+            layer32(w, F(px), F(pnrm), F(pqkv), F(pctx), F(patt), F(pmid), F(pffn), M, false, [&] {
+                launch32_context_attention(F(pqkv), F(w.qkv.bias), input_lengths, F(k_cache) + l * cache_l,
+                                           F(v_cache) + l * cache_l, B, S, nhl, dh, cfg.rotary_embedding_dim, s_max, F(pctx),
+                                           stream, tile);
+            });
+        }
+    }
+    void decoder32(int B, int s_max)
+    {
+        Range        r("ftcf.GptNeoXDecoder");
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        stats.decode_path    = 2;
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
+            const bool outer = !(l > 0 && l < L - 1);
+            layer32(w, F(x), F(nrm), F(qkv), F(ctx), F(att), F(mid), F(ffn), B, outer, [&] {
+                Mmha32Params mp{};
+                mp.qkv = F(qkv);
+                mp.qkv_bias = F(w.qkv.bias);
+                mp.k_cache = F(k_cache) + l * cache_l;
+                mp.v_cache = F(v_cache) + l * cache_l;
+                mp.seq_len = seq_len;
+                mp.pad_count = pad_count;
+                mp.masked_tokens = masked;
+                mp.finished = finished;
+                mp.d_step = &state->step;
+                mp.B = B;
+                mp.nh = nhl;
+                mp.dh = dh;
+                mp.rot = cfg.rotary_embedding_dim;
+                mp.s_max = s_max;
+                mp.ctx = F(ctx);
+                if (ses.K > 1) {
+                    mp.cache_indir   = cache_indir;
+                    mp.beam_width    = ses.K;
+                    mp.max_input_len = ses.S;
+                    mp.indir_plane   = (size_t)B * s_max;
+                }
+                launch32_mmha(mp, stream);
+            });
         }
     }
 
@@ -1735,7 +1835,18 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         in_len = tiled_len;
     }
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, in_len, state, B, S, s_max, stream, K);
-    if (S > 1 && K > 1) {
+    if (S > 1 && K > 1 && fp32) {
+        launch32_prompt_embedding(F(px), nullptr, F(wte), a.input_ids, batch, S, H, stream);
+        launch_tile_prompt_ids(step_ids, a.input_ids, batch, K, S, stream);
+        context_decoder32(batch, S, a.input_lengths, s_max, K);
+        launch32_gather_last_token(F(x), F(px), a.input_lengths, batch, S, H, stream, K);
+    }
+    else if (S > 1 && fp32) {
+        launch32_prompt_embedding(F(px), step_ids, F(wte), in_ids, B, S, H, stream);
+        context_decoder32(B, S, in_len, s_max, 1);
+        launch32_gather_last_token(F(x), F(px), in_len, B, S, H, stream);
+    }
+    else if (S > 1 && K > 1) {
         launch_prompt_embedding(px, nullptr, wte, a.input_ids, batch, S, H, stream);
         launch_tile_prompt_ids(step_ids, a.input_ids, batch, K, S, stream);
         context_decoder(batch, S, a.input_lengths, s_max, K);
@@ -1837,18 +1948,26 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
     const ftcf_forward_args& a = ses.a;
     const int B = ses.B, S = ses.S, s_max = ses.s_max;
     const int tp = cfg.tensor_para_size;
-    if (with_decoder) {
+    if (with_decoder && fp32) {
+        launch32_step_prologue(F(x), F(wte), step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
+                               stream);
+        decoder32(B, s_max);
+    }
+    else if (with_decoder) {
             launch_step_prologue(x, wte, step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
                                  stream);
             decoder(B, s_max);
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
-        const bool fuse_ln = B <= 4;
+        const bool fuse_ln = B <= 4 && !fp32;
         if (!fuse_ln) {
-            launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, true, stream);
+            launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, !fp32, stream);
         }
         auto lm = [&](const f16* Wrows, float* out, int rows, int ld) {
-            if (fuse_ln) {
+            if (fp32) {  // Wrows counts f16 elements: the caller's row offset is scaled here
+                launch32_lm_head(F(nrm), F(lm_head) + (Wrows - lm_head), out, B, rows, H, ld, stream);
+            }
+            else if (fuse_ln) {
                 launch_lm_head(x, Wrows, out, B, rows, H, ld, stream, final_g, final_b, 1e-5f);
             }
             else {
@@ -2055,10 +2174,13 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         FTCF_CHECK_ARG(cfg && w && out, "NULL argument");
         require_device();
         FTCF_CHECK_ARG(cfg->pipeline_para_size == 1, "pipeline_para_size must be 1 (the CodeFuse harness forces it)");
-        if (cfg->dtype != FTCF_FP16) {
-            throw Error(FTCF_ERR_UNSUPPORTED, "the GPU engine runs fp16 weights/activations only");
+        if (cfg->dtype != FTCF_FP16 && cfg->dtype != FTCF_FP32) {
+            throw Error(FTCF_ERR_UNSUPPORTED, "the GPU engine instantiates fp16 and fp32 (as GptNeoXOp.cc:56-105)");
         }
         FTCF_CHECK_ARG(cfg->int8_mode == 0 || cfg->int8_mode == 1, "int8_mode must be 0 or 1");
+        if (cfg->dtype == FTCF_FP32 && cfg->int8_mode != 0) {
+            throw Error(FTCF_ERR_UNSUPPORTED, "weight-only int8 needs half activations (CutlassFpAIntBGemmRunner<half, uint8_t>)");
+        }
         const int tp = cfg->tensor_para_size;
         FTCF_CHECK_ARG(tp >= 1 && cfg->head_num % tp == 0 && cfg->inter_size % tp == 0 && cfg->vocab_size % tp == 0,
                        "head_num, inter_size and vocab_size must be divisible by tensor_para_size");
@@ -2077,6 +2199,7 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->V     = cfg->vocab_size;
         e->vl    = e->V / tp;
         e->int8  = cfg->int8_mode == 1;
+        e->fp32  = cfg->dtype == FTCF_FP32;
         e->user_stream = (hipStream_t)cfg->stream;
         FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         FTCF_HIP_CHECK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -2086,9 +2209,14 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         // weights still being uploaded / produced on the caller's stream happen-before the re-tiling below
         FTCF_HIP_CHECK(hipEventRecord(e->ev_user, e->user_stream));
         FTCF_HIP_CHECK(hipStreamWaitEvent(e->stream, e->ev_user, 0));
-        FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
-        FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
-                       "hidden, local hidden and local inter sizes must be multiples of 64");
+        if (e->fp32) {
+            FTCF_CHECK_ARG(e->dh >= 32 && e->dh <= 256 && e->dh % 2 == 0, "size_per_head must be even, 32..256");
+        }
+        else {
+            FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
+            FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
+                           "hidden, local hidden and local inter sizes must be multiples of 64");
+        }
         if (e->int8) {
             FTCF_CHECK_ARG(w->n_int8_weights == 4 * L && w->n_scales == 4 * L, "int8 lists must hold 4*L tensors");
         }
@@ -2122,6 +2250,14 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
                                    && lw.attn_out.scale && lw.ffn1.scale && lw.ffn2.scale,
                                "missing int8 kernel / scale tensor");
             }
+            else if (e->fp32) {
+                // row-major [K, N] fp32 kernels are read in place
+                lw.qkv.kernel = W(2, l);
+                lw.attn_out.kernel = W(4, l);
+                lw.ffn1.kernel = W(6, l);
+                lw.ffn2.kernel = W(8, l);
+                FTCF_CHECK_ARG(lw.qkv.kernel && lw.attn_out.kernel && lw.ffn1.kernel && lw.ffn2.kernel, "missing fp32 kernel tensor");
+            }
             else {
                 // re-tile the reference-layout [K, N] fp16 kernels once (the binding keeps the originals alive)
                 struct {
@@ -2148,7 +2284,7 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->final_b = (const f16*)w->weights[12 * L + 2];
         e->lm_head = (const f16*)w->weights[12 * L + 3];
         FTCF_CHECK_ARG(e->wte && e->final_g && e->final_b && e->lm_head, "missing embedding / final layernorm / lm_head");
-        e->k3_q = chunk_pick_q(e->H / 16, (e->hl + e->il) / (e->int8 ? TILE_K_I8 : TILE_K_F16));
+        e->k3_q = e->fp32 ? 1 : chunk_pick_q(e->H / 16, (e->hl + e->il) / (e->int8 ? TILE_K_I8 : TILE_K_F16));
         if (const char* m = getenv("FTCF_STAGE_MAX_ROWS")) {
             e->STAGE_MAX_ROWS = std::max(0, std::min(4, atoi(m)));
         }

@@ -224,6 +224,36 @@ void        launch_decode_persistent_group(const PersistGroupParams& g, bool int
 // tensor-parallel instantiations (kernels_persist_tp.hip); nullptr when the shape has none
 const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
 
+// ---- fp32 instantiation (FTGptNeoX<float>, GptNeoXOp.cc:56-70) : kernels_fp32.hip ----
+struct Mmha32Params {
+    const float*   qkv;       // [B, 3*Hl]
+    const float*   qkv_bias;  // [3*Hl]
+    float *        k_cache, *v_cache;  // [B, nh, s_max, dh]
+    const int*     seq_len;
+    const int*     pad_count;
+    const uint8_t* masked_tokens;  // [B, s_max]
+    const uint8_t* finished;
+    const int*     d_step;
+    int            B, nh, dh, rot, s_max;
+    float*         ctx;  // [B, Hl]
+    const int*     cache_indir;  // beam search: [2][B][s_max], or NULL
+    int            beam_width, max_input_len;
+    size_t         indir_plane;
+};
+void launch32_prompt_embedding(float* out, int* output_ids, const float* table, const int* ids, int B, int S, int H,
+                               hipStream_t s);
+void launch32_step_prologue(float* out, const float* table, const int* output_ids, const int* d_step, float* rot_table,
+                            const int* pad_count, int B, int H, int rot, hipStream_t s);
+void launch32_gather_last_token(float* out, const float* hidden, const int* input_lengths, int B, int S, int H,
+                                hipStream_t s, int tile = 1);
+void launch32_add_bias_residual(float* out, const float* a, const float* b, const float* bias, int m, int n, hipStream_t s);
+void launch32_gemm(const float* A, const float* W, const float* bias, int act, float* C, int m, int n, int k, hipStream_t s);
+void launch32_lm_head(const float* A, const float* W_nk, float* logits, int m, int n, int k, int ldc, hipStream_t s);
+void launch32_context_attention(float* qkv, const float* qkv_bias, const int* input_lengths, float* k_cache, float* v_cache,
+                                int B, int S, int nh, int dh, int rot, int s_max, float* ctx, hipStream_t s,
+                                int cache_row_mult = 1);
+void launch32_mmha(const Mmha32Params& p, hipStream_t s);
+
 // ---- dynamic decode : kernels_sampling.hip ----
 struct DecodeState {  // device resident, one per engine
     int step;         // current step (max_input_len .. total-1)

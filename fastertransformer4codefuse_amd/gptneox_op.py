@@ -79,9 +79,10 @@ class GptNeoXOp:
             _check_input(t, f"weights[{i}]")
             if t.numel() and t.dtype != st:
                 raise RuntimeError("Invalid datatype. All weights must have the same dtype")
-        if st != torch.float16:
-            raise RuntimeError("Wrong tensor type: the MI355X engine supports torch.float16 weights only "
-                               "(the reference also instantiates float32)")
+        if st not in (torch.float16, torch.float32):  # GptNeoXOp.cc:56-105: FTGptNeoX<float> / FTGptNeoX<half>
+            raise RuntimeError("Wrong Tensor type.")
+        if st == torch.float32 and int(int8_mode) != 0:
+            raise RuntimeError("int8_mode needs half weights (CutlassFpAIntBGemmRunner<half, uint8_t>)")
         self.end_id_ = int(end_id)
         self.vocab_size_ = int(vocab_size)
         self.tensor_para_size_ = int(tensor_para_size)
@@ -113,7 +114,8 @@ class GptNeoXOp:
         cfg = capi.GptNeoXConfig(int(head_num), int(size_per_head), int(inter_size), int(layer_num), int(vocab_size),
                                  int(rotary_embedding_dim), int(start_id), int(end_id), int(tensor_para_size),
                                  self.rank_ % int(tensor_para_size), int(pipeline_para_size), int(int8_mode),
-                                 capi.FP16, int(bool(use_gptj_residual)), int(self.device_), stream,
+                                 capi.FP32 if st == torch.float32 else capi.FP16, int(bool(use_gptj_residual)),
+                                 int(self.device_), stream,
                                  self._comm, 1)
         self._h = C.c_void_p()
         capi.check(capi.lib().ftcf_gptneox_create(C.byref(cfg), C.byref(w), C.byref(self._h)))

@@ -127,7 +127,9 @@ typedef struct {
     int start_id, end_id;
     int tensor_para_size, tensor_para_rank, pipeline_para_size; /* pipeline_para_size must be 1 */
     int int8_mode;                                               /* 0, or 1 = weight only */
-    int dtype;                                                   /* ftcf_dtype of `weights` (FTCF_FP16 on GPU) */
+    int dtype; /* ftcf_dtype of `weights` = the engine instantiated, as GptNeoXOp.cc:56-105 selects it from weights[0]:
+                * FTCF_FP16 (every decode path, int8_mode 0 / 1) or FTCF_FP32 (FTGptNeoX<float>: fp32 weights, activations and
+                * K/V cache, general path, int8_mode 0 only -- the validation instantiation, not tuned) */
     int use_gptj_residual;
     int device;        /* HIP device ordinal */
     void* stream;      /* hipStream_t all work is enqueued on (GptNeoXOp.h:180-185) */

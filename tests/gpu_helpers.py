@@ -12,7 +12,7 @@ def dev(a, dtype=torch.float16):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True):
+def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True, dtype=torch.float16):
     """cfg: dict like tests.helpers ; w: reference-order list of float32 numpy arrays -- the full TP=1 layout, or with
     tp > 1 the shard of `rank` (tests.helpers.shard_weights)."""
     L = cfg["num_layer"]
@@ -30,11 +30,12 @@ def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True
                     qi = {2: 0, 4: 1, 6: 2, 8: 3}[g]
                     int8_w[qi * L + l] = q.cuda()
                     scales[qi * L + l] = s.cuda()
-                    weights.append(torch.empty(0, dtype=torch.float16, device="cuda"))
+                    weights.append(torch.empty(0, dtype=dtype, device="cuda"))
                     continue
-            weights.append(dev(a) if a.size else torch.empty(0, dtype=torch.float16, device="cuda"))
+            weights.append(dev(a, dtype) if a.size else torch.empty(0, dtype=dtype, device="cuda"))
     V = cfg["vocab_size"]
-    weights += [dev(w[12 * L].reshape(V, H)), dev(w[12 * L + 1]), dev(w[12 * L + 2]), dev(w[12 * L + 3].reshape(V, H))]
+    weights += [dev(w[12 * L].reshape(V, H), dtype), dev(w[12 * L + 1], dtype), dev(w[12 * L + 2], dtype),
+                dev(w[12 * L + 3].reshape(V, H), dtype)]
     if not int8_mode:
         int8_w, scales = [], []
     op = GptNeoXOp(comm, rank, cfg["head_num"], cfg["size_per_head"], I, L, V, cfg["rotary_dim"], cfg.get("start_id", 0),
