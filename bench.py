@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--inter", type=int, default=20480)
     p.add_argument("--vocab", type=int, default=100864)
     p.add_argument("--rotary", type=int, default=32)
+    p.add_argument("--top-k", type=int, default=1, help="sampling top_k (1 = greedy, the headline; the reference harness "
+                                                         "defaults to 50)")
+    p.add_argument("--top-p", type=float, default=0.0, help="sampling top_p (with --top-k 0: the top-p layer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-e2e", action="store_true")
     p.add_argument("--profile-steps", type=int, default=48)
@@ -205,7 +208,8 @@ def main():
     out_ids = torch.empty((B, 1, total), dtype=torch.int32, device=dev)
     seq = torch.empty((B, 1), dtype=torch.int32, device=dev)
     cum = torch.empty((B, 1), dtype=torch.float32, device=dev)
-    top_k = np.array([1], np.int32)
+    top_k = np.array([a.top_k], np.int32)
+    top_p = np.array([a.top_p], np.float32)
     minlen = np.array([out_len], np.int32)  # end_id cannot be sampled: all steps run
 
     def make_args(olen):
@@ -213,6 +217,8 @@ def main():
         fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
         fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, olen, 1
         fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+        if a.top_p > 0:
+            fa.top_p, fa.n_top_p = top_p.ctypes.data, 1
         fa.min_length, fa.n_min_length = minlen.ctypes.data, 1
         fa.return_cum_log_probs = 1  # codefuse_example.py:745
         fa.output_ids, fa.sequence_lengths, fa.cum_log_probs = out_ids.data_ptr(), seq.data_ptr(), cum.data_ptr()
@@ -353,7 +359,7 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"CodeFuse-13B-shaped GPT-NeoX (L={a.layers},H={H},I={a.inter},V={a.vocab}) "
                                f"{'weight-only int8' if a.dtype == 'int8' else 'fp16'} TP={tp}, bs={B}, "
-                               f"{S}-in/{out_len}-out greedy decode", "weights": a.dtype, "tensor_parallel": tp,
+                               f"{S}-in/{out_len}-out {'greedy' if a.top_k == 1 else 'top-k ' + str(a.top_k)} decode", "weights": a.dtype, "tensor_parallel": tp,
                    "batch": B, "prompt_len": S, "output_len": out_len, "return_cum_log_probs": 1,
                    "timed_window": f"output tokens {first}..{first + steps - 1} of the {S}-in/{out_len}-out request "
                                    f"(KV length {S + first}..{S + first + steps - 1}, mean {t_mean:g}; request mean "

@@ -1871,6 +1871,12 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     sp.end_id = cfg.end_id;
     sp.input_lengths = in_len;
     sp.top_k = d_top_k;
+    sp.max_top_k = 1;
+    sp.any_top_p = 0;
+    for (int i = 0; i < batch; i++) {
+        sp.max_top_k = std::max(sp.max_top_k, k_eff[i]);
+        sp.any_top_p |= (k_eff[i] == 0);
+    }
     sp.top_p_topk = d_p_topk;
     sp.top_p_topp = d_p_topp;
     sp.temperature = d_temp;

@@ -267,6 +267,7 @@ struct SamplingParams {
     int          max_input_len, total_len, end_id;
     const int*   input_lengths;
     const int*   top_k;        // device [B] effective k (0 => row belongs to the top-p layer)
+    int          max_top_k, any_top_p;  // host view of the same: largest k of the batch, any top-p row (LDS sizing)
     const float* top_p_topk;   // device [B] p used by the top-k layer
     const float* top_p_topp;   // device [B] p used by the top-p layer
     const float* temperature;  // device [B]

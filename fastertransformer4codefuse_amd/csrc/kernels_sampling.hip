@@ -11,6 +11,8 @@
 #include "ftcf_common.h"
 #include "kernels.h"
 
+#include <mutex>
+
 namespace ftcf {
 
 constexpr int TOPK_BLOCKS = 8;     // blocks per row in stage 1 (the reference's BLOCKS_PER_BEAM_)
@@ -229,16 +231,57 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
 }
 
 // ---- step 2: stage-1 top-k: every block extracts the k best of its contiguous vocabulary slice ------------------
+// The k best of a slice as a SET (stage 2 sorts the union of the slices' sets): the k-th largest value is found by a radix
+// select over the order-preserving integer image of the floats -- four histogram passes of 8 bits over the slice in LDS
+// -- then everything above it is emitted through an LDS counter, and of the elements EQUAL to it the ones with the lowest
+// indices (the tie rule of `better`: value desc, index asc) by a block-wide prefix count.  Cost is independent of k.
+// (The first version extracted one maximum per pass over the slice: 373 us per token at the reference harness's default
+// top_k = 50, codefuse_example.py:799 -- 14 % of a 13B decode step.)
+constexpr int STAGE1_MAXE = 60;  // elements per thread of a stage-1 slice (registers): V <= 8 x 256 x 60 = 122880
+constexpr int TOPP_K = 128;  // candidates per slice kept for the rows of the top-p layer (see k_sample)
+
+__device__ __forceinline__ unsigned fkey(const float v)  // v1 > v2 <=> fkey(v1) > fkey(v2) (no NaNs among logits)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// exclusive prefix sum of one int per thread over the 256-thread block; `tot` = block total.  red: 4 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(const int v, int* red, int& tot)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int       inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) {
+            inc += t;
+        }
+    }
+    if (lane == 63) {
+        red[wid] = inc;
+    }
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wid; w++) {
+        base += red[w];
+    }
+    tot = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, float* cand_v, int* cand_i, int slice)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redv[4];
     __shared__ int   redi[4];
-    float*           sv = reinterpret_cast<float*>(smem);  // [slice]
+    __shared__ int   hist[256];
+    __shared__ int   hist8[8][257];
+    __shared__ int   s_sel[4];  // [0] chosen bin, [1] still needed inside it, [2] emit counter
     const int        b = blockIdx.y, blk = blockIdx.x;
     int              k = p.top_k[b];
-    if (k == 0) {
-        k = 1;  // top-p rows only need the arg max for the shortcut test
+    const bool       topp = k == 0;
+    if (topp) {
+        k = TOPP_K;  // top-p rows: the head of the sorted order comes from these candidates
     }
     if (p.finished[b]) {
         return;
@@ -247,14 +290,33 @@ __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, flo
     const int    i0 = blk * slice;
     const int    n  = max(0, min(slice, V - i0));
     const float* l  = p.logits + (size_t)b * V + i0;
+    float*       ov = cand_v + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
+    int*         oi = cand_i + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
+    // the thread's elements i = tid + 256 j live in REGISTERS from here on (all loads in flight at once; the arg max, the
+    // soft-max statistics, the four select passes and the emission read them there -- an earlier form staged the slice in LDS
+    // and every pass serialised on its LDS read -> atomic dependency)
+    float     vals[STAGE1_MAXE];
+    const int ne = n > (int)threadIdx.x ? (n - (int)threadIdx.x + 255) / 256 : 0;
+#pragma unroll
+    for (int j = 0; j < STAGE1_MAXE; j++) {
+        vals[j] = (j < ne) ? l[threadIdx.x + 256 * j] : -INFINITY;
+    }
+    VI    best{-INFINITY, 0x7fffffff};
     float lmax = -FLT_MAX;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = l[i];
-        sv[i]         = v;
-        lmax          = fmaxf(lmax, v);
+#pragma unroll
+    for (int j = 0; j < STAGE1_MAXE; j++) {
+        if (j < ne) {
+            const float v = vals[j];
+            const int   i = threadIdx.x + 256 * j;
+            lmax          = fmaxf(lmax, v);
+            if (best.i == 0x7fffffff || better(v, i, best.v, best.i)) {
+                best.v = v;
+                best.i = i;
+            }
+        }
     }
     __syncthreads();
-    if (p.return_cum_log_probs && p.top_k[b] > 0) {  // softmax statistics of the slice: {max, sum of exp(v - max)}
+    if (p.return_cum_log_probs && !topp) {  // softmax statistics of the slice: {max, sum of exp(v - max)}
         lmax = wave_max(lmax);
         if ((threadIdx.x & 63) == 0) {
             redv[threadIdx.x >> 6] = lmax;
@@ -263,8 +325,11 @@ __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, flo
         const float m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
         __syncthreads();
         float se = 0.f;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            se += __expf(sv[i] - m);
+#pragma unroll
+        for (int j = 0; j < STAGE1_MAXE; j++) {
+            if (j < ne) {
+                se += __expf(vals[j] - m);
+            }
         }
         se = wave_sum(se);
         if ((threadIdx.x & 63) == 0) {
@@ -278,45 +343,228 @@ __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, flo
         }
         __syncthreads();
     }
-    float* ov = cand_v + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
-    int*   oi = cand_i + ((size_t)b * TOPK_BLOCKS + blk) * TOPK_MAX;
-    uint32_t* taken = reinterpret_cast<uint32_t*>(sv + slice);  // [ceil(slice/32)]
-    for (int i = threadIdx.x; i < (slice + 31) / 32; i += 256) {
-        taken[i] = 0u;
+    const int ke = k < n ? k : n;  // candidates this slice can supply
+    for (int i = ke + threadIdx.x; i < k; i += 256) {
+        ov[i] = -INFINITY;
+        oi[i] = -1;
     }
-    __syncthreads();
-    for (int it = 0; it < k; it++) {
-        VI best{-INFINITY, 0x7fffffff};
-        for (int i = threadIdx.x; i < n; i += 256) {
-            if ((taken[i >> 5] >> (i & 31)) & 1u) {
-                continue;
-            }
-            const float v = sv[i];
-            if (best.i == 0x7fffffff || better(v, i, best.v, best.i)) {
-                best.v = v;
-                best.i = i;
-            }
-        }
+    if (ke == 0) {
+        return;
+    }
+    if (ke == 1) {  // greedy / k = 1: the arg max came with the load pass
         const VI r = block_best(best, redv, redi);
         if (threadIdx.x == 0) {
-            const bool valid = r.i != 0x7fffffff;
-            ov[it] = valid ? r.v : -INFINITY;
-            oi[it] = valid ? (i0 + r.i) : -1;
-            if (valid) {
-                taken[r.i >> 5] |= 1u << (r.i & 31);
+            ov[0] = r.v;
+            oi[0] = i0 + r.i;
+        }
+        return;
+    }
+    // ---- radix select: key of the ke-th largest element ----
+    unsigned prefix = 0u, mask = 0u;
+    int      need = ke;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            hist8[q][threadIdx.x] = 0;
+        }
+        __syncthreads();
+        // (eight private copies of the histogram, picked by lane: the sign / exponent bytes of a row's logits fall into a
+        // handful of bins)
+#pragma unroll
+        for (int j = 0; j < STAGE1_MAXE; j++) {
+            const unsigned key = fkey(vals[j]);
+            if (j < ne && (key & mask) == prefix) {
+                atomicAdd(&hist8[threadIdx.x & 7][(key >> shift) & 255u], 1);
             }
         }
         __syncthreads();
+        {
+            int t = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                t += hist8[q][threadIdx.x];
+            }
+            hist[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // bins 4 * lane .. 4 * lane + 3; suffix sums from the top bin down
+            const int lane = threadIdx.x;
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int       above = mine;  // inclusive suffix over lanes >= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(above, o, 64);
+                if (lane + o < 64) {
+                    above += t;
+                }
+            }
+            above -= mine;  // elements in bins of higher lanes
+            // the lane whose bins contain the need-th element (counted from the top)
+            if (above < need && above + mine >= need) {
+                int acc = above;
+                int bin = 4 * lane + 3;
+                const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    if (acc + hh[q] >= need) {
+                        bin = 4 * lane + q;
+                        break;
+                    }
+                    acc += hh[q];
+                }
+                s_sel[0] = bin;
+                s_sel[1] = need - acc;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_sel[0] << shift;
+        mask |= 255u << shift;
+        need = s_sel[1];
+        __syncthreads();
+    }
+    // prefix = key of the ke-th largest; `need` of the elements equal to it belong to the set, (ke - need) are greater
+    if (threadIdx.x == 0) {
+        s_sel[2] = 0;
+    }
+    __syncthreads();
+    int ties = 0;
+#pragma unroll
+    for (int j = 0; j < STAGE1_MAXE; j++) {
+        if (j < ne) {
+            const unsigned key = fkey(vals[j]);
+            if (key > prefix) {
+                const int pos = atomicAdd(&s_sel[2], 1);
+                ov[pos]       = vals[j];
+                oi[pos]       = i0 + (int)threadIdx.x + 256 * j;
+            }
+            else if (key == prefix) {
+                ties++;
+            }
+        }
+    }
+    int       tot  = 0;
+    int       rank = block_excl_scan(ties, redi, tot);
+    const int tie0 = ke - need;
+    if (tot == need) {  // every element equal to the threshold belongs to the set (the usual case: exactly one)
+#pragma unroll
+        for (int j = 0; j < STAGE1_MAXE; j++) {
+            if (j < ne && fkey(vals[j]) == prefix) {
+                ov[tie0 + rank] = vals[j];
+                oi[tie0 + rank] = i0 + (int)threadIdx.x + 256 * j;
+                rank++;
+            }
+        }
+        return;
+    }
+    // more equal elements than places: the ones with the lowest indices (the tie rule of `better`) -- index order needs a
+    // contiguous chunk per thread
+    const int per = (n + 255) / 256;
+    const int c0 = threadIdx.x * per, c1 = min(n, c0 + per);
+    ties = 0;
+    for (int i = c0; i < c1; i++) {
+        ties += fkey(l[i]) == prefix ? 1 : 0;
+    }
+    rank = block_excl_scan(ties, redi, tot);
+    for (int i = c0; i < c1 && rank < need; i++) {
+        if (fkey(l[i]) == prefix) {
+            ov[tie0 + rank] = l[i];
+            oi[tie0 + rank] = i0 + i;
+            rank++;
+        }
     }
 }
 
 // ---- step 3: merge + sample (one block per row) -----------------------------------------------------------------
+// bitonic sort of n2 (a power of two) {value, id} pairs in LDS, best first (value desc, id asc)
+__device__ __forceinline__ void bitonic_sort_best_first(float* v, int* id, const int n2)
+{
+    for (int sz = 2; sz <= n2; sz <<= 1) {
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < n2 / 2; t += blockDim.x) {
+                const int  lo = ((t / st) * 2) * st + (t % st), hi = lo + st;
+                const bool desc = ((lo & sz) == 0);  // this block of the network sorts best-first
+                const bool hi_better = better(v[hi], id[hi], v[lo], id[lo]);
+                if (hi_better == desc) {
+                    const float tv = v[lo];
+                    const int   ti = id[lo];
+                    v[lo]  = v[hi];
+                    id[lo] = id[hi];
+                    v[hi]  = tv;
+                    id[hi] = ti;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the same network over n2 pairs in GLOBAL memory (one workgroup): strides >= CH run on global memory, every run of
+// strides < CH on CH-element chunks staged through LDS (lv / li: CH entries each)
+constexpr int SORT_CH = 4096;
+__device__ __forceinline__ void bitonic_sort_global(float* v, int* id, const int n2, float* lv, int* li)
+{
+    for (int sz = 2; sz <= n2; sz <<= 1) {
+        int st = sz >> 1;
+        for (; st >= SORT_CH; st >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < n2 / 2; t += blockDim.x) {
+                const int  lo = ((t / st) * 2) * st + (t % st), hi = lo + st;
+                const bool desc = ((lo & sz) == 0);
+                const float vl = v[lo], vh = v[hi];
+                const int   il = id[lo], ih = id[hi];
+                if (better(vh, ih, vl, il) == desc) {
+                    v[lo]  = vh;
+                    id[lo] = ih;
+                    v[hi]  = vl;
+                    id[hi] = il;
+                }
+            }
+        }
+        if (st == 0) {
+            continue;
+        }
+        __syncthreads();
+        const int ch = n2 < SORT_CH ? n2 : SORT_CH;
+        for (int c0 = 0; c0 < n2; c0 += ch) {
+            for (int i = threadIdx.x; i < ch; i += blockDim.x) {
+                lv[i] = v[c0 + i];
+                li[i] = id[c0 + i];
+            }
+            for (int s2 = st; s2 > 0; s2 >>= 1) {
+                __syncthreads();
+                for (int t = threadIdx.x; t < ch / 2; t += blockDim.x) {
+                    const int  lo = ((t / s2) * 2) * s2 + (t % s2), hi = lo + s2;
+                    const bool desc = (((c0 + lo) & sz) == 0);
+                    if (better(lv[hi], li[hi], lv[lo], li[lo]) == desc) {
+                        const float tv = lv[lo];
+                        const int   ti = li[lo];
+                        lv[lo] = lv[hi];
+                        li[lo] = li[hi];
+                        lv[hi] = tv;
+                        li[hi] = ti;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < ch; i += blockDim.x) {
+                v[c0 + i]  = lv[i];
+                id[c0 + i] = li[i];
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* cand_v, int* cand_i)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redv[4];
     __shared__ int   redi[4];
     __shared__ float s_rnd;
+    __shared__ int   s_pick[2];
     const int        b = blockIdx.x;
     const int        V = p.V;
     const int        step = p.state->step;
@@ -329,37 +577,48 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
     }
     const int k = p.top_k[b];
     float*    l = p.logits + (size_t)b * V;
-    if (k > 0) {
-        // ---- top-k layer (sampling_topk_kernels.cu:210-311) ----
-        float* sv   = reinterpret_cast<float*>(smem);       // [k] sorted values
-        int*   si   = reinterpret_cast<int*>(sv + TOPK_MAX);  // [k] ids
-        float* cv   = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
-        int*   ci   = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
-        for (int it = 0; it < k; it++) {
+    // the union of the slices' candidate sets, sorted best first: [0, n2) in LDS
+    const int kc = k > 0 ? k : TOPP_K;
+    int       n2 = 1;
+    while (n2 < TOPK_BLOCKS * kc) {
+        n2 <<= 1;
+    }
+    float* sv = reinterpret_cast<float*>(smem);    // [n2] values
+    int*   si = reinterpret_cast<int*>(sv + n2);   // [n2] ids
+    {
+        const float* cv = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        const int*   ci = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+        for (int c = threadIdx.x; c < n2; c += 256) {
+            const int blk = c / kc, j = c % kc;
+            float     v   = -INFINITY;
+            int       id  = 0x7fffffff;
+            if (c < TOPK_BLOCKS * kc && ci[blk * TOPK_MAX + j] >= 0) {
+                v  = cv[blk * TOPK_MAX + j];
+                id = ci[blk * TOPK_MAX + j];
+            }
+            sv[c] = v;
+            si[c] = id;
+        }
+        if (kc > 1) {
+            bitonic_sort_best_first(sv, si, n2);
+        }
+        else {  // one candidate per slice: the best of 8
+            __syncthreads();
             VI best{-INFINITY, 0x7fffffff};
-            for (int c = threadIdx.x; c < TOPK_BLOCKS * k; c += 256) {
-                const int   blk = c / k, j = c % k;
-                const int   id  = ci[blk * TOPK_MAX + j];
-                const float v   = cv[blk * TOPK_MAX + j];
-                if (id >= 0 && better(v, id, best.v, best.i)) {
-                    best.v = v;
-                    best.i = id;
-                }
+            if (threadIdx.x < TOPK_BLOCKS) {
+                best.v = sv[threadIdx.x];
+                best.i = si[threadIdx.x];
             }
             const VI r = block_best(best, redv, redi);
             if (threadIdx.x == 0) {
-                sv[it] = r.v;
-                si[it] = r.i;
-            }
-            // remove the winner from the candidate lists
-            for (int c = threadIdx.x; c < TOPK_BLOCKS * k; c += 256) {
-                const int blk = c / k, j = c % k;
-                if (ci[blk * TOPK_MAX + j] == r.i) {
-                    ci[blk * TOPK_MAX + j] = -1;
-                }
+                sv[0] = r.v;
+                si[0] = r.i;
             }
             __syncthreads();
         }
+    }
+    if (k > 0) {
+        // ---- top-k layer (sampling_topk_kernels.cu:210-311): sv / si [0, k) are the row's k best ----
         if (threadIdx.x == 0) {
             const float smax = sv[0];
             float       ssum = 0.f;
@@ -412,50 +671,111 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
     }
     else {
         // ---- top-p layer (sampling_topp_kernels.cu:802-1000): probabilities are in `l` ----
-        // stage 1 (k forced to 1) left the arg max of every slice in the candidate lists
-        float* cv = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
-        int*   ci = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
-        VI     best{-INFINITY, 0x7fffffff};
-        if (threadIdx.x < TOPK_BLOCKS && ci[threadIdx.x * TOPK_MAX] >= 0) {
-            best.v = cv[threadIdx.x * TOPK_MAX];
-            best.i = ci[threadIdx.x * TOPK_MAX];
-        }
-        const VI    top = block_best(best, redv, redi);
+        // The reference sorts the whole row and walks it until rand * p <= cumulative probability.  Here the walk runs over
+        // the sorted candidates (TOPP_K per slice): every candidate ABOVE the largest value a slice may have left out
+        // (v_cut = max over the slices that supplied all TOPP_K of their smallest candidate) is at its exact place of the
+        // full order, so the same fp32 additions happen in the same order.  Only a walk that gets past v_cut -- a nearly
+        // flat distribution -- falls back to extracting one maximum of the remaining row per pass.
         const float thr = p.top_p_topp[b];
-        float       u01 = 0.f;
         if (threadIdx.x == 0) {
-            u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
+            const float u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
             p.draw_counter[b] += 1;
             s_rnd = u01 * thr;
         }
-        __syncthreads();
-        int   id = top.i;
-        float pr = top.v;
-        if (!(top.v >= thr)) {
-            // exact sorted walk: repeatedly extract the (value desc, index asc) maximum and accumulate in fp32 until
-            // rand * p <= cumulative -- identical to the sequential scan over the sorted array.
-            float cum = 0.f;
-            for (int it = 0; it < V; it++) {
-                VI bb{-INFINITY, 0x7fffffff};
-                for (int i = threadIdx.x; i < V; i += 256) {
-                    const float v = l[i];
-                    if (better(v, i, bb.v, bb.i)) {
-                        bb.v = v;
-                        bb.i = i;
+        float v_cut = -INFINITY;
+        {
+            const float* cv = cand_v + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+            const int*   ci = cand_i + (size_t)b * TOPK_BLOCKS * TOPK_MAX;
+            for (int q = 0; q < TOPK_BLOCKS; q++) {
+                if (ci[q * TOPK_MAX + TOPP_K - 1] >= 0) {  // the slice had at least TOPP_K elements: more may follow
+                    float mn = INFINITY;
+                    for (int j = threadIdx.x; j < TOPP_K; j += 256) {
+                        mn = fminf(mn, cv[q * TOPK_MAX + j]);
                     }
+                    mn = -wave_max(-mn);
+                    if ((threadIdx.x & 63) == 0) {
+                        redv[threadIdx.x >> 6] = mn;
+                    }
+                    __syncthreads();
+                    v_cut = fmaxf(v_cut, fminf(fminf(redv[0], redv[1]), fminf(redv[2], redv[3])));
+                    __syncthreads();
                 }
-                const VI r = block_best(bb, redv, redi);
-                cum += r.v;
-                id = r.i;
-                pr = r.v;
-                if (s_rnd <= cum || it == V - 1) {
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float cum = 0.f;
+            int   i   = 0;
+            s_pick[0] = -1;
+            for (; i < TOPK_BLOCKS * TOPP_K; i++) {
+                if (si[i] == 0x7fffffff || !(sv[i] > v_cut)) {
+                    break;  // past the part of the order the candidates are known to hold
+                }
+                cum += sv[i];
+                if (s_rnd <= cum) {
+                    s_pick[0] = i;
                     break;
                 }
-                if (threadIdx.x == 0) {
-                    l[r.i] = -INFINITY;
+            }
+            s_pick[1] = i;       // candidates consumed without reaching the threshold (when s_pick[0] < 0)
+            redv[0]   = cum;
+        }
+        __syncthreads();
+        int   id = 0;
+        float pr = 0.f;
+        if (s_pick[0] >= 0) {
+            id = si[s_pick[0]];
+            pr = sv[s_pick[0]];
+        }
+        else {
+            // The walk left the part of the order the candidates hold (a flat distribution: > ~1000 tokens under top_p): sort
+            // the WHOLE row, as the reference always does (one segmented radix sort, sampling_topp_kernels.cu:1015-1100), and
+            // walk it from the start -- the same additions in the same order.  Bitonic network over the row's pairs in the
+            // workspace by this one workgroup (short strides through LDS); the first version extracted one maximum per pass over V
+            // (seconds per token in this regime).
+            int NV = 1;
+            while (NV < V) {
+                NV <<= 1;
+            }
+            float* fv = reinterpret_cast<float*>(cand_i + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX) + (size_t)p.B * TOPK_BLOCKS * 2
+                        + (size_t)b * 2 * NV;
+            int*   fi = reinterpret_cast<int*>(fv + NV);
+            __syncthreads();
+            for (int i = threadIdx.x; i < NV; i += 256) {
+                fv[i] = i < V ? l[i] : -INFINITY;
+                fi[i] = i < V ? i : 0x7fffffff;
+            }
+            bitonic_sort_global(fv, fi, NV, sv, reinterpret_cast<int*>(sv + SORT_CH));
+            // sequential fp32 walk by thread 0 over chunks staged through LDS
+            float cum = 0.f;
+            int   sel = V - 1;
+            for (int c0 = 0; c0 < V; c0 += 1024) {
+                __syncthreads();
+                for (int i = threadIdx.x; i < 1024; i += 256) {
+                    sv[i] = c0 + i < V ? fv[c0 + i] : 0.f;
                 }
                 __syncthreads();
+                if (threadIdx.x == 0) {
+                    s_pick[0] = -1;
+                    const int m = min(1024, V - c0);
+                    for (int i = 0; i < m; i++) {
+                        cum += sv[i];
+                        if (s_rnd <= cum) {
+                            s_pick[0] = c0 + i;
+                            break;
+                        }
+                    }
+                    redv[0] = cum;
+                }
+                __syncthreads();
+                cum = redv[0];
+                if (s_pick[0] >= 0) {
+                    sel = s_pick[0];
+                    break;
+                }
             }
+            id = fi[sel];
+            pr = fv[sel];
         }
         if (threadIdx.x == 0) {
             *out_id = id;
@@ -534,7 +854,13 @@ size_t sampling_workspace_bytes(int B, int V)
 {
     (void)V;
     // candidate values + ids of the stage-1 slices, then {max, sum of exp} per slice
-    return (size_t)B * TOPK_BLOCKS * TOPK_MAX * (sizeof(float) + sizeof(int)) + (size_t)B * TOPK_BLOCKS * 2 * sizeof(float);
+    size_t nv = 1;
+    while (nv < (size_t)V) {
+        nv <<= 1;
+    }
+    // ... then, per row, the {value, id} pairs of the whole row padded to a power of two (full sort of a top-p row)
+    return (size_t)B * TOPK_BLOCKS * TOPK_MAX * (sizeof(float) + sizeof(int)) + (size_t)B * TOPK_BLOCKS * 2 * sizeof(float)
+           + (size_t)B * 2 * nv * sizeof(float);
 }
 
 void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
@@ -551,9 +877,31 @@ void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
     FTCF_CHECK_ARG(prep_smem <= 60 * 1024, "sequence too long for the repetition-penalty staging buffer");
     hipLaunchKernelGGL(k_decode_prep, dim3(p.B), dim3(1024), prep_smem, s, p);
     const int slice = (p.V + TOPK_BLOCKS - 1) / TOPK_BLOCKS;
-    FTCF_CHECK_ARG((size_t)slice * 4 <= 60 * 1024, "vocabulary slice does not fit in LDS");
-    hipLaunchKernelGGL(k_topk_stage1, dim3(TOPK_BLOCKS, p.B), dim3(256), (size_t)slice * 4 + ((slice + 31) / 32) * 4, s, p, cand_v, cand_i, slice);
-    hipLaunchKernelGGL(k_sample, dim3(p.B), dim3(256), (size_t)TOPK_MAX * 8, s, p, cand_v, cand_i);
+    FTCF_CHECK_ARG(slice <= 256 * STAGE1_MAXE, "vocabulary too large: a stage-1 slice holds 256 x 60 logits in registers (V <= 122880)");
+    hipLaunchKernelGGL(k_topk_stage1, dim3(TOPK_BLOCKS, p.B), dim3(256), 0, s, p, cand_v, cand_i, slice);
+    // stage 2 sorts the union of the slices' candidate sets in LDS: the next power of two above 8 * k pairs
+    int kc = std::max(1, std::min(p.max_top_k, TOPK_MAX));
+    if (p.any_top_p) {
+        kc = std::max(kc, TOPP_K);
+    }
+    size_t n2 = 1;
+    while (n2 < (size_t)TOPK_BLOCKS * kc) {
+        n2 <<= 1;
+    }
+    const size_t sample_smem = std::max(n2 * 8, p.any_top_p ? (size_t)SORT_CH * 8 : (size_t)0);
+    if (sample_smem > 48 * 1024) {  // per device: the attribute is per device (and cheap to set again)
+        static std::mutex mu;
+        static bool       done[64] = {};
+        int               dev = 0;
+        FTCF_HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[dev & 63]) {
+            FTCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)((size_t)TOPK_BLOCKS * TOPK_MAX * 8)));
+            done[dev & 63] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_sample, dim3(p.B), dim3(256), sample_smem, s, p, cand_v, cand_i);
     hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
     FTCF_HIP_CHECK(hipGetLastError());
 }
