@@ -1,0 +1,71 @@
+"""Continuous batching over a paged K/V cache (include/ftcf.h `ftcf_batcher_*`).
+
+    op = GptNeoXOp(...)                       # fp16 / int8 engine, tensor_para_size 1
+    cb = ContinuousBatcher(op, max_batch=8, page_tokens=64, num_pages=512, max_seq_len=2048)
+    rid = cb.submit(prompt_ids, max_new_tokens=128)          # greedy; top_k / top_p / temperature / seed optional
+    while cb.busy():
+        for request_id, token, finished in cb.step():
+            ...
+
+The engine `op` must not run a request of its own while a batcher call is in progress."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class ContinuousBatcher:
+    def __init__(self, op, max_batch, page_tokens, num_pages, max_seq_len):
+        self._op = op  # keeps the engine (and its weights) alive
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().ftcf_batcher_create(op._h, int(max_batch), int(page_tokens), int(num_pages), int(max_seq_len),
+                                                  C.byref(self._h)))
+        n = 2 * self.max_batch
+        self._ids = (C.c_long * n)()
+        self._tok = (C.c_int * n)()
+        self._fin = (C.c_int * n)()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                capi.lib().ftcf_batcher_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def submit(self, prompt_ids, max_new_tokens, top_k=0, top_p=0.0, temperature=1.0, seed=0):
+        ids = np.ascontiguousarray(prompt_ids, dtype=np.int32).reshape(-1)
+        rid = C.c_long(0)
+        capi.check(capi.lib().ftcf_batcher_submit(self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), int(ids.size),
+                                                  int(max_new_tokens), int(top_k), C.c_float(top_p), C.c_float(temperature),
+                                                  C.c_ulonglong(int(seed)), C.byref(rid)))
+        return int(rid.value)
+
+    def step(self):
+        """One scheduler iteration; returns [(request_id, token, finished), ...] in production order."""
+        n = C.c_int(0)
+        capi.check(capi.lib().ftcf_batcher_step(self._h, self._ids, self._tok, self._fin, 2 * self.max_batch, C.byref(n)))
+        return [(int(self._ids[i]), int(self._tok[i]), bool(self._fin[i])) for i in range(n.value)]
+
+    def status(self):
+        w, r, f = C.c_int(0), C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().ftcf_batcher_status(self._h, C.byref(w), C.byref(r), C.byref(f)))
+        return {"waiting": w.value, "running": r.value, "free_pages": f.value}
+
+    def busy(self):
+        s = self.status()
+        return s["waiting"] > 0 or s["running"] > 0
+
+    def run_all(self, max_iterations=1 << 20):
+        """Drains the queue; returns {request_id: [tokens]}."""
+        out = {}
+        it = 0
+        while self.busy():
+            for rid, tok, _ in self.step():
+                out.setdefault(rid, []).append(tok)
+            it += 1
+            if it > max_iterations:
+                raise RuntimeError("the batcher did not drain")
+        return out

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -2410,4 +2411,499 @@ extern "C" int ftcf_gptneox_set_profiling(ftcf_gptneox_t h, int enabled)
 extern "C" int ftcf_gptneox_destroy(ftcf_gptneox_t h)
 {
     return guarded([&] { delete h; });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Continuous batching over a paged K/V cache (no counterpart in the reference, whose serving layer -- the
+// Triton backend -- allocates the cache per request, GptNeoX.cc:84-156).
+//
+// A batcher borrows an engine (weights, streams, kernels) and owns
+//   * a K/V POOL of fixed-size pages, [L][page][head][P tokens][dh] fp16, shared by all sequences, with a free list;
+//   * `max_batch` SLOTS: page table, length, last token, sampling parameters of the sequence living there;
+//   * a queue of waiting requests.
+// One iteration (ftcf_batcher_step) = ADMIT waiting requests into free slots while their pages (prompt + max_new_tokens,
+// reserved up front: a running sequence never has to be preempted) are available, then ONE decode step for all running
+// slots.  Admission runs the prompt through the engine's own context path (ftcf_gptneox_forward with output_len 1: prefill +
+// first token sampled by the engine's dynamic decode) and scatters the prompt's K/V into the slot's pages; the decode
+// step is the general layer sequence of the engine (§4a: dual LayerNorm, burst / tiled GEMMs, fused residual) with the
+// attention replaced by k_mmha_paged, the LM head, and the engine's sampling kernels on per-slot arrays.  A sequence leaves
+// when it emits end_id or reaches max_new_tokens; its pages return to the free list at once.
+// Scope of this first version: parallel-residual models, tensor_para_size 1, fp16 / int8 engines, beam_width 1, top-k /
+// top-p / temperature sampling (no repetition penalty, stop words or callbacks).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_batcher_embed(f16* out, const f16* table, const int* tok, int H)
+{
+    const int  id  = tok[blockIdx.x];
+    const f16* src = table + (size_t)id * H;
+    f16*       dst = out + (size_t)blockIdx.x * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+        *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+    }
+}
+__global__ void k_batcher_tick(DecodeState* gemm_state)
+{
+    gemm_state->step = (gemm_state->step + 1) & 0x7ffff;  // part of the burst GEMMs' granule tags (19 bits)
+}
+
+struct ftcf_batcher {
+    struct Request {
+        long             id;
+        std::vector<int> prompt;
+        int              max_new, top_k;
+        float            top_p, temperature;
+        uint64_t         seed;
+    };
+    struct Slot {
+        bool             active = false;
+        long             id = 0;
+        int              len = 0, generated = 0, max_new = 0;
+        std::vector<int> pages;
+    };
+    ftcf_gptneox* e = nullptr;
+    int           max_batch = 0, P = 0, num_pages = 0, max_pages = 0, max_len = 0;
+    size_t        pool_layer_elems = 0;
+    // device
+    f16 *kpool = nullptr, *vpool = nullptr;
+    f16 *x = nullptr, *nrm = nullptr, *nrm2 = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
+    float*    logits = nullptr;
+    int *     d_pt = nullptr, *d_len = nullptr, *d_tok = nullptr, *d_topk = nullptr, *d_zero = nullptr, *d_prompt = nullptr, *d_plen = nullptr,
+        *d_pout = nullptr, *d_pseq = nullptr, *d_pages_tmp = nullptr;
+    uint8_t*     d_fin = nullptr;
+    float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr;
+    uint64_t *   d_seed = nullptr, *d_draws = nullptr;
+    DecodeState *d_state = nullptr, *d_gstate = nullptr;
+    void*        samp_ws = nullptr;
+    float*       smallm_ws = nullptr;
+    size_t       smallm_partial = 0;
+    unsigned     smallm_seq = 0;
+    long         gemm_steps = 0;
+    std::vector<void*> owned;
+    // host
+    std::vector<Slot>   slots;
+    std::deque<Request> waiting;
+    std::vector<int>    free_pages;
+    long                next_id = 1;
+    int                 max_prompt = 0;
+
+    template<typename T>
+    T* dmalloc(size_t n, bool zero = true)
+    {
+        void* p = nullptr;
+        FTCF_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        if (zero) {
+            FTCF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+        }
+        owned.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    ~ftcf_batcher()
+    {
+        for (void* p : owned) {
+            (void)hipFree(p);
+        }
+    }
+
+    void init(ftcf_gptneox* eng, int mb, int page_tokens, int pages, int max_seq_len)
+    {
+        e = eng;
+        FTCF_CHECK_ARG(!e->fp32 && e->cfg.tensor_para_size == 1 && e->cfg.use_gptj_residual,
+                       "the batcher serves fp16 / int8 engines with parallel residual and tensor_para_size 1");
+        FTCF_CHECK_ARG(mb >= 1 && mb <= 64 && page_tokens >= 8 && pages >= 1 && max_seq_len >= 2, "bad batcher geometry");
+        FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
+        max_batch = mb;
+        P         = page_tokens;
+        num_pages = pages;
+        max_pages = (max_seq_len + P - 1) / P;
+        max_len   = max_pages * P;
+        max_prompt = max_seq_len - 1;
+        FTCF_CHECK_ARG(mmha_paged_smem_bytes(e->dh, max_pages, max_len) <= 64 * 1024, "max_seq_len too large for the paged attention");
+        const int    H = e->H, hl = e->hl, il = e->il, L = e->L, V = e->V;
+        const size_t B = (size_t)max_batch;
+        pool_layer_elems = (size_t)num_pages * e->nhl * P * e->dh;
+        kpool = dmalloc<f16>((size_t)L * pool_layer_elems, false);
+        vpool = dmalloc<f16>((size_t)L * pool_layer_elems, false);
+        x = dmalloc<f16>(B * H);
+        nrm = dmalloc<f16>(B * H);
+        nrm2 = dmalloc<f16>(B * H);
+        qkv = dmalloc<f16>(B * 3 * hl);
+        ctx = dmalloc<f16>(B * hl);
+        att = dmalloc<f16>(B * H);
+        mid = dmalloc<f16>(B * il);
+        ffn = dmalloc<f16>(B * H);
+        logits = dmalloc<float>(B * V);
+        d_pt = dmalloc<int>(B * max_pages);
+        d_len = dmalloc<int>(B);
+        d_tok = dmalloc<int>(B);
+        d_topk = dmalloc<int>(B);
+        d_zero = dmalloc<int>(B);
+        d_fin = dmalloc<uint8_t>(B);
+        d_ptopk = dmalloc<float>(B);
+        d_ptopp = dmalloc<float>(B);
+        d_temp = dmalloc<float>(B);
+        d_cum = dmalloc<float>(B);
+        d_seed = dmalloc<uint64_t>(B);
+        d_draws = dmalloc<uint64_t>(B);
+        d_state = dmalloc<DecodeState>(1);
+        d_gstate = dmalloc<DecodeState>(1);
+        d_prompt = dmalloc<int>(max_seq_len);
+        d_plen = dmalloc<int>(1);
+        d_pout = dmalloc<int>(max_seq_len + 1);
+        d_pseq = dmalloc<int>(1);
+        d_pages_tmp = dmalloc<int>(max_pages);
+        samp_ws = dmalloc<char>(sampling_workspace_bytes(max_batch, V), false);
+        if (max_batch > 4 && max_batch <= 16) {
+            const bool i8 = e->int8;
+            smallm_partial = gemm_smallm_workspace_bytes(max_batch, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(max_batch, il, H, i8)
+                             + gemm_smallm_workspace_bytes(max_batch, H, hl, i8) + gemm_smallm_workspace_bytes(max_batch, H, il, i8);
+            smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
+        }
+        std::vector<uint8_t> fin(max_batch, 1);
+        FTCF_HIP_CHECK(hipMemcpy(d_fin, fin.data(), max_batch, hipMemcpyHostToDevice));
+        slots.assign(max_batch, Slot{});
+        free_pages.resize(num_pages);
+        for (int i = 0; i < num_pages; i++) {
+            free_pages[i] = num_pages - 1 - i;
+        }
+    }
+
+    long submit(const int* ids, int n, int max_new, int top_k, float top_p, float temperature, uint64_t seed)
+    {
+        FTCF_CHECK_ARG(ids && n >= 1 && max_new >= 1, "empty prompt or max_new_tokens < 1");
+        FTCF_CHECK_ARG(n + max_new <= max_len && n <= max_prompt, "prompt + max_new_tokens exceed the batcher's max_seq_len");
+        FTCF_CHECK_ARG((n + max_new + P - 1) / P <= num_pages, "the request needs more pages than the pool has");
+        FTCF_CHECK_ARG(top_k >= 0 && top_k <= 1024 && top_p >= 0.f && top_p <= 1.f && temperature > 0.f, "bad sampling parameters");
+        for (int i = 0; i < n; i++) {
+            FTCF_CHECK_ARG(ids[i] >= 0 && ids[i] < e->V, "token id out of range");
+        }
+        Request r;
+        r.id = next_id++;
+        r.prompt.assign(ids, ids + n);
+        r.max_new = max_new;
+        r.top_k = top_k;
+        r.top_p = top_p;
+        r.temperature = temperature;
+        r.seed = seed;
+        waiting.push_back(std::move(r));
+        return waiting.back().id;
+    }
+
+    struct Event {
+        long id;
+        int  token, finished;
+    };
+
+    void release(Slot& s)
+    {
+        for (int pg : s.pages) {
+            free_pages.push_back(pg);
+        }
+        s.pages.clear();
+        s.active = false;
+    }
+
+    // prompt -> engine context path (+ first token) -> pages of slot `si`
+    void admit(int si, const Request& r, std::vector<Event>& ev)
+    {
+        Range        rg("ftcf.batcher.admit");
+        hipStream_t  st = e->stream;
+        const int    S = (int)r.prompt.size();
+        Slot&        s = slots[si];
+        const int    need = (S + r.max_new + P - 1) / P;
+        s.pages.clear();
+        for (int i = 0; i < need; i++) {
+            s.pages.push_back(free_pages.back());
+            free_pages.pop_back();
+        }
+        FTCF_HIP_CHECK(hipMemcpy(d_prompt, r.prompt.data(), (size_t)S * 4, hipMemcpyHostToDevice));
+        FTCF_HIP_CHECK(hipMemcpy(d_plen, &S, 4, hipMemcpyHostToDevice));
+        ftcf_forward_args a{};
+        a.input_ids = d_prompt;
+        a.input_lengths = d_plen;
+        a.batch_size = 1;
+        a.max_input_len = S;
+        a.output_len = 1;
+        a.beam_width = 1;
+        // the engine's own rule for (top_k, top_p) = (0, 0) is greedy; pass the request's values through
+        a.top_k = &r.top_k;
+        a.n_top_k = 1;
+        a.top_p = &r.top_p;
+        a.n_top_p = 1;
+        a.temperature = &r.temperature;
+        a.n_temperature = 1;
+        a.random_seed = &r.seed;
+        a.n_random_seed = 1;
+        a.output_ids = d_pout;
+        a.sequence_lengths = d_pseq;
+        e->forward(a);  // host synchronous: K/V of positions [0, S) are in the engine's cache [L][1][nh][S + 1][dh]
+        int first = 0;
+        FTCF_HIP_CHECK(hipMemcpy(&first, d_pout + S, 4, hipMemcpyDeviceToHost));
+        std::vector<int> row(max_pages, 0);
+        for (size_t i = 0; i < s.pages.size(); i++) {
+            row[i] = s.pages[i];
+        }
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_pt + (size_t)si * max_pages, row.data(), (size_t)max_pages * 4, hipMemcpyHostToDevice, st));
+        launch_scatter_kv_to_pages(e->k_cache, e->v_cache, kpool, vpool, d_pt + (size_t)si * max_pages, e->L, e->nhl, e->dh, S + 1,
+                                   S, P, pool_layer_elems, st);
+        // per-slot state of the decode steps
+        const int      keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);  // BaseSamplingLayer: (0, 0) = greedy
+        const float    ptk = (r.top_p == 0.f) ? 1.f : r.top_p;
+        const uint8_t  zero8 = 0;
+        const uint64_t one = 1;
+        const float    zf = 0.f;
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, &S, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_tok + si, &first, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_topk + si, &keff, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopk + si, &ptk, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopp + si, &r.top_p, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_temp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_seed + si, &r.seed, 8, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_draws + si, &one, 8, hipMemcpyHostToDevice, st));  // draw 0 went to the first token
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, &zf, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, &zero8, 1, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));  // the host temporaries above die here
+        s.active = true;
+        s.id = r.id;
+        s.len = S;
+        s.generated = 1;
+        s.max_new = r.max_new;
+        const int done = (first == e->cfg.end_id || s.generated >= s.max_new) ? 1 : 0;
+        ev.push_back(Event{r.id, first, done});
+        if (done) {
+            const uint8_t one8 = 1;
+            FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+            release(s);
+        }
+    }
+
+    // one token for every running slot
+    void decode(std::vector<Event>& ev)
+    {
+        Range                  rg("ftcf.batcher.decode");
+        hipStream_t            st = e->stream;
+        const int              B = max_batch, H = e->H, hl = e->hl, il = e->il, L = e->L, V = e->V;
+        const bool             int8 = e->int8;
+        const bool             dual = residual_dual_ln_supported(H);
+        hipLaunchKernelGGL(k_batcher_embed, dim3(B), dim3(256), 0, st, x, e->wte, d_tok, H);
+        if ((gemm_steps++ & 0x3ffff) == 0 && smallm_ws) {  // the tag space of the burst GEMMs wraps: start it clean
+            FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
+        }
+        hipLaunchKernelGGL(k_batcher_tick, dim3(1), dim3(1), 0, st, d_gstate);
+        auto gemm = [&](const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int n, int k) {
+            gemm_dispatch(A, w.kernel, w.scale, bias, act, C, B, n, k, int8, st, nullptr, 0, e->num_cu);
+        };
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = e->layers[l];
+            if (!dual) {
+                launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
+                launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, st);
+            }
+            else if (l == 0) {
+                launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm, nrm2, B, H,
+                                        1e-5f, st);
+            }
+            MmhaPagedParams mp{};
+            mp.qkv = qkv;
+            mp.qkv_bias = w.qkv.bias;
+            mp.kpool = kpool + (size_t)l * pool_layer_elems;
+            mp.vpool = vpool + (size_t)l * pool_layer_elems;
+            mp.page_table = d_pt;
+            mp.len = d_len;
+            mp.finished = d_fin;
+            mp.B = B;
+            mp.nh = e->nhl;
+            mp.dh = e->dh;
+            mp.rot = e->cfg.rotary_embedding_dim;
+            mp.P = P;
+            mp.max_pages = max_pages;
+            mp.ctx = ctx;
+            if (smallm_ws) {
+                const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
+                                          {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
+                launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
+                launch_mmha_paged(mp, max_len, st);
+                const SmallmDesc p3[2] = {{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl},
+                                          {mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}};
+                launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
+            }
+            else {
+                gemm(nrm, w.qkv, nullptr, 0, qkv, 3 * hl, H);
+                launch_mmha_paged(mp, max_len, st);
+                gemm(ctx, w.attn_out, nullptr, 0, att, H, hl);
+                gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, il, H);
+                gemm(mid, w.ffn2, nullptr, 0, ffn, H, il);
+            }
+            // (every slot's hidden state is recomputed from its token each step: the residual never aliases across steps,
+            // so the fp32-sum variant of the context decoder applies to all layers)
+            if (dual) {
+                const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
+                launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, (l > 0 && l < L - 1) ? 1 : 0, nx ? nx->ln1_g : nullptr,
+                                        nx ? nx->ln1_b : nullptr, nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H,
+                                        1e-5f, st);
+            }
+            else {
+                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, 1, (l > 0 && l < L - 1) ? 1 : 0, true, st);
+            }
+        }
+        if (B <= 4) {
+            launch_lm_head(x, e->lm_head, logits, B, V, H, V, st, e->final_g, e->final_b, 1e-5f);
+        }
+        else {
+            launch_layernorm(x, e->final_g, e->final_b, nrm, B, H, 1e-5f, true, st);
+            lm_head_dispatch(nrm, e->lm_head, logits, B, V, H, V, st);
+        }
+        SamplingParams sp{};
+        sp.logits = logits;
+        sp.B = B;
+        sp.V = V;
+        sp.max_input_len = 0;
+        sp.total_len = 1;
+        sp.end_id = e->cfg.end_id;
+        sp.input_lengths = d_zero;
+        sp.top_k = d_topk;
+        sp.top_p_topk = d_ptopk;
+        sp.top_p_topp = d_ptopp;
+        sp.temperature = d_temp;
+        sp.random_seed = d_seed;
+        sp.draw_counter = d_draws;
+        sp.apply_temperature = host_any_temperature ? 1 : 0;
+        sp.apply_repetition = 0;
+        sp.return_cum_log_probs = 1;
+        sp.output_ids = d_tok;  // "time-major [total, B]" with total = 1: the sampled token of slot b lands in d_tok[b]
+        sp.finished = d_fin;
+        sp.seq_len = d_len;     // + 1 per sampled token: the slot's length
+        sp.cum_log_probs = d_cum;
+        sp.pad_count = d_zero;
+        sp.state = d_state;     // step stays 0
+        sp.ws = samp_ws;
+        sp.max_top_k = host_max_top_k;
+        sp.any_top_p = host_any_top_p;
+        launch_dynamic_decode(sp, st, false);
+        std::vector<int>     tok(B);
+        std::vector<uint8_t> fin(B);
+        FTCF_HIP_CHECK(hipMemcpyAsync(tok.data(), d_tok, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(fin.data(), d_fin, (size_t)B, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        for (int si = 0; si < B; si++) {
+            Slot& s = slots[si];
+            if (!s.active) {
+                continue;
+            }
+            s.len += 1;
+            s.generated += 1;
+            const int done = (fin[si] || s.generated >= s.max_new) ? 1 : 0;
+            ev.push_back(Event{s.id, tok[si], done});
+            if (done) {
+                if (!fin[si]) {
+                    const uint8_t one8 = 1;
+                    FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                }
+                release(s);
+            }
+        }
+    }
+
+    int  host_max_top_k = 1, host_any_top_p = 0;
+    bool host_any_temperature = false;
+    std::vector<int>   slot_topk;
+    std::vector<float> slot_temp;
+
+    void step(std::vector<Event>& ev)
+    {
+        FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
+        if (slot_topk.empty()) {
+            slot_topk.assign(max_batch, 1);
+            slot_temp.assign(max_batch, 1.f);
+        }
+        // the running slots first (a request admitted in this iteration has its first token already)
+        bool any = false;
+        for (const Slot& s : slots) {
+            any |= s.active;
+        }
+        if (any) {
+            decode(ev);
+        }
+        for (int si = 0; si < max_batch && !waiting.empty(); si++) {
+            if (slots[si].active) {
+                continue;
+            }
+            const Request& r    = waiting.front();
+            const int      need = ((int)r.prompt.size() + r.max_new + P - 1) / P;
+            if ((int)free_pages.size() < need) {
+                break;  // FIFO: nobody overtakes the head of the queue
+            }
+            const int keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);
+            slot_topk[si]  = keff;
+            slot_temp[si]  = r.temperature;
+            admit(si, r, ev);
+            waiting.pop_front();
+        }
+        host_max_top_k = 1;
+        host_any_top_p = 0;
+        host_any_temperature = false;
+        for (int si = 0; si < max_batch; si++) {
+            if (slots[si].active) {
+                host_max_top_k = std::max(host_max_top_k, slot_topk[si]);
+                host_any_top_p |= (slot_topk[si] == 0);
+                host_any_temperature |= (slot_temp[si] != 1.f);
+            }
+        }
+    }
+};
+
+extern "C" int ftcf_batcher_create(ftcf_gptneox_t engine, int max_batch, int page_tokens, int num_pages, int max_seq_len,
+                                   ftcf_batcher_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(engine && out, "NULL argument");
+        require_device();
+        auto b = std::make_unique<ftcf_batcher>();
+        b->init(engine, max_batch, page_tokens, num_pages, max_seq_len);
+        *out = b.release();
+    });
+}
+extern "C" int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k,
+                                   float top_p, float temperature, unsigned long long seed, long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit(prompt_ids, prompt_len, max_new_tokens, top_k, top_p, temperature, (uint64_t)seed);
+    });
+}
+extern "C" int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_ids && tokens && finished && n_events, "NULL argument");
+        FTCF_CHECK_ARG(capacity >= 2 * b->max_batch, "event arrays must hold 2 * max_batch entries");
+        std::vector<ftcf_batcher::Event> ev;
+        b->step(ev);
+        *n_events = (int)ev.size();
+        for (size_t i = 0; i < ev.size(); i++) {
+            request_ids[i] = ev[i].id;
+            tokens[i]      = ev[i].token;
+            finished[i]    = ev[i].finished;
+        }
+    });
+}
+extern "C" int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        int run = 0;
+        for (const auto& s : b->slots) {
+            run += s.active ? 1 : 0;
+        }
+        if (waiting) {
+            *waiting = (int)b->waiting.size();
+        }
+        if (running) {
+            *running = run;
+        }
+        if (free_pages) {
+            *free_pages = (int)b->free_pages.size();
+        }
+    });
+}
+extern "C" int ftcf_batcher_destroy(ftcf_batcher_t b)
+{
+    return guarded([&] { delete b; });
 }

@@ -157,6 +157,22 @@ void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* 
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
                                 hipStream_t s, int cache_row_mult = 1);  // K/V of prompt row b live in cache row b * mult
 
+// paged decoder attention (continuous batching front end): per-slot page tables into a shared K/V pool
+struct MmhaPagedParams {
+    const f16*     qkv;       // [B, 3*Hl]
+    const f16*     qkv_bias;  // [3*Hl]
+    f16 *          kpool, *vpool;  // THIS layer's pool: [num_pages][nh][P][dh]
+    const int*     page_table;     // [B][max_pages]
+    const int*     len;            // [B] cached tokens of the slot (= position of the current token)
+    const uint8_t* finished;       // [B] 1: slot empty or finished (skipped)
+    int            B, nh, dh, rot, P, max_pages;
+    f16*           ctx;  // [B, Hl]
+};
+size_t mmha_paged_smem_bytes(int dh, int max_pages, int max_len);
+void   launch_mmha_paged(const MmhaPagedParams& p, int max_len, hipStream_t s);
+void   launch_scatter_kv_to_pages(const f16* kc, const f16* vc, f16* kpool, f16* vpool, const int* pages, int L, int nh, int dh,
+                                  int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s);
+
 // ---- fused attention + FFN1 weight stream : kernels_fused.hip ----
 void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8, int M, hipStream_t s);
 
@@ -323,7 +339,7 @@ void   launch_gather_tree_beam(int* output_ids, int* sequence_lengths, const int
                                const int* seq_len, const int* input_lengths, int B, int K, int max_input_len, int total,
                                int end_id, hipStream_t s);
 size_t sampling_workspace_bytes(int B, int V);
-void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s);
+void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish = true);
 void   launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
                           uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
                           int s_max, hipStream_t s, int beam_width = 1);

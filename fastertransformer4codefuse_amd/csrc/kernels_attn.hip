@@ -548,4 +548,205 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Paged decoder attention (the continuous-batching front end, engine.hip `ftcf_batcher`): the K/V of a
+// sequence live in fixed-size pages of a pool shared by all sequences, [page][head][P tokens][dh], found through the
+// sequence's page table.  Same arithmetic as mmha_partial with one split (attn_device.cuh): half q/k/v + bias, NeoX rotary
+// at position = number of cached tokens, fp32 scores, exp against the row maximum, fp32 PV, one normalisation with the
+// reference's +1e-6 (decoder_masked_multihead_attention_template.hpp:1632).  One workgroup per (head, slot); a sequence's
+// length is its own (no padding, no masks: a slot's tokens are dense from position 0).
+// ---------------------------------------------------------------------------------------------------------------
+template<int DH>
+__global__ __launch_bounds__(256) void k_mmha_paged(const MmhaPagedParams p)
+{
+    constexpr int LPK = DH / 8;    // lanes per key/value row (16 B each)
+    constexpr int KPI = 64 / LPK;  // rows per wave-load
+    extern __shared__ __attribute__((aligned(16))) char smem_pg[];
+    __shared__ float s_red[16];
+    const int h = blockIdx.x, b = blockIdx.y;
+    if (p.finished[b]) {
+        return;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const int tl  = p.len[b];  // cached tokens = position of the current one
+    f16*      s_q = reinterpret_cast<f16*>(smem_pg);
+    f16*      s_k = s_q + DH;
+    f16*      s_v = s_k + DH;
+    float*    s_o = reinterpret_cast<float*>(s_v + DH);  // [4][DH]
+    int*      s_pt = reinterpret_cast<int*>(s_o + 4 * DH);  // [max_pages]
+    float*    s_p = reinterpret_cast<float*>(s_pt + p.max_pages);  // [tl + 1]
+    const int hl  = p.nh * DH;
+    for (int i = threadIdx.x; i < p.max_pages; i += 256) {
+        s_pt[i] = p.page_table[(size_t)b * p.max_pages + i];
+    }
+    if (threadIdx.x < DH) {
+        const int    d    = threadIdx.x;
+        const size_t base = (size_t)b * 3 * hl + h * DH + d;
+        s_q[d] = p.qkv[base] + p.qkv_bias[h * DH + d];
+        s_k[d] = p.qkv[base + hl] + p.qkv_bias[hl + h * DH + d];
+        s_v[d] = p.qkv[base + 2 * hl] + p.qkv_bias[2 * hl + h * DH + d];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.rot / 2) {
+        float cs, sn;
+        rotary_coef(threadIdx.x, p.rot, tl, cs, sn);
+        const int j = threadIdx.x, j2 = j + p.rot / 2;
+        f16       a = s_q[j], c = s_q[j2];
+        rotary_apply(a, c, cs, sn);
+        s_q[j]  = a;
+        s_q[j2] = c;
+        f16 ka = s_k[j], kc = s_k[j2];
+        rotary_apply(ka, kc, cs, sn);
+        s_k[j]  = ka;
+        s_k[j2] = kc;
+    }
+    __syncthreads();
+    const size_t page_elems = (size_t)p.nh * p.P * DH;
+    auto row_ptr = [&](const f16* pool, const int t) -> const f16* {
+        return pool + (size_t)s_pt[t / p.P] * page_elems + ((size_t)h * p.P + (t % p.P)) * DH;
+    };
+    if (threadIdx.x < DH) {  // append the current token (its page was allocated by the scheduler)
+        f16* kd = const_cast<f16*>(row_ptr(p.kpool, tl));
+        f16* vd = const_cast<f16*>(row_ptr(p.vpool, tl));
+        kd[threadIdx.x] = s_k[threadIdx.x];
+        vd[threadIdx.x] = s_v[threadIdx.x];
+    }
+    const float inv_sqrt_dh = rsqrtf((float)DH);
+    const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+    float       lmax        = -INFINITY;
+    for (int t0 = 0; t0 < tl; t0 += 4 * KPI) {
+        const int   t  = t0 + wid * KPI + grp;
+        const int   tc = t < tl ? t : tl - 1;
+        const f16x8 kv = *reinterpret_cast<const f16x8*>(row_ptr(p.kpool, tc) + sub * 8);
+        float       a  = 0.f;
+        a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
+        a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
+        a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
+        a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
+        a              = group_sum(a, LPK) * inv_sqrt_dh;
+        if (t < tl && sub == 0) {
+            s_p[t] = a;
+            lmax   = fmaxf(lmax, a);
+        }
+    }
+    if (wid == 0) {  // current token from LDS
+        float a = 0.f;
+        if (lane < LPK) {
+            const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
+            const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
+            a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
+            a              = dot2(f16x2{q8[2], q8[3]}, f16x2{kv[2], kv[3]}, a);
+            a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
+            a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
+        }
+        a = wave_sum(a) * inv_sqrt_dh;
+        if (lane == 0) {
+            s_p[tl] = a;
+            lmax    = fmaxf(lmax, a);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) {
+        s_red[wid] = lmax;
+    }
+    __syncthreads();
+    const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float       lsum = 0.f;
+    for (int i = threadIdx.x; i <= tl; i += 256) {
+        const float e = __expf(s_p[i] - m);
+        s_p[i]        = e;
+        lsum += e;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) {
+        s_red[4 + wid] = lsum;
+    }
+    __syncthreads();
+    const float inv = 1.f / (((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) + 1.e-6f);
+    // PV: lane (grp, sub) accumulates dims sub*8 .. +7 over its keys, then the key groups of a wave and the waves are added
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < tl; t0 += 4 * KPI) {
+        const int   t  = t0 + wid * KPI + grp;
+        const int   tc = t < tl ? t : tl - 1;
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(row_ptr(p.vpool, tc) + sub * 8);
+        const float w  = t < tl ? s_p[t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            o[j] = fmaf(w, (float)vv[j], o[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        for (int off = LPK; off < 64; off <<= 1) {
+            o[j] += __shfl_xor(o[j], off, 64);
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            s_o[wid * DH + sub * 8 + j] = o[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        const int   d = threadIdx.x;
+        const float v = ((s_o[d] + s_o[DH + d]) + (s_o[2 * DH + d] + s_o[3 * DH + d])) + s_p[tl] * (float)s_v[d];
+        p.ctx[(size_t)b * hl + h * DH + d] = (f16)(v * inv);
+    }
+}
+
+size_t mmha_paged_smem_bytes(int dh, int max_pages, int max_len)
+{
+    return (size_t)3 * dh * 2 + (size_t)4 * dh * 4 + (size_t)max_pages * 4 + (size_t)(max_len + 2) * 4;
+}
+
+void launch_mmha_paged(const MmhaPagedParams& p, int max_len, hipStream_t s)
+{
+    FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
+    FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh, "rotary_embedding_dim must be even and <= size_per_head");
+    const size_t smem = mmha_paged_smem_bytes(p.dh, p.max_pages, max_len);
+    FTCF_CHECK_ARG(smem <= 64 * 1024, "paged attention keeps a sequence's scores in LDS: max sequence length <= ~15000");
+    dim3 grid(p.nh, p.B);
+    if (p.dh == 128) {
+        hipLaunchKernelGGL((k_mmha_paged<128>), grid, dim3(256), smem, s, p);
+    }
+    else {
+        hipLaunchKernelGGL((k_mmha_paged<64>), grid, dim3(256), smem, s, p);
+    }
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
+// K/V of a freshly prefilled prompt: contiguous engine cache [L][1 row][nh][s_max][dh] -> the sequence's pages of every layer
+__global__ void k_scatter_kv_to_pages(const f16* __restrict__ kc, const f16* __restrict__ vc, f16* kpool, f16* vpool,
+                                      const int* __restrict__ pages, int L, int nh, int dh, int s_max, int S, int P,
+                                      size_t pool_layer_elems)
+{
+    // one 16-byte piece per thread: (layer, head, token, piece)
+    const int    ppr   = dh / 8;
+    const size_t total = (size_t)L * nh * S * ppr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int    pc = (int)(i % ppr);
+        size_t       r  = i / ppr;
+        const int    t  = (int)(r % S);
+        r /= S;
+        const int    h = (int)(r % nh), l = (int)(r / nh);
+        const size_t src = (((size_t)l * nh + h) * s_max + t) * dh + pc * 8;
+        const size_t dst = (size_t)l * pool_layer_elems + ((size_t)pages[t / P] * nh + h) * P * dh + (size_t)(t % P) * dh + pc * 8;
+        *reinterpret_cast<u32x4*>(kpool + dst) = *reinterpret_cast<const u32x4*>(kc + src);
+        *reinterpret_cast<u32x4*>(vpool + dst) = *reinterpret_cast<const u32x4*>(vc + src);
+    }
+}
+void launch_scatter_kv_to_pages(const f16* kc, const f16* vc, f16* kpool, f16* vpool, const int* pages, int L, int nh, int dh,
+                                int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s)
+{
+    const size_t total = (size_t)L * nh * S * (dh / 8);
+    if (total == 0) {
+        return;
+    }
+    hipLaunchKernelGGL(k_scatter_kv_to_pages, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, kc, vc,
+                       kpool, vpool, pages, L, nh, dh, s_max, S, P, pool_layer_elems);
+    FTCF_HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace ftcf

@@ -863,7 +863,7 @@ size_t sampling_workspace_bytes(int B, int V)
            + (size_t)B * 2 * nv * sizeof(float);
 }
 
-void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
+void launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish)
 {
     float* cand_v = reinterpret_cast<float*>(p.ws);
     int*   cand_i = reinterpret_cast<int*>(cand_v + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX);
@@ -902,7 +902,9 @@ void launch_dynamic_decode(const SamplingParams& p, hipStream_t s)
         }
     }
     hipLaunchKernelGGL(k_sample, dim3(p.B), dim3(256), sample_smem, s, p, cand_v, cand_i);
-    hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
+    if (finish) {  // (the continuous-batching front end keeps its own per-slot bookkeeping on the host)
+        hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
+    }
     FTCF_HIP_CHECK(hipGetLastError());
 }
 

@@ -211,6 +211,25 @@ int ftcf_gptneox_get_stats(ftcf_gptneox_t h, ftcf_forward_stats* stats);
 int ftcf_gptneox_set_profiling(ftcf_gptneox_t h, int enabled);
 int ftcf_gptneox_destroy(ftcf_gptneox_t h);
 
+
+/* ---- continuous batching over a paged K/V cache (no counterpart in the reference, whose serving layer
+ * triton_backend/gptneox/ allocates the cache per request, models/gptneox/GptNeoX.cc:84-156) --------------------------------
+ * A batcher borrows an engine (which must outlive it and must not run a request of its own while a batcher call is in
+ * progress).  K/V live in `num_pages` pages of `page_tokens` tokens shared by all sequences; up to `max_batch` sequences
+ * decode together; waiting requests are admitted, in order, as soon as a slot and the pages for prompt + max_new_tokens are
+ * free.  fp16 / int8 engines, parallel residual, tensor_para_size 1, beam_width 1; sampling: top_k / top_p / temperature. */
+typedef struct ftcf_batcher* ftcf_batcher_t;
+int ftcf_batcher_create(ftcf_gptneox_t engine, int max_batch, int page_tokens, int num_pages, int max_seq_len,
+                        ftcf_batcher_t* out);
+/* prompt_ids: HOST array.  (top_k, top_p) = (0, 0) is greedy, as in the reference's sampling layer. */
+int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k, float top_p,
+                        float temperature, unsigned long long seed, long* request_id);
+/* One scheduler iteration: one decode step for the running sequences, then admissions (prefill + first token).  Returns one
+ * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch. */
+int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events);
+int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages);
+int ftcf_batcher_destroy(ftcf_batcher_t b);
+
 #ifdef __cplusplus
 }
 #endif

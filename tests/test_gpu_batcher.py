@@ -1,0 +1,157 @@
+"""-m gpu: continuous batching over the paged K/V cache (include/ftcf.h `ftcf_batcher_*`).
+
+The oracle for a batcher is the engine itself: whatever order requests arrive in, however they share decode steps and pages,
+every request must produce what `GptNeoXOp.forward` produces for it alone (greedy: token exact on the tiny model, up to
+near ties on the int8 1024-hidden model), and the pool must get all its pages back."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_tiny, random_model
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+MID = dict(head_num=8, size_per_head=64, inter_size=2048, num_layer=3, vocab_size=2048, rotary_dim=16, start_id=0, end_id=2)
+
+
+@pytest.fixture(scope="module")
+def gh():
+    from tests import gpu_helpers
+    from fastertransformer4codefuse_amd import capi
+    capi.require_gpu()
+    return gpu_helpers
+
+
+def _alone(gh, op, prompt, n_new, V, end_id):
+    """Tokens the engine generates for this prompt by itself (greedy), cut at end_id like the batcher's stream."""
+    r = gh.run_op(op, np.asarray(prompt, np.int32)[None, :], [len(prompt)], n_new, V, top_k=1)
+    toks = r["output_ids"][0, len(prompt):].tolist()
+    out = []
+    for t in toks:
+        out.append(t)
+        if t == end_id:
+            break
+    return out, r["logits"][:, 0]
+
+
+def _drain(cb, arrivals):
+    """arrivals: {iteration: [(prompt, max_new), ...]} -> {request index: tokens}, iterations used."""
+    got, ids, it, k = {}, {}, 0, 0
+    pending = dict(arrivals)
+    while pending or cb.busy():
+        for prompt, max_new in pending.pop(it, []):
+            ids[cb.submit(prompt, max_new)] = k
+            k += 1
+        for rid, tok, fin in cb.step():
+            got.setdefault(ids[rid], []).append(tok)
+        it += 1
+        assert it < 10000
+    return got, it
+
+
+def test_tiny_requests_arriving_over_time_match_the_engine_alone(gh):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(3)
+    prompts = [z["prompt"].tolist(), z["prompt_b"].tolist(), z["prompt"][:5].tolist(), z["prompt_1"].tolist(),
+               rng.randint(3, V, size=23).tolist(), rng.randint(3, V, size=9).tolist(), z["prompt"][::-1].tolist()]
+    new = [8, 6, 12, 5, 10, 3, 7]
+    ref = [_alone(gh, op, p, n, V, end_id)[0] for p, n in zip(prompts, new)]
+    # 3 slots, 8-token pages: more requests than slots, arrivals while others are decoding
+    cb = ContinuousBatcher(op, max_batch=3, page_tokens=8, num_pages=24, max_seq_len=64)
+    free0 = cb.status()["free_pages"]
+    got, _ = _drain(cb, {0: [(prompts[0], new[0]), (prompts[1], new[1])], 2: [(prompts[2], new[2]), (prompts[3], new[3])],
+                         3: [(prompts[4], new[4])], 9: [(prompts[5], new[5]), (prompts[6], new[6])]})
+    for i in range(len(prompts)):
+        assert got[i] == ref[i], (i, got[i], ref[i])
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}  # every page came back
+    # the engine is still usable for plain requests afterwards, and the batcher for a second wave
+    assert _alone(gh, op, prompts[0], new[0], V, end_id)[0] == ref[0]
+    got2, _ = _drain(cb, {0: [(prompts[4], new[4])]})
+    assert got2[0] == ref[4]
+
+
+def test_requests_wait_for_pages_and_all_finish(gh):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    prompts = [z["prompt"].tolist(), z["prompt_b"].tolist(), z["prompt"][:7].tolist(), z["prompt"][3:].tolist()]
+    new = [9, 9, 9, 9]
+    ref = [_alone(gh, op, p, n, V, end_id)[0] for p, n in zip(prompts, new)]
+    # 4 slots but only 7 pages of 8 tokens: a 16 + 9 token request takes 4 of them -> the queue has to wait for pages
+    cb = ContinuousBatcher(op, max_batch=4, page_tokens=8, num_pages=7, max_seq_len=32)
+    got, iters = _drain(cb, {0: [(p, n) for p, n in zip(prompts, new)]})
+    for i in range(4):
+        assert got[i] == ref[i], i
+    assert iters > 9  # not everybody could run together
+    assert cb.status()["free_pages"] == 7
+    with pytest.raises(RuntimeError):
+        cb.submit(list(range(3, 40)), 4)  # longer than max_seq_len
+
+
+def test_end_id_stops_a_sequence_and_frees_its_slot(gh):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V = cfg["vocab_size"]
+    ref_tokens = z["hf_tokens"].tolist()
+    cfg2 = dict(cfg, end_id=int(ref_tokens[3]))  # the 4th generated token of the golden prompt is now the end token
+    op = gh.make_op(cfg2, w)
+    alone, _ = _alone(gh, op, z["prompt"].tolist(), 8, V, cfg2["end_id"])
+    assert alone[-1] == cfg2["end_id"] and len(alone) <= 4
+    cb = ContinuousBatcher(op, max_batch=2, page_tokens=16, num_pages=8, max_seq_len=48)
+    got, _ = _drain(cb, {0: [(z["prompt"].tolist(), 8), (z["prompt_b"].tolist(), 8)]})
+    assert got[0] == alone
+    assert got[1] == _alone(gh, op, z["prompt_b"].tolist(), 8, V, cfg2["end_id"])[0]
+
+
+@pytest.mark.parametrize("int8_mode,max_batch", [(0, 2), (1, 6), (1, 20)])
+def test_mid_model_batches_follow_the_engine(gh, int8_mode, max_batch):
+    """1024-hidden model: max_batch 2 (GEMV forms), 6 (burst GEMMs with the in-launch split-K reduction), 20 (tiled GEMM)."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg = MID
+    w = random_model(cfg, seed=17)
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w, int8_mode=int8_mode)
+    rng = np.random.RandomState(9)
+    n_req = max_batch + 3
+    prompts = [rng.randint(3, V, size=int(rng.randint(4, 60))).tolist() for _ in range(n_req)]
+    new = [int(rng.randint(2, 12)) for _ in range(n_req)]
+    cb = ContinuousBatcher(op, max_batch=max_batch, page_tokens=16, num_pages=6 * max_batch, max_seq_len=96)
+    arrivals = {0: [(prompts[i], new[i]) for i in range(max_batch)], 4: [(prompts[i], new[i]) for i in range(max_batch, n_req)]}
+    got, _ = _drain(cb, arrivals)
+    for i in range(n_req):
+        alone, logits = _alone(gh, op, prompts[i], new[i], V, end_id)
+        for t, (a, b) in enumerate(zip(got[i], alone)):
+            if a != b:  # the paged attention sums in another order than the split-KV kernel: only a near tie may flip a token
+                top2 = np.sort(logits[t])[-2:]
+                assert top2[1] - top2[0] <= 1e-2 * np.abs(logits[t]).max(), (i, t)
+                break
+        else:
+            assert len(got[i]) == len(alone)
+    assert cb.status()["free_pages"] == 6 * max_batch
+
+
+def test_sampling_parameters_run_through_the_batcher(gh):
+    """top-k / top-p / temperature rows together in one batch: tokens are valid, sequences end, pages come back."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    op = gh.make_op(cfg, w)
+    cb = ContinuousBatcher(op, max_batch=4, page_tokens=8, num_pages=16, max_seq_len=40)
+    ids = [cb.submit(z["prompt"].tolist(), 6, top_k=8, temperature=0.8, seed=1),
+           cb.submit(z["prompt_b"].tolist(), 6, top_k=0, top_p=0.7, seed=2),
+           cb.submit(z["prompt"][:5].tolist(), 6, top_k=40, top_p=0.5, temperature=1.3, seed=3),
+           cb.submit(z["prompt_1"].tolist(), 6)]
+    out = cb.run_all()
+    assert sorted(out) == sorted(ids)
+    for rid in ids:
+        assert 1 <= len(out[rid]) <= 6 and all(0 <= t < cfg["vocab_size"] for t in out[rid])
+    # same seeds, same arrival order -> the same tokens again
+    ids2 = [cb.submit(z["prompt"].tolist(), 6, top_k=8, temperature=0.8, seed=1),
+            cb.submit(z["prompt_b"].tolist(), 6, top_k=0, top_p=0.7, seed=2),
+            cb.submit(z["prompt"][:5].tolist(), 6, top_k=40, top_p=0.5, temperature=1.3, seed=3),
+            cb.submit(z["prompt_1"].tolist(), 6)]
+    out2 = cb.run_all()
+    assert [out2[i] for i in ids2] == [out[i] for i in ids]
+    assert cb.status()["free_pages"] == 16
