@@ -2545,10 +2545,10 @@ struct ftcf_batcher {
         d_draws = dmalloc<uint64_t>(B);
         d_state = dmalloc<DecodeState>(1);
         d_gstate = dmalloc<DecodeState>(1);
-        d_prompt = dmalloc<int>(max_seq_len);
-        d_plen = dmalloc<int>(1);
-        d_pout = dmalloc<int>(max_seq_len + 1);
-        d_pseq = dmalloc<int>(1);
+        d_prompt = dmalloc<int>(B * max_seq_len);
+        d_plen = dmalloc<int>(B);
+        d_pout = dmalloc<int>(B * (max_seq_len + 1));
+        d_pseq = dmalloc<int>(B);
         d_pages_tmp = dmalloc<int>(max_pages);
         samp_ws = dmalloc<char>(sampling_workspace_bytes(max_batch, V), false);
         if (max_batch > 4 && max_batch <= 16) {
@@ -2601,77 +2601,99 @@ struct ftcf_batcher {
         s.active = false;
     }
 
-    // prompt -> engine context path (+ first token) -> pages of slot `si`
-    void admit(int si, const Request& r, std::vector<Event>& ev)
+    // prompts -> ONE ragged batch through the engine's context path (+ first tokens) -> pages of their slots
+    void admit(const std::vector<int>& sis, const std::vector<Request>& rs, std::vector<Event>& ev)
     {
         Range        rg("ftcf.batcher.admit");
         hipStream_t  st = e->stream;
-        const int    S = (int)r.prompt.size();
-        Slot&        s = slots[si];
-        const int    need = (S + r.max_new + P - 1) / P;
-        s.pages.clear();
-        for (int i = 0; i < need; i++) {
-            s.pages.push_back(free_pages.back());
-            free_pages.pop_back();
+        const int    n  = (int)sis.size();
+        int          S  = 0;
+        for (const Request& r : rs) {
+            S = std::max(S, (int)r.prompt.size());
         }
-        FTCF_HIP_CHECK(hipMemcpy(d_prompt, r.prompt.data(), (size_t)S * 4, hipMemcpyHostToDevice));
-        FTCF_HIP_CHECK(hipMemcpy(d_plen, &S, 4, hipMemcpyHostToDevice));
+        std::vector<int>      ids((size_t)n * S, e->cfg.end_id), lens(n), topk(n);
+        std::vector<float>    topp(n), temp(n);
+        std::vector<uint64_t> seed(n);
+        for (int i = 0; i < n; i++) {
+            const Request& r = rs[i];
+            std::copy(r.prompt.begin(), r.prompt.end(), ids.begin() + (size_t)i * S);
+            lens[i] = (int)r.prompt.size();
+            topk[i] = r.top_k;
+            topp[i] = r.top_p;
+            temp[i] = r.temperature;
+            seed[i] = r.seed;
+            Slot&     s = slots[sis[i]];
+            const int need = (lens[i] + r.max_new + P - 1) / P;
+            s.pages.clear();
+            for (int k = 0; k < need; k++) {
+                s.pages.push_back(free_pages.back());
+                free_pages.pop_back();
+            }
+        }
+        FTCF_HIP_CHECK(hipMemcpy(d_prompt, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+        FTCF_HIP_CHECK(hipMemcpy(d_plen, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
         ftcf_forward_args a{};
         a.input_ids = d_prompt;
         a.input_lengths = d_plen;
-        a.batch_size = 1;
+        a.batch_size = n;
         a.max_input_len = S;
         a.output_len = 1;
         a.beam_width = 1;
-        // the engine's own rule for (top_k, top_p) = (0, 0) is greedy; pass the request's values through
-        a.top_k = &r.top_k;
-        a.n_top_k = 1;
-        a.top_p = &r.top_p;
-        a.n_top_p = 1;
-        a.temperature = &r.temperature;
-        a.n_temperature = 1;
-        a.random_seed = &r.seed;
-        a.n_random_seed = 1;
+        a.top_k = topk.data();
+        a.n_top_k = n;
+        a.top_p = topp.data();
+        a.n_top_p = n;
+        a.temperature = temp.data();
+        a.n_temperature = n;
+        a.random_seed = seed.data();
+        a.n_random_seed = n;
         a.output_ids = d_pout;
         a.sequence_lengths = d_pseq;
-        e->forward(a);  // host synchronous: K/V of positions [0, S) are in the engine's cache [L][1][nh][S + 1][dh]
-        int first = 0;
-        FTCF_HIP_CHECK(hipMemcpy(&first, d_pout + S, 4, hipMemcpyDeviceToHost));
-        std::vector<int> row(max_pages, 0);
-        for (size_t i = 0; i < s.pages.size(); i++) {
-            row[i] = s.pages[i];
-        }
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_pt + (size_t)si * max_pages, row.data(), (size_t)max_pages * 4, hipMemcpyHostToDevice, st));
-        launch_scatter_kv_to_pages(e->k_cache, e->v_cache, kpool, vpool, d_pt + (size_t)si * max_pages, e->L, e->nhl, e->dh, S + 1,
-                                   S, P, pool_layer_elems, st);
-        // per-slot state of the decode steps
-        const int      keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);  // BaseSamplingLayer: (0, 0) = greedy
-        const float    ptk = (r.top_p == 0.f) ? 1.f : r.top_p;
-        const uint8_t  zero8 = 0;
-        const uint64_t one = 1;
-        const float    zf = 0.f;
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, &S, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_tok + si, &first, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_topk + si, &keff, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopk + si, &ptk, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopp + si, &r.top_p, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_temp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_seed + si, &r.seed, 8, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_draws + si, &one, 8, hipMemcpyHostToDevice, st));  // draw 0 went to the first token
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, &zf, 4, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, &zero8, 1, hipMemcpyHostToDevice, st));
-        FTCF_HIP_CHECK(hipStreamSynchronize(st));  // the host temporaries above die here
-        s.active = true;
-        s.id = r.id;
-        s.len = S;
-        s.generated = 1;
-        s.max_new = r.max_new;
-        const int done = (first == e->cfg.end_id || s.generated >= s.max_new) ? 1 : 0;
-        ev.push_back(Event{r.id, first, done});
-        if (done) {
-            const uint8_t one8 = 1;
-            FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
-            release(s);
+        e->forward(a);  // host synchronous: K/V of row i, positions [0, len_i), are in the engine's cache [L][n][nh][S + 1][dh]
+        std::vector<int> out((size_t)n * (S + 1));
+        FTCF_HIP_CHECK(hipMemcpy(out.data(), d_pout, out.size() * 4, hipMemcpyDeviceToHost));
+        const size_t row_kv = (size_t)e->nhl * (S + 1) * e->dh;  // one row of one layer of the engine's cache
+        for (int i = 0; i < n; i++) {
+            const Request& r  = rs[i];
+            const int      si = sis[i], len = lens[i];
+            Slot&          s  = slots[si];
+            // the engine's output rows are compacted (prompt, then the generated tokens: invokeGatherTree removes the padding)
+            const int        first = out[(size_t)i * (S + 1) + len];
+            std::vector<int> row(max_pages, 0);
+            std::copy(s.pages.begin(), s.pages.end(), row.begin());
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_pt + (size_t)si * max_pages, row.data(), (size_t)max_pages * 4, hipMemcpyHostToDevice, st));
+            launch_scatter_kv_to_pages(e->k_cache + (size_t)i * row_kv, e->v_cache + (size_t)i * row_kv, kpool, vpool,
+                                       d_pt + (size_t)si * max_pages, e->L, e->nhl, e->dh, S + 1, len, P, pool_layer_elems, st,
+                                       (size_t)n * row_kv);
+            // per-slot state of the decode steps
+            const int      keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);  // BaseSamplingLayer: (0, 0) = greedy
+            const float    ptk = (r.top_p == 0.f) ? 1.f : r.top_p;
+            const uint8_t  zero8 = 0;
+            const uint64_t one = 1;
+            const float    zf = 0.f;
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, &len, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_tok + si, &first, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_topk + si, &keff, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopk + si, &ptk, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopp + si, &r.top_p, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_temp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_seed + si, &r.seed, 8, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_draws + si, &one, 8, hipMemcpyHostToDevice, st));  // draw 0 went to the first token
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, &zf, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, &zero8, 1, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipStreamSynchronize(st));  // the host temporaries above die here
+            s.active = true;
+            s.id = r.id;
+            s.len = len;
+            s.generated = 1;
+            s.max_new = r.max_new;
+            const int done = (first == e->cfg.end_id || s.generated >= s.max_new) ? 1 : 0;
+            ev.push_back(Event{r.id, first, done});
+            if (done) {
+                const uint8_t one8 = 1;
+                FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                release(s);
+            }
         }
     }
 
@@ -2716,7 +2738,25 @@ struct ftcf_batcher {
             mp.P = P;
             mp.max_pages = max_pages;
             mp.ctx = ctx;
-            if (smallm_ws) {
+            if (smallm_ws && e->decode_branches && e->side) {
+                // the attention branch and the FFN branch on two streams, as the engine's batched decode
+                const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(B, 3 * hl, H, int8),
+                             o_out = o_f1 + gemm_smallm_workspace_bytes(B, il, H, int8),
+                             o_f2  = o_out + gemm_smallm_workspace_bytes(B, H, hl, int8);
+                auto one = [&](const SmallmDesc& d, size_t off, hipStream_t s2) {
+                    launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, B, int8, s2, &d_gstate->step, &smallm_seq, off);
+                };
+                FTCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                one(SmallmDesc{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H}, o_qkv, st);
+                one(SmallmDesc{nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}, o_f1, e->side);
+                launch_mmha_paged(mp, max_len, st);
+                one(SmallmDesc{mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}, o_f2, e->side);
+                one(SmallmDesc{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl}, o_out, st);
+                FTCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
+            else if (smallm_ws) {
                 const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
                                           {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
                 launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
@@ -2822,20 +2862,29 @@ struct ftcf_batcher {
         if (any) {
             decode(ev);
         }
+        // admissions: as many of the queue's head requests as there are free slots and pages, prefilled as ONE ragged batch
+        std::vector<int>     sis;
+        std::vector<Request> rs;
+        int                  pages_left = (int)free_pages.size();
         for (int si = 0; si < max_batch && !waiting.empty(); si++) {
             if (slots[si].active) {
                 continue;
             }
             const Request& r    = waiting.front();
             const int      need = ((int)r.prompt.size() + r.max_new + P - 1) / P;
-            if ((int)free_pages.size() < need) {
+            if (pages_left < need) {
                 break;  // FIFO: nobody overtakes the head of the queue
             }
+            pages_left -= need;
             const int keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);
             slot_topk[si]  = keff;
             slot_temp[si]  = r.temperature;
-            admit(si, r, ev);
+            sis.push_back(si);
+            rs.push_back(std::move(waiting.front()));
             waiting.pop_front();
+        }
+        if (!sis.empty()) {
+            admit(sis, rs, ev);
         }
         host_max_top_k = 1;
         host_any_top_p = 0;

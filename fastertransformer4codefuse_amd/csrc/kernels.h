@@ -171,7 +171,7 @@ struct MmhaPagedParams {
 size_t mmha_paged_smem_bytes(int dh, int max_pages, int max_len);
 void   launch_mmha_paged(const MmhaPagedParams& p, int max_len, hipStream_t s);
 void   launch_scatter_kv_to_pages(const f16* kc, const f16* vc, f16* kpool, f16* vpool, const int* pages, int L, int nh, int dh,
-                                  int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s);
+                                  int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s, size_t src_layer_elems = 0);
 
 // ---- fused attention + FFN1 weight stream : kernels_fused.hip ----
 void launch_mmha_ln_gemv(const MmhaParams& ap, const LnGemvParams& gp, bool int8, int M, hipStream_t s);

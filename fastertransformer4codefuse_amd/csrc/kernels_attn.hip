@@ -717,10 +717,11 @@ void launch_mmha_paged(const MmhaPagedParams& p, int max_len, hipStream_t s)
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
-// K/V of a freshly prefilled prompt: contiguous engine cache [L][1 row][nh][s_max][dh] -> the sequence's pages of every layer
+// K/V of a freshly prefilled prompt: one row of the engine cache [L][rows][nh][s_max][dh] (kc / vc point at the row in layer 0,
+// src_layer_elems = rows * nh * s_max * dh) -> the sequence's pages of every layer
 __global__ void k_scatter_kv_to_pages(const f16* __restrict__ kc, const f16* __restrict__ vc, f16* kpool, f16* vpool,
                                       const int* __restrict__ pages, int L, int nh, int dh, int s_max, int S, int P,
-                                      size_t pool_layer_elems)
+                                      size_t pool_layer_elems, size_t src_layer_elems)
 {
     // one 16-byte piece per thread: (layer, head, token, piece)
     const int    ppr   = dh / 8;
@@ -731,21 +732,24 @@ __global__ void k_scatter_kv_to_pages(const f16* __restrict__ kc, const f16* __r
         const int    t  = (int)(r % S);
         r /= S;
         const int    h = (int)(r % nh), l = (int)(r / nh);
-        const size_t src = (((size_t)l * nh + h) * s_max + t) * dh + pc * 8;
+        const size_t src = (size_t)l * src_layer_elems + ((size_t)h * s_max + t) * dh + pc * 8;
         const size_t dst = (size_t)l * pool_layer_elems + ((size_t)pages[t / P] * nh + h) * P * dh + (size_t)(t % P) * dh + pc * 8;
         *reinterpret_cast<u32x4*>(kpool + dst) = *reinterpret_cast<const u32x4*>(kc + src);
         *reinterpret_cast<u32x4*>(vpool + dst) = *reinterpret_cast<const u32x4*>(vc + src);
     }
 }
 void launch_scatter_kv_to_pages(const f16* kc, const f16* vc, f16* kpool, f16* vpool, const int* pages, int L, int nh, int dh,
-                                int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s)
+                                int s_max, int S, int P, size_t pool_layer_elems, hipStream_t s, size_t src_layer_elems)
 {
+    if (src_layer_elems == 0) {
+        src_layer_elems = (size_t)nh * s_max * dh;  // a one-row cache
+    }
     const size_t total = (size_t)L * nh * S * (dh / 8);
     if (total == 0) {
         return;
     }
     hipLaunchKernelGGL(k_scatter_kv_to_pages, dim3((int)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, s, kc, vc,
-                       kpool, vpool, pages, L, nh, dh, s_max, S, P, pool_layer_elems);
+                       kpool, vpool, pages, L, nh, dh, s_max, S, P, pool_layer_elems, src_layer_elems);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
