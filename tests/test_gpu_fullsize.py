@@ -375,3 +375,40 @@ def test_full_size_tensor_parallel_tp8_bs16(full):
     for r in range(1, 8):
         assert np.array_equal(res[r][0], res[0][0])
     _close(t1, l1, res[0][0], res[0][1], S, 5e-3, "tp8 bs16")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The continuous-batching front end at full size: CodeFuse-13B int8, 6 slots (burst GEMMs, paged attention, two streams),
+# requests arriving while others decode -- each must reproduce what the engine generates for it alone.
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_continuous_batching_follows_the_engine(full):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    a = full[0]
+    V = a.vocab
+    op = _op(full)
+    g = torch.Generator().manual_seed(49)
+    lens, new = [200, 256, 131, 64, 256, 17, 240, 99], [6, 5, 6, 4, 6, 6, 3, 5]
+    prompts = [torch.randint(3, V, (n,), generator=g, dtype=torch.int32) for n in lens]
+    alone = []
+    for p, n in zip(prompts, new):
+        t, l = _run(op, p[None, :].cuda(), n, V)
+        alone.append((t[0, len(p):].tolist(), l[:, 0]))
+    cb = ContinuousBatcher(op, max_batch=6, page_tokens=64, num_pages=6 * 5, max_seq_len=320)
+    ids, got, it = {}, {}, 0
+    arrivals = {0: [0, 1, 2, 3], 2: [4, 5], 3: [6, 7]}
+    while arrivals or cb.busy():
+        for i in arrivals.pop(it, []):
+            ids[cb.submit(prompts[i].tolist(), new[i])] = i
+        for rid, tok, fin in cb.step():
+            got.setdefault(ids[rid], []).append(tok)
+        it += 1
+        assert it < 200
+    for i in range(len(prompts)):
+        ref, logits = alone[i]
+        assert len(got[i]) == len(ref)
+        for t, (x, y) in enumerate(zip(got[i], ref)):
+            if x != y:  # another summation order in the paged attention / the batched GEMMs: only a near tie may flip a token
+                top2 = np.sort(logits[t])[-2:]
+                assert top2[1] - top2[0] <= 1e-2 * np.abs(logits[t]).max(), (i, t)
+                break
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": 30}
