@@ -873,6 +873,8 @@ struct ftcf_gptneox {
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
     std::vector<void*>        owned;  // tiled fp16 copies (int8_mode == 0)
+    void*                     bounce = nullptr;  // FTCF_FP16_RETILE_IN_PLACE: staging of one matrix during create()
+    size_t                    bounce_bytes = 0;
 
     DeviceBuffer arena;
     // decode / state views (valid after plan())
@@ -2275,11 +2277,30 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
                               {4, (size_t)hl, (size_t)H, &lw.attn_out},
                               {6, (size_t)H, (size_t)il, &lw.ffn1},
                               {8, (size_t)il, (size_t)H, &lw.ffn2}};
+                // FTCF_FP16_RETILE_IN_PLACE=1: the caller's row-major kernels are OVERWRITTEN with the tiled image (through one
+                // bounce buffer) instead of being kept next to a tiled copy -- the engine then holds one copy of the fp16 weights
+                // (26 GB instead of 52 GB at 13B); the caller must not read those tensors as [K, N] matrices afterwards
+                const bool in_place = getenv("FTCF_FP16_RETILE_IN_PLACE") && atoi(getenv("FTCF_FP16_RETILE_IN_PLACE")) != 0;
                 for (auto& it : items) {
                     const void* src = W(it.g, l);
                     FTCF_CHECK_ARG(src != nullptr, "missing fp16 kernel tensor");
+                    const size_t bytes = it.K * it.N * 2;
+                    if (in_place) {
+                        if (e->bounce_bytes < bytes) {
+                            if (e->bounce) {
+                                FTCF_HIP_CHECK(hipStreamSynchronize(e->stream));
+                                (void)hipFree(e->bounce);
+                            }
+                            FTCF_HIP_CHECK(hipMalloc(&e->bounce, bytes));
+                            e->bounce_bytes = bytes;
+                        }
+                        launch_fp16_rowmajor_to_tiled((const f16*)src, it.K, it.N, (f16*)e->bounce, e->stream);
+                        FTCF_HIP_CHECK(hipMemcpyAsync(const_cast<void*>(src), e->bounce, bytes, hipMemcpyDeviceToDevice, e->stream));
+                        it.d->kernel = src;
+                        continue;
+                    }
                     void* dst = nullptr;
-                    FTCF_HIP_CHECK(hipMalloc(&dst, it.K * it.N * 2));
+                    FTCF_HIP_CHECK(hipMalloc(&dst, bytes));
                     e->owned.push_back(dst);
                     launch_fp16_rowmajor_to_tiled((const f16*)src, it.K, it.N, (f16*)dst, e->stream);
                     it.d->kernel = dst;
@@ -2340,6 +2361,11 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         FTCF_HIP_CHECK(hipHostMalloc((void**)&e->h_flags, 64, hipHostMallocDefault));
         e->h_flags[0] = e->h_flags[1] = 0;
         FTCF_HIP_CHECK(hipStreamSynchronize(e->stream));
+        if (e->bounce) {
+            (void)hipFree(e->bounce);
+            e->bounce       = nullptr;
+            e->bounce_bytes = 0;
+        }
         *out = e.release();
     });
 }
