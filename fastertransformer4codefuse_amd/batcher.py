@@ -54,6 +54,12 @@ class ContinuousBatcher:
         capi.check(capi.lib().ftcf_batcher_status(self._h, C.byref(w), C.byref(r), C.byref(f)))
         return {"waiting": w.value, "running": r.value, "free_pages": f.value}
 
+    def cancel(self, request_id):
+        """Drops a waiting or running request; returns False when the id is unknown or already finished."""
+        found = C.c_int(0)
+        capi.check(capi.lib().ftcf_batcher_cancel(self._h, C.c_long(int(request_id)), C.byref(found)))
+        return bool(found.value)
+
     def busy(self):
         s = self.status()
         return s["waiting"] > 0 or s["running"] > 0

@@ -2978,6 +2978,33 @@ extern "C" int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running,
         }
     });
 }
+extern "C" int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        int hit = 0;
+        for (auto it = b->waiting.begin(); it != b->waiting.end(); ++it) {
+            if (it->id == request_id) {
+                b->waiting.erase(it);
+                hit = 1;
+                break;
+            }
+        }
+        for (int si = 0; si < b->max_batch && !hit; si++) {
+            ftcf_batcher::Slot& s = b->slots[si];
+            if (s.active && s.id == request_id) {
+                FTCF_HIP_CHECK(hipSetDevice(b->e->cfg.device));
+                const uint8_t one8 = 1;
+                FTCF_HIP_CHECK(hipMemcpy(b->d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                b->release(s);
+                hit = 1;
+            }
+        }
+        if (found) {
+            *found = hit;
+        }
+    });
+}
 extern "C" int ftcf_batcher_destroy(ftcf_batcher_t b)
 {
     return guarded([&] { delete b; });

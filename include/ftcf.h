@@ -228,6 +228,8 @@ int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len,
  * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch. */
 int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events);
 int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages);
+/* drop a waiting or running request (its pages return to the pool at once); *found = 0 when the id is unknown or already done */
+int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found);
 int ftcf_batcher_destroy(ftcf_batcher_t b);
 
 #ifdef __cplusplus

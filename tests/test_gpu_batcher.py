@@ -155,3 +155,24 @@ def test_sampling_parameters_run_through_the_batcher(gh):
     out2 = cb.run_all()
     assert [out2[i] for i in ids2] == [out[i] for i in ids]
     assert cb.status()["free_pages"] == 16
+
+
+def test_cancel_returns_the_pages_and_leaves_the_others_untouched(gh):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    ref, _ = _alone(gh, op, z["prompt_b"].tolist(), 10, V, end_id)
+    cb = ContinuousBatcher(op, max_batch=2, page_tokens=8, num_pages=12, max_seq_len=40)
+    a = cb.submit(z["prompt"].tolist(), 12)
+    b = cb.submit(z["prompt_b"].tolist(), 10)
+    c = cb.submit(z["prompt"][:6].tolist(), 5)  # waits: two slots
+    got = {}
+    for rid, tok, fin in cb.step() + cb.step():
+        got.setdefault(rid, []).append(tok)
+    assert cb.cancel(a) and cb.cancel(c) and not cb.cancel(12345)
+    while cb.busy():
+        for rid, tok, fin in cb.step():
+            got.setdefault(rid, []).append(tok)
+    assert got[b] == ref and c not in got and len(got[a]) == 2
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": 12}
