@@ -48,7 +48,7 @@ constexpr int PS_UK_LONG  = 16;          // ... or 16 (512 keys: 3072 tokens of 
                                          // batches (idle between the two streams) -- and the short form, the headline's, keeps
                                          // the code it was tuned with
 #ifndef PS_FULL_P1_V
-#define PS_FULL_P1_V false
+#define PS_FULL_P1_V true
 #endif
 #ifndef PS_FULL_P3_V
 #define PS_FULL_P3_V false
