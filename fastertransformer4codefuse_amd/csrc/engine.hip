@@ -1054,9 +1054,11 @@ struct ftcf_gptneox {
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
             // (the four GEMMs of a layer may be in flight together: one region each)
-            smallm_partial = gemm_smallm_workspace_bytes(B, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(B, il, H, int8)
-                             + gemm_smallm_workspace_bytes(B, H, hl, int8) + gemm_smallm_workspace_bytes(B, H, il, int8);
-            smallm_ws = (!fp32 && B > STAGE_MAX_ROWS && B <= 16) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
+            // (17..SMALLM_MAX_ROWS rows run the same kernel in chunks of 16 rows: sized for one chunk)
+            const int bc   = std::min(B, 16);
+            smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
+                             + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
+            smallm_ws = (!fp32 && B > STAGE_MAX_ROWS && B <= SMALLM_MAX_ROWS) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -1413,18 +1415,28 @@ struct ftcf_gptneox {
                     launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
                                             nrm2, B, H, 1e-5f, stream);
                 }
-                if (B <= 16 && smallm_ws && decode_branches && side) {
+                if (B <= SMALLM_MAX_ROWS && smallm_ws && decode_branches && side) {
                     // The attention branch [QKV -> MMHA -> out-proj] (78.6 + K/V + 26.2 MB at 13B int8) and the FFN branch
                     // [FFN1 -> FFN2] (2 x 104.9 MB) of a parallel-residual layer are independent: two streams.  Every one
                     // of these launches is a short burst -- the whole matrix requested at once, gone in ~30 us -- whose
                     // ramp-up and drain leave the HBM idle; the other branch's launch fills those gaps.
-                    const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(B, 3 * hl, H, int8),
-                                 o_out = o_f1 + gemm_smallm_workspace_bytes(B, il, H, int8),
-                                 o_f2  = o_out + gemm_smallm_workspace_bytes(B, H, hl, int8);
-                    auto one = [&](const SmallmDesc& d, size_t off, hipStream_t s) {
-                        timed(KIND_SMALLM, wbytes * (double)d.n * d.k, [&] {
-                            launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, B, int8, s, &state->step, &smallm_seq, off);
-                        }, s);
+                    const int    bc = std::min(B, 16);
+                    const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8),
+                                 o_out = o_f1 + gemm_smallm_workspace_bytes(bc, il, H, int8),
+                                 o_f2  = o_out + gemm_smallm_workspace_bytes(bc, H, hl, int8);
+                    auto one = [&](const SmallmDesc& d0, size_t off, hipStream_t s) {
+                        // (one launch that keeps the weights in registers and passes the rows 16 at a time through the x tile
+                        // was measured: 256 VGPRs, one workgroup per CU -- 8.2 / 8.3 / 13.0 ms at 24 / 32 / 64 rows, i.e.
+                        // slower than re-reading the weights per 16 rows except at 64)
+                        for (int r0 = 0; r0 < B; r0 += 16) {  // 16 rows per launch (launches of one GEMM are in stream order)
+                            SmallmDesc d = d0;
+                            d.A          = d0.A + (size_t)r0 * d0.k;
+                            d.C          = d0.C + (size_t)r0 * d0.n;
+                            const int M  = std::min(16, B - r0);
+                            timed(KIND_SMALLM, wbytes * (double)d.n * d.k, [&] {
+                                launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, M, int8, s, &state->step, &smallm_seq, off);
+                            }, s);
+                        }
                     };
                     FTCF_HIP_CHECK(hipEventRecord(ev_fork, stream));
                     FTCF_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
@@ -1476,6 +1488,11 @@ struct ftcf_gptneox {
     // shard); B = 2: 4.13 vs 3.85; B = 3: 4.64 vs 3.65; B = 4: 5.78 vs 3.73 -- the m = 2..4 forms of the GEMV kernels stream
     // at a fraction of the m = 1 rate.  FTCF_STAGE_MAX_ROWS (<= 4) overrides, the tests use it to keep those forms covered.
     int STAGE_MAX_ROWS = 1;
+    // Rows up to which the batched decode GEMMs run the burst kernel, 16 rows per launch (the weights are then read
+    // ceil(B / 16) times).  Above 16 rows the alternative is the prefill-shaped tiled GEMM, which at these row counts is a
+    // few dozen workgroups streaming their weight panels serially: 13B int8, ms per step, tiled vs chunked burst:
+    // bs = 24: 13.8 vs 6.7; 32: 13.9 vs 7.2; 48: - vs 10.5; 64: 19.4 vs 13.7 (FTCF_SMALLM_MAX_ROWS overrides).
+    int SMALLM_MAX_ROWS = 64;
 
     // decoder attention of rows [r0, r0 + M) of the batch (KV cache [L][B][nh][s_max][dh]); `salt` makes the granule
     // tags of every launch of a token distinct
@@ -2316,6 +2333,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_STAGE_MAX_ROWS")) {
             e->STAGE_MAX_ROWS = std::max(0, std::min(4, atoi(m)));
         }
+        if (const char* m = getenv("FTCF_SMALLM_MAX_ROWS")) {
+            e->SMALLM_MAX_ROWS = std::max(16, std::min(256, atoi(m)));
+        }
         if (const char* m = getenv("FTCF_K3_Q")) {
             e->k3_q = atoi(m);
         }
@@ -2577,10 +2597,11 @@ struct ftcf_batcher {
         d_pseq = dmalloc<int>(B);
         d_pages_tmp = dmalloc<int>(max_pages);
         samp_ws = dmalloc<char>(sampling_workspace_bytes(max_batch, V), false);
-        if (max_batch > 4 && max_batch <= 16) {
+        if (max_batch > 4 && max_batch <= e->SMALLM_MAX_ROWS) {
             const bool i8 = e->int8;
-            smallm_partial = gemm_smallm_workspace_bytes(max_batch, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(max_batch, il, H, i8)
-                             + gemm_smallm_workspace_bytes(max_batch, H, hl, i8) + gemm_smallm_workspace_bytes(max_batch, H, il, i8);
+            const int  bc = std::min(max_batch, 16);  // 16 rows per launch
+            smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(bc, il, H, i8)
+                             + gemm_smallm_workspace_bytes(bc, H, hl, i8) + gemm_smallm_workspace_bytes(bc, H, il, i8);
             smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
         }
         std::vector<uint8_t> fin(max_batch, 1);
@@ -2766,11 +2787,18 @@ struct ftcf_batcher {
             mp.ctx = ctx;
             if (smallm_ws && e->decode_branches && e->side) {
                 // the attention branch and the FFN branch on two streams, as the engine's batched decode
-                const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(B, 3 * hl, H, int8),
-                             o_out = o_f1 + gemm_smallm_workspace_bytes(B, il, H, int8),
-                             o_f2  = o_out + gemm_smallm_workspace_bytes(B, H, hl, int8);
-                auto one = [&](const SmallmDesc& d, size_t off, hipStream_t s2) {
-                    launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, B, int8, s2, &d_gstate->step, &smallm_seq, off);
+                const int    bc = std::min(B, 16);
+                const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8),
+                             o_out = o_f1 + gemm_smallm_workspace_bytes(bc, il, H, int8),
+                             o_f2  = o_out + gemm_smallm_workspace_bytes(bc, H, hl, int8);
+                auto one = [&](const SmallmDesc& d0, size_t off, hipStream_t s2) {
+                    for (int r0 = 0; r0 < B; r0 += 16) {
+                        SmallmDesc d = d0;
+                        d.A          = d0.A + (size_t)r0 * d0.k;
+                        d.C          = d0.C + (size_t)r0 * d0.n;
+                        launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, std::min(16, B - r0), int8, s2, &d_gstate->step,
+                                                 &smallm_seq, off);
+                    }
                 };
                 FTCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
                 FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
@@ -2782,7 +2810,7 @@ struct ftcf_batcher {
                 FTCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
                 FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
             }
-            else if (smallm_ws) {
+            else if (smallm_ws && B <= 16) {
                 const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
                                           {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
                 launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
