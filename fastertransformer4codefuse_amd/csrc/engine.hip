@@ -1055,10 +1055,14 @@ struct ftcf_gptneox {
             }
             // (the four GEMMs of a layer may be in flight together: one region each)
             // (17..SMALLM_MAX_ROWS rows run the same kernel in chunks of 16 rows: sized for one chunk)
-            const int bc   = std::min(B, 16);
+            // (a prompt phase of up to SMALLM_MAX_ROWS tokens in all is HBM bound like a decode step: it takes the same kernel)
+            const int  bc         = 16;
+            const long prefill_m  = S > 1 ? (long)(B / K) * S : 0;
+            const bool decode_ws  = B > STAGE_MAX_ROWS && B <= SMALLM_MAX_ROWS;
+            const bool prefill_ws = prefill_m > 4 && prefill_m <= SMALLM_MAX_ROWS;
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
-            smallm_ws = (!fp32 && B > STAGE_MAX_ROWS && B <= SMALLM_MAX_ROWS) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
+            smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -1103,10 +1107,17 @@ struct ftcf_gptneox {
     // ---- FfnLayer / attention projections over M rows (general path) ----
     void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
     {
-        // (the split-K workspace is sized for the decode rows; a short prefill may bring more rows than that)
-        const bool ws_ok = smallm_ws && m <= 16 && gemm_smallm_workspace_bytes(m, n, k, int8) <= smallm_partial;
-        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, ws_ok ? smallm_ws : nullptr, smallm_partial,
-                      num_cu, &state->step, &smallm_seq);
+        // 5..SMALLM_MAX_ROWS rows (batched decode steps off the branch form, short prompt phases): the burst kernel, 16 rows
+        // per launch.  13B int8 prefill, ms: 17 tokens 12.5 -> 6.6, 33..48: 16.3 -> 9.6 (above that the tiled GEMM is as fast).
+        if (smallm_ws && m > 4 && m <= SMALLM_MAX_ROWS && gemm_smallm_workspace_bytes(16, n, k, int8) <= smallm_partial) {
+            for (int r0 = 0; r0 < m; r0 += 16) {
+                launch_gemm_smallm(A + (size_t)r0 * k, w.kernel, w.scale, bias, act, C + (size_t)r0 * n, smallm_ws, smallm_partial,
+                                   std::min(16, m - r0), n, k, int8, num_cu, stream, &state->step, &smallm_seq);
+            }
+            return;
+        }
+        gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, nullptr, smallm_partial, num_cu, &state->step,
+                      &smallm_seq);
     }
 
     void allreduce(f16* buf, size_t count)
