@@ -58,7 +58,7 @@ class ForwardStats(C.Structure):
                 ("gemv_kind", C.c_int), ("decode_path", C.c_int)]
 
 
-# every symbol include/ftcf.h declares (tests/test_capi_symbols.py checks the two lists against the header)
+# every symbol include/ftcf.h declares (tests/test_capi_host.py checks the list against the header and the library)
 EXPORTED = [
     "ftcf_last_error", "ftcf_version", "ftcf_device_count", "ftcf_symmetric_quantize_int8",
     "ftcf_int8_rowmajor_to_tiled", "ftcf_int8_tiled_to_rowmajor", "ftcf_int8_cuda_sm80_to_rowmajor",
