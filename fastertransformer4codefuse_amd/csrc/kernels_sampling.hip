@@ -612,7 +612,106 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
             sv[c] = v;
             si[c] = id;
         }
-        if (kc > 1) {
+        int k2 = 1;
+        while (k2 < kc) {
+            k2 <<= 1;
+        }
+        if (k > 0 && kc > 1 && n2 >= 4 * k2) {
+            // top-k rows need the k best of the union, not all of it in order: radix select of the k-th best (as stage 1, over
+            // the LDS copy), the winners compacted into k2 = 2^ceil(log2 k) slots, THOSE sorted (k = 50: 21 network stages
+            // instead of 45 over 512 pairs)
+            __shared__ int hist[256];
+            __shared__ int s_sel[4];
+            float*         tv = reinterpret_cast<float*>(si + n2);  // [k2]
+            int*           ti = reinterpret_cast<int*>(tv + k2);    // [k2]
+            __syncthreads();
+            unsigned prefix = 0u, mask = 0u;
+            int      need = kc;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                hist[threadIdx.x] = 0;
+                __syncthreads();
+                for (int c = threadIdx.x; c < n2; c += 256) {
+                    const unsigned key = fkey(sv[c]);
+                    if ((key & mask) == prefix) {
+                        atomicAdd(&hist[(key >> shift) & 255u], 1);
+                    }
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) {
+                    const int lane = threadIdx.x;
+                    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                    const int mine = h0 + h1 + h2 + h3;
+                    int       above = mine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int t = __shfl_down(above, o, 64);
+                        if (lane + o < 64) {
+                            above += t;
+                        }
+                    }
+                    above -= mine;
+                    if (above < need && above + mine >= need) {
+                        int       acc = above, bin = 4 * lane + 3;
+                        const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                        for (int q = 3; q >= 0; q--) {
+                            if (acc + hh[q] >= need) {
+                                bin = 4 * lane + q;
+                                break;
+                            }
+                            acc += hh[q];
+                        }
+                        s_sel[0] = bin;
+                        s_sel[1] = need - acc;
+                    }
+                }
+                __syncthreads();
+                prefix |= (unsigned)s_sel[0] << shift;
+                mask |= 255u << shift;
+                need = s_sel[1];
+                __syncthreads();
+            }
+            // `need` of the entries equal to the threshold belong to the set: the ones with the smallest ids (the rule of `better`)
+            if (threadIdx.x == 0) {
+                s_sel[2] = 0;
+            }
+            for (int c = threadIdx.x; c < k2; c += 256) {
+                tv[c] = -INFINITY;
+                ti[c] = 0x7fffffff;
+            }
+            __syncthreads();
+            // (the k-th best itself always equals the threshold: the usual case is exactly `need` such entries, all taken)
+            int nties = 0;
+            for (int c = threadIdx.x; c < n2; c += 256) {
+                nties += fkey(sv[c]) == prefix ? 1 : 0;
+            }
+            int       tie_total = 0;
+            (void)block_excl_scan(nties, redi, tie_total);
+            const bool all_ties = tie_total == need;
+            for (int c = threadIdx.x; c < n2; c += 256) {
+                const unsigned key = fkey(sv[c]);
+                bool           take = key > prefix || (all_ties && key == prefix);
+                if (!all_ties && key == prefix) {
+                    int rank = 0;  // entries with the same value and a smaller id: real duplicates at the threshold, rare
+                    for (int d = 0; d < n2; d++) {
+                        rank += (fkey(sv[d]) == prefix && (si[d] < si[c] || (si[d] == si[c] && d < c))) ? 1 : 0;
+                    }
+                    take = rank < need;
+                }
+                if (take) {
+                    const int pos = atomicAdd(&s_sel[2], 1);
+                    tv[pos]       = sv[c];
+                    ti[pos]       = si[c];
+                }
+            }
+            bitonic_sort_best_first(tv, ti, k2);
+            for (int c = threadIdx.x; c < kc; c += 256) {
+                sv[c] = tv[c];
+                si[c] = ti[c];
+            }
+            __syncthreads();
+        }
+        else if (kc > 1) {
             bitonic_sort_best_first(sv, si, n2);
         }
         else {  // one candidate per slice: the best of 8
@@ -901,7 +1000,11 @@ void launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish)
     while (n2 < (size_t)TOPK_BLOCKS * kc) {
         n2 <<= 1;
     }
-    const size_t sample_smem = std::max(n2 * 8, p.any_top_p ? (size_t)SORT_CH * 8 : (size_t)0);
+    size_t k2h = 1;
+    while (k2h < (size_t)kc) {
+        k2h <<= 1;
+    }
+    const size_t sample_smem = std::max(n2 * 8 + k2h * 8, p.any_top_p ? (size_t)SORT_CH * 8 : (size_t)0);
     if (sample_smem > 48 * 1024) {  // per device: the attribute is per device (and cheap to set again)
         static std::mutex mu;
         static bool       done[64] = {};
@@ -910,7 +1013,7 @@ void launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish)
         std::lock_guard<std::mutex> g(mu);
         if (!done[dev & 63]) {
             FTCF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)((size_t)TOPK_BLOCKS * TOPK_MAX * 8)));
+                                               (int)((size_t)TOPK_BLOCKS * TOPK_MAX * 8 + (size_t)TOPK_MAX * 8)));
             done[dev & 63] = true;
         }
     }
