@@ -55,6 +55,35 @@ constexpr int PS_UK_LONG  = 16;          // ... or 16 (512 keys: 3072 tokens of 
 #endif
 // streamer waves: issue the whole first rotation (32 KiB) before the hand-off instead of half of it
 constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
+// Round 3 (profiles/r03_notes.md).  PS_EARLY_P3: the streamer waves request the first FFN2 weight batches (1: half a
+// rotation, 2: the whole rotation) BEFORE the attention -- right after the K/V rows, while the workgroup waits for the
+// slowest QKV producer anyway -- instead of after it; q/k/v are then swept by the control waves alone (a poll of a
+// streamer wave would return behind its own 16-32 KiB).  Short attention form only (the long form keeps its K/V rows in
+// the register batches).  PS_CTRL_EARLY: the control waves request their P3 share's first batches (1: half, 2: whole
+// rotation) before they wait for ctx instead of after.
+#ifndef PS_EARLY_P3
+#define PS_EARLY_P3 0
+#endif
+#ifndef PS_CTRL_EARLY
+#define PS_CTRL_EARLY 0
+#endif
+// PS_NF: register batches a wave keeps IN FLIGHT in the steady state (the fourth / third / second one has landed and
+// waits to be consumed).  Everything a compute unit has outstanding sits in ONE in-order return queue, and whatever the
+// chip has outstanding beyond bandwidth x unloaded latency only adds to the latency of every request -- the hand-off polls
+// included (3 batches x 8 waves = 192 KiB per CU = 50 MB on the chip = 7.5 us of HBM time).
+// PS_PACE: the first rotation is requested with at most PS_PACE batches of a wave in flight (0: back to back).
+#ifndef PS_NF
+#define PS_NF 3
+#endif
+#ifndef PS_PACE
+#define PS_PACE 0
+#endif
+template<int N>
+__device__ __forceinline__ void ps_wait_vm()  // at most N vector-memory operations of this wave outstanding
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
 
 typedef const PersistLayer PsLayerC;
@@ -276,8 +305,19 @@ struct PsStream {
     }
     __device__ __forceinline__ void prime_hi()
     {
-        load(R2, 2);
-        load(R3, 3);
+        if constexpr (PS_PACE > 0 && PS_PACE < 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            ps_wait_vm<PS_U*(PS_PACE - 1)>();
+            load(R2, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            ps_wait_vm<PS_U*(PS_PACE - 1)>();
+            load(R3, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        else {
+            load(R2, 2);
+            load(R3, 3);
+        }
     }
     __device__ __forceinline__ void prime()
     {
@@ -297,18 +337,30 @@ struct PsStream {
         for (int i = 0; i < last; i += PS_NBUF) {
             consume(R0, i);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PS_NF < 3) {
+                ps_wait_vm<PS_U*(PS_NF - 1)>();
+            }
             load(R0, i + 4);
             __builtin_amdgcn_sched_barrier(0);
             consume(R1, i + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PS_NF < 3) {
+                ps_wait_vm<PS_U*(PS_NF - 1)>();
+            }
             load(R1, i + 5);
             __builtin_amdgcn_sched_barrier(0);
             consume(R2, i + 2);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PS_NF < 3) {
+                ps_wait_vm<PS_U*(PS_NF - 1)>();
+            }
             load(R2, i + 6);
             __builtin_amdgcn_sched_barrier(0);
             consume(R3, i + 3);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PS_NF < 3) {
+                ps_wait_vm<PS_U*(PS_NF - 1)>();
+            }
             load(R3, i + 7);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -394,9 +446,11 @@ __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 // attention of one (row b, head h, split sp) on the whole 8-wave workgroup
 // (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.cuh::mmha_partial)
 // ---------------------------------------------------------------------------------------------------------------
-template<int DH, int UK>
+template<int DH, int UK, int NSW = 3 * DH / 2>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
+    static constexpr int NQ  = 3 * DH / 2;             // q | k | v granules (pairs of halves) of one head
+    static constexpr int NB2 = (NQ + NSW - 1) / NSW;   // granules per sweeping thread (NSW threads sweep)
     static constexpr int KPI = 64 / LPK;
     static constexpr bool ALIAS = UK > PS_U;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
     static_assert(UK <= 2 * PS_U, "K rows live in R0|R1, V rows in R2|R3");
@@ -421,7 +475,7 @@ struct PsAttn {
             return vreg[u];
         }
     }
-    unsigned mask_bits, bias2;
+    unsigned mask_bits, bias2[NB2];
     int      tl, chunk, t_beg;
     float    rot_cs, rot_sn;
     bool     fin;
@@ -467,10 +521,14 @@ struct PsAttn {
             rot_cs = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2];
             rot_sn = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2 + 1];
         }
-        bias2 = 0u;
-        if (tx < 3 * DH / 2) {  // this thread's pair of q / k / v bias values (sweep_qkv)
-            const int seg = tx / (DH / 2), i = tx % (DH / 2);
-            bias2 = *PS_G(unsigned, reinterpret_cast<const unsigned*>(lw.b_qkv + (size_t)seg * p.nh * DH + h * DH) + i);
+#pragma unroll
+        for (int k = 0; k < NB2; k++) {  // this thread's pairs of q / k / v bias values (sweep_qkv)
+            const int gi = tx + k * NSW;
+            bias2[k]     = 0u;
+            if (tx < NSW && gi < NQ) {
+                const int seg = gi / (DH / 2), i = gi % (DH / 2);
+                bias2[k] = *PS_G(unsigned, reinterpret_cast<const unsigned*>(lw.b_qkv + (size_t)seg * p.nh * DH + h * DH) + i);
+            }
         }
         fin = p.finished && p.finished[b];
         tl  = p.seq_len[b];
@@ -482,29 +540,33 @@ struct PsAttn {
             return;
         }
         f16* s_q = reinterpret_cast<f16*>(smem);  // [DH] q | [DH] k | [DH] v
-        if (tx < 3 * DH / 2) {
-            const int  seg = tx / (DH / 2), i = tx % (DH / 2);
-            const int  hl  = p.nh * DH;
-            const u64* g   = p.gq + ((size_t)b * 3 * hl + (size_t)seg * hl + h * DH) / 2 + i;
-            u64        v;
-            int        spins = 0;
-            for (;;) {
-                v = ld_granule(g);
-                if ((unsigned)(v >> 32) == tag) {
-                    break;
+#pragma unroll
+        for (int k = 0; k < NB2; k++) {
+            const int gi = tx + k * NSW;
+            if (tx < NSW && gi < NQ) {
+                const int  seg = gi / (DH / 2), i = gi % (DH / 2);
+                const int  hl  = p.nh * DH;
+                const u64* g   = p.gq + ((size_t)b * 3 * hl + (size_t)seg * hl + h * DH) / 2 + i;
+                u64        v;
+                int        spins = 0;
+                for (;;) {
+                    v = ld_granule(g);
+                    if ((unsigned)(v >> 32) == tag) {
+                        break;
+                    }
+                    if (++spins > PS_SPIN) {
+                        __hip_atomic_store(p.err, 5, PS_RLX, PS_AGT);
+                        break;
+                    }
+                    if ((spins & 255) == 0 && __hip_atomic_load(p.err, PS_RLX, PS_AGT) != 0) {
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (++spins > PS_SPIN) {
-                    __hip_atomic_store(p.err, 5, PS_RLX, PS_AGT);
-                    break;
-                }
-                if ((spins & 255) == 0 && __hip_atomic_load(p.err, PS_RLX, PS_AGT) != 0) {
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+                const f16 x0 = bits_f16((unsigned)v), x1 = bits_f16((unsigned)v >> 16);
+                s_q[seg * DH + 2 * i]     = x0 + bits_f16(bias2[k]);
+                s_q[seg * DH + 2 * i + 1] = x1 + bits_f16(bias2[k] >> 16);
             }
-            const f16 x0 = bits_f16((unsigned)v), x1 = bits_f16((unsigned)v >> 16);
-            s_q[seg * DH + 2 * i]     = x0 + bits_f16(bias2);
-            s_q[seg * DH + 2 * i + 1] = x1 + bits_f16(bias2 >> 16);
         }
     }
     // returns false when the row is finished (nothing published)
@@ -801,7 +863,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     // loads are harmless re-reads); so do the two-row and tensor-parallel forms, which spilled 35-41 VGPRs without it.
     // The short one-row form -- the headline's -- keeps the code it was tuned with: the same change
     // there measured -0.7 % (profiles/r02_notes.md: hipcc's allocation of this kernel moves +-2 % with anything).
-    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP;
+#ifndef PS_NOCARRY_ALL
+#define PS_NOCARRY_ALL 0
+#endif
+    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || PS_NOCARRY_ALL;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB;
     const int     wid = threadIdx.x >> 6;
@@ -1228,7 +1293,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
 
             // =========================== attention ===============================================================
             asm volatile("" : "+v"(tid));
-            PsAttn<DH, UK> at;
+            // (EARLY: see PS_EARLY_P3; the long form's K/V rows occupy the register batches)
+            constexpr int EARLY = (UK > PS_U) ? 0 : PS_EARLY_P3;
+            using Attn          = PsAttn<DH, UK, EARLY ? PS_NC * 64 : 3 * DH / 2>;
+            Attn       at;
             const bool has_item = bid < n_items;
             int        a_sp = 0, a_h = 0, a_b = 0;
             if (has_item) {
@@ -1242,15 +1310,33 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             stamp(l, 5);
             bool live = false;
             u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
-            if constexpr (PsAttn<DH, UK>::ALIAS) {
+            if constexpr (Attn::ALIAS) {
                 // (rows in the stream's register batches: requested UNCONDITIONALLY -- a workgroup without an item reads
                 // item 0's rows for nothing -- because registers assigned under a condition carry their previous contents,
                 // here all four weight batches, around the layer loop: 30 spilled VGPRs)
                 at.issue(p, lw, a_h, a_b, a_sp, tid, st);
             }
-            if (has_item) {
+            if constexpr (EARLY != 0) {
+                if (has_item) {
+                    at.issue(p, lw, a_h, a_b, a_sp, tid, st);
+                }
+                if constexpr (!CTRL) {
+                    // behind the K/V rows in this wave's return order, ahead of everything else: in flight through the
+                    // whole attention window (the q/k/v hop alone is 4-5 us for the median workgroup)
+                    st.prime_lo();
+                    if constexpr (EARLY == 2) {
+                        st.prime_hi();
+                    }
+                }
+                if (has_item) {
+                    at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
+                    stamp(l, 6);
+                    live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
+                }
+            }
+            else if (has_item) {
                 // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
-                if constexpr (!PsAttn<DH, UK>::ALIAS) {
+                if constexpr (!Attn::ALIAS) {
                     at.issue(p, lw, a_h, a_b, a_sp, tid, st);
                 }
                 at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
@@ -1279,9 +1365,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 load_p3_consts(l);
                 // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
                 // and the control waves, which carry the attention's critical path, must not wait for it
-                st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
-                if constexpr (PS_FULL_P3) {
-                    st.prime_hi();
+                if constexpr (EARLY == 0) {
+                    st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
+                    if constexpr (PS_FULL_P3) {
+                        st.prime_hi();
+                    }
                 }
             }
             // =========================== P3: [FFN2 u out-proj] -> residual ========================================
@@ -1290,6 +1378,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             // announce it through an LDS counter that gates every batch touching ctx; their own share is the END of the
             // workgroup's tile space, i.e. the out-proj pieces.
             if constexpr (CTRL) {
+                if constexpr (PS_CTRL_EARLY != 0) {
+                    // the weights of the control waves' share (the out-proj pieces) need nothing: requested before the
+                    // wait for ctx (polls of this wave return behind them -- ctx is 6-10 us away anyway)
+                    st.prime_lo();
+                    if constexpr (PS_CTRL_EARLY == 2) {
+                        st.prime_hi();
+                    }
+                }
                 if (has_item && a_sp == 0 && wid == 0) {
                     if (live) {
                         ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
@@ -1311,10 +1407,12 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     atomicAdd(&s.misc[32], 1);  // DS operations of a wave execute in order: the writes above are visible
                 }
                 load_p3_consts(l);
-                st.prime_lo();
+                if constexpr (PS_CTRL_EARLY == 0) {
+                    st.prime_lo();
+                }
             }
             stamp(l, 9);
-            st.template run<CTRL || !PS_FULL_P3>();
+            st.template run<CTRL ? (PS_CTRL_EARLY != 2) : (EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));
