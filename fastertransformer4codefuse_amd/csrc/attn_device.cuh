@@ -13,6 +13,83 @@ __device__ __forceinline__ float group_sum(float v, int lanes_per_key)
     return v;
 }
 
+// the same sum inside groups of 8 or 16 lanes on the VALU's data-parallel-primitive path: no LDS crossbar round trips
+// (__shfl_xor is a ds_bpermute: ~64 cycles each, four in a row per key block).  Every lane of the group gets the sum.
+template<int CTRL>
+__device__ __forceinline__ float dpp_read(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template<int LPK>
+__device__ __forceinline__ float group_sum_dpp(float v)
+{
+    static_assert(LPK == 8 || LPK == 16, "8 or 16 lanes per key");
+    v += dpp_read<0xB1>(v);  // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_read<0x4E>(v);  // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_read<0x141>(v);  // row_half_mirror: the other quad of the eight
+    if constexpr (LPK == 16) {
+        v += dpp_read<0x140>(v);  // row_mirror: the other eight of the row
+    }
+    return v;
+}
+
+// wave-wide max / sum without the LDS crossbar: four DPP steps inside every row of 16 lanes, then the four row results
+// through readlane (uniform result)
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    v = fmaxf(v, dpp_read<0xB1>(v));
+    v = fmaxf(v, dpp_read<0x4E>(v));
+    v = fmaxf(v, dpp_read<0x141>(v));
+    v = fmaxf(v, dpp_read<0x140>(v));
+    const int   b  = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v = group_sum_dpp<16>(v);
+    const int   b  = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// the value of lane + 1 (same row of 16 lanes; the last lane of a row reads 0): packs pairs of halves without ds_bpermute
+__device__ __forceinline__ unsigned next_lane_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);  // row_shl:1
+}
+// v + (the same lane of the row 16 / 32 lanes away), on gfx950's lane-swap instructions (VALU, no LDS crossbar).  The
+// instruction swaps its two operands in place (odd rows of the first with even rows of the second / upper half of the
+// first with lower half of the second); with ONE value in both, hipcc's builtin adds the first result to itself (measured,
+// ROCm 7.2), so the statement is written out: two copies in, both out, two wait states after the last VALU write.
+__device__ __forceinline__ float xor16_sum(float v)
+{
+    float a = v, c = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(c));  // {rows 0 0 2 2}, {rows 1 1 3 3}
+    return a + c;
+}
+__device__ __forceinline__ float xor32_sum(float v)
+{
+    float a = v, c = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(c));  // {lower half twice}, {upper half twice}
+    return a + c;
+}
+// sum over the key groups of a wave: lanes l, l + LPK, l + 2 LPK, ... (every lane gets it)
+template<int LPK>
+__device__ __forceinline__ float across_groups_sum(float v)
+{
+    if constexpr (LPK == 8) {
+        v += dpp_read<0x128>(v);  // row_ror:8
+    }
+    return xor32_sum(xor16_sum(v));
+}
+
 // rotary coefficient exactly as the reference computes it (decoder_masked_multihead_attention_utils.h:1325-1329):
 // inv_freq = t / 10000^(2j/rot) ; {cos, sin}(inv_freq) in fp32
 __device__ __forceinline__ void rotary_coef(int j, int rot, int pos, float& cs, float& sn)

@@ -906,6 +906,9 @@ struct ftcf_gptneox {
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
+    char*               ps_tab = nullptr;     // the plan's run / tile tables, built once per request by a launch over no layers
+    bool                ps_tab_ready = false;
+    bool                ps_lm_fused = false;  // the LM head runs as the tail of the persistent launch (one GPU, H % 512 == 0)
     unsigned long long *ps_gq = nullptr, *ps_gm = nullptr, *ps_gc = nullptr, *ps_gx = nullptr, *ps_gp = nullptr,
                        *ps_ga = nullptr;
     size_t              ps_slab_n = 0;
@@ -1032,7 +1035,7 @@ struct ftcf_gptneox {
             if (persist && !fp32 && K == 1 && B <= 2 && cfg.use_gptj_residual && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3);
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, tpn == 1);
                 const bool resident = !pplan.ok ? false
                                       : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
                                                  : persist_resident(pplan, int8, B, dh, num_cu, tpn);
@@ -1040,6 +1043,7 @@ struct ftcf_gptneox {
                     pplan = PersistPlan{};  // not every workgroup would be resident: the hand-offs could never complete
                 }
             }
+            ps_lm_fused = false;
             if (pplan.ok) {
                 ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
                             + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 + (size_t)B * nhl * pplan.nsplit * (dh + 2);
@@ -1051,6 +1055,10 @@ struct ftcf_gptneox {
                 ps_ga       = ps_gq ? ps_gp + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 : nullptr;
                 ps_err      = ps_gq ? reinterpret_cast<int*>(ps_gq + ps_slab_n) : nullptr;
                 d_players   = c.take<PersistLayer>(L);
+                ps_tab      = c.take<char>(persist_table_bytes(pplan) * pplan.NB);
+                ps_tab_ready = false;
+                static const int lm_env = getenv("FTCF_PERSIST_LM") ? atoi(getenv("FTCF_PERSIST_LM")) : 1;
+                ps_lm_fused = lm_env != 0 && tpn == 1 && H % 512 == 0;
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
             // (the four GEMMs of a layer may be in flight together: one region each)
@@ -1332,6 +1340,16 @@ struct ftcf_gptneox {
         pp.rot_table = rot_table;
         pp.eps = 1e-5f;
         pp.ts = ps_ts;
+        pp.tab = ps_tab;
+        pp.tab_mode = (ps_tab && ps_tab_ready) ? 2 : 0;
+        if (ps_lm_fused) {  // final LayerNorm + LM head as the launch's tail (enqueue_step then skips its own launch)
+            pp.lm_w      = lm_head;
+            pp.lm_g      = final_g;
+            pp.lm_b      = final_b;
+            pp.lm_logits = logits;
+            pp.lm_rows   = V;
+            pp.lm_ldc    = V;
+        }
         return pp;
     }
 
@@ -1372,7 +1390,7 @@ struct ftcf_gptneox {
                 g.barrier();
                 return;
             }
-            timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_persistent(pp, int8, stream); });
+            timed(KIND_PERSIST, layer_bytes * L + (ps_lm_fused ? 2.0 * V * H : 0.0), [&] { launch_decode_persistent(pp, int8, stream); });
             return;
         }
         for (int l = 0; l < L; l++) {
@@ -1851,6 +1869,17 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         }
         FTCF_HIP_CHECK(hipMemcpyAsync(d_players, pl.data(), sizeof(PersistLayer) * L, hipMemcpyHostToDevice, stream));
         FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
+        ps_tab_ready = false;
+        static const int tab_env = getenv("FTCF_PERSIST_TABLES") ? atoi(getenv("FTCF_PERSIST_TABLES")) : 1;
+        if (tab_env && ps_tab && cfg.tensor_para_size == 1) {
+            // the run / tile tables of this plan: one launch over no layers builds and stores them, every token's launch
+            // loads them (17 us of table building per launch otherwise)
+            PersistParams pp = persist_params(B, s_max);
+            pp.l_begin = pp.l_end = 0;
+            pp.tab_mode = 1;
+            launch_decode_persistent(pp, int8, stream);
+            ps_tab_ready = true;
+        }
         comm_stream_sync(cfg.comm, stream);  // `pl` dies at scope exit
     }
     // beam search: the reference tiles the inputs K times and runs the context phase on all batch * K rows
@@ -1997,7 +2026,8 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
         const bool fuse_ln = B <= 4 && !fp32;
-        if (!fuse_ln) {
+        const bool lm_done = with_decoder && pplan.ok && ps_lm_fused;  // the persistent launch computed the logits itself
+        if (!fuse_ln && !lm_done) {
             launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, !fp32, stream);
         }
         auto lm = [&](const f16* Wrows, float* out, int rows, int ld) {
@@ -2011,7 +2041,9 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
                 lm_head_dispatch(nrm, Wrows, out, B, rows, H, ld, stream);
             }
         };
-        if (tp == 1) {
+        if (lm_done) {
+        }
+        else if (tp == 1) {
             timed(KIND_LM_HEAD, 2.0 * V * H, [&] { lm(lm_head, logits, V, V); });
         }
         else {

@@ -198,6 +198,7 @@ struct PersistPlan {
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
+    int    a3;        // the attention runs on the control waves alone, K rows by LDS-DMA (one row, short form, TP = 1)
     size_t smem;
 };
 struct PersistParams {
@@ -223,6 +224,16 @@ struct PersistParams {
     // for xw[tp_rank], peer mappings otherwise); window layout [tp source ranks][M*H/2] granules of {tag, pair of halves}
     int                 tp_rank;
     unsigned long long* xw[8];
+    // the plan's run / tile tables, precomputed once per plan: [NB][persist_table_bytes(plan)] ; tab_mode 0: none (build in
+    // the launch), 1: build and store (a launch over no layers), 2: load
+    char*               tab;
+    int                 tab_mode;
+    // LM head as the tail of the launch that runs the last layer (GptNeoX.cc:853-925, one GPU): final LayerNorm of x' and
+    // logits[m][v] = h[m] . lm_w[v] for all lm_rows rows of the [V][H] fp16 tensor; lm_w == NULL: not fused
+    const f16*          lm_w;
+    const f16 *         lm_g, *lm_b;
+    float*              lm_logits;  // [M][lm_ldc]
+    int                 lm_rows, lm_ldc;
 };
 constexpr int PERSIST_MAX_TP = 8;
 struct PersistGroupParams {  // local group launch: every rank's parameters, nb workgroups each
@@ -230,9 +241,11 @@ struct PersistGroupParams {  // local group launch: every rank's parameters, nb 
     int           world, nb;
 };
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int cs1, int cs3);
+                         int cs1, int cs3, bool allow_a3 = false);
 // every workgroup of the plan's grid resident at once on this device?  (also raises the kernel's dynamic-LDS limit there)
 bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp = 1);
+// bytes of the table region one workgroup stores / loads (PersistParams::tab holds NB of them)
+size_t      persist_table_bytes(const PersistPlan& pl);
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
 // all ranks of a local group in one launch (grid = world * NB): residency of the whole group
 bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world);

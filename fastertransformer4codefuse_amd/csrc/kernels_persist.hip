@@ -7,15 +7,17 @@ namespace ftcf {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3)
+static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3, bool a3)
 {
+    // (a3: the K rows of the KV split, 1 KiB aligned behind everything else)
     return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)PS_RMAX * PS_NW * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
-           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (e1 + e3) * 4
-           + (size_t)PS_NW * (e1 + e3) / PS_U * 4;
+           + 2 * sizeof(RunRec) * PS_RMAX + 2 * PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (e1 + e3) * 4
+           + (size_t)PS_NW * (e1 + e3) / PS_U * 4 + (a3 ? 1024 + (size_t)PS_UK * PS_NW * 1024 : 0)
+           + ((M == 1 && !a3 && PS_PART3) ? (size_t)PS_RMAX * PS_NW * M * 16 * 4 : 0);
 }
 
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int cs1, int cs3)
+                         int cs1, int cs3, bool allow_a3)
 {
     PersistPlan pl{};
     const int   M  = B;
@@ -136,7 +138,11 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (pl.xs_halves > 0x1ffff) {
         return pl;
     }
-    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3);
+    // A3 (the attention on the control waves, K rows by LDS-DMA): one row, the short attention form, and 64 KiB more LDS
+    static const int a3_env = getenv("FTCF_PERSIST_A3") ? atoi(getenv("FTCF_PERSIST_A3")) : 0;
+    pl.a3 = (a3_env != 0 && allow_a3 && M == 1 && pl.uk == PS_UK
+             && ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, true) <= 160 * 1024) ? 1 : 0;
+    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, pl.a3 != 0);
     if (pl.smem > 160 * 1024) {
         return pl;
     }
@@ -146,15 +152,27 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     return pl;
 }
 
-template<bool INT8, int M, int DH, int UK>
+size_t persist_table_bytes(const PersistPlan& pl)
+{
+    // rt1 | rt3 | rsc | rsc3 | red | misc | lt1 | lt3 | bt1 | bt3 (persist_device.cuh, the carve of the kernel's LDS)
+    return 2 * sizeof(RunRec) * PS_RMAX + 2 * PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (pl.e1 + pl.e3) * 4
+           + (size_t)PS_NW * (pl.e1 + pl.e3) / PS_U * 4;
+}
+
+template<bool INT8, int M, int DH, int UK, bool A3 = false>
 static const void* ps_kernel()
 {
-    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false>);
+    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false, false, A3>);
 }
-static const void* ps_kernel_for(bool int8, int M, int dh, int uk)
+static const void* ps_kernel_for(bool int8, int M, int dh, int uk, bool a3)
 {
 #define PS_SEL(I8, MM, D)                                                                                              \
     if (int8 == I8 && M == MM && dh == D) {                                                                            \
+        if constexpr (MM == 1) {                                                                                       \
+            if (a3 && uk == PS_UK) {                                                                                   \
+                return ps_kernel<I8, MM, D, PS_UK, true>();                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
         return uk == PS_UK_LONG ? ps_kernel<I8, MM, D, PS_UK_LONG>() : ps_kernel<I8, MM, D, PS_UK>();                  \
     }
     PS_SEL(true, 1, 128)
@@ -201,7 +219,7 @@ bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_c
     if (tp > 1) {
         return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
     }
-    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk), pl, num_cu, pl.NB);
+    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk, pl.a3 != 0), pl, num_cu, pl.NB);
 }
 
 void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
@@ -210,7 +228,7 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk);
+    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0);
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
     FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;

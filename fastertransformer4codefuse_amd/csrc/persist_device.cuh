@@ -78,6 +78,17 @@ constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
 #ifndef PS_PACE
 #define PS_PACE 0
 #endif
+// one wave-wide LDS-DMA: lane i's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * i (MI355X guide, section 5.7:
+// M0 carries the LDS base and is compiler-reserved, so it is saved, set and restored inside ONE statement); the request
+// counts on vmcnt like any load, the compiler does not know about it
+__device__ __forceinline__ void ps_lds_dma16(const void* gsrc, const unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 template<int N>
 __device__ __forceinline__ void ps_wait_vm()  // at most N vector-memory operations of this wave outstanding
 {
@@ -424,14 +435,17 @@ struct PsSmem {
     f16*      xraw;  // [M][H]
     f16*      xs;    // x region (P1: LN1(x) | LN2(x) ; P3: mid | ctx)
     float*    part;  // [RMAX][NW][M*16]
+    float*    part3; // P3's own partial sums (one row, not A3): no barrier between the P1 epilogue and the P3 set-up
     char*     att;   // attention scratch
     RunRec*   rt1;   // [RMAX] P1 runs
     RunRec*   rt3;   // [RMAX] P3 runs
     f16*      rsc;   // [RMAX][16] scales of the current stage
+    f16*      rsc3;  // A3: P3's scales in their own array (written before the barrier that ends P1)
     float*    red;   // 64
     int*      misc;  // 64: [0] nmerge, [1..8] merge groups
     unsigned *lt1, *lt3;  // [NW][e1], [NW][e3]
     unsigned *bt1, *bt3;  // [NW][e1 / PS_U], [NW][e3 / PS_U]
+    char*     kbuf;       // A3: K rows of the workgroup's KV split, [UK][NW][1 KiB] (LDS-DMA destination)
 };
 
 __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
@@ -484,6 +498,11 @@ struct PsAttn {
     template<typename ST>
     __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st)
     {
+        issue_impl<true>(p, lw, h, b, sp, tx, st);
+    }
+    template<bool ROWS, typename ST>
+    __device__ __forceinline__ void issue_impl(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st)
+    {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
         chunk = (((p.s_max + p.plan.nsplit - 1) / p.plan.nsplit) + 15) & ~15;
@@ -494,17 +513,19 @@ struct PsAttn {
         // re-read its last row: a cache hit, not K/V traffic of the neighbouring split
         int t_last = t_beg + chunk - 1;
         t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
+        if constexpr (ROWS) {
 #pragma unroll
-        for (int u = 0; u < UK; u++) {
-            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < t_last ? t : t_last;
-            kr(st, u) = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
-        }
+            for (int u = 0; u < UK; u++) {
+                int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+                t       = t < t_last ? t : t_last;
+                kr(st, u) = *PS_G(u32x4, kc + (size_t)t * DH + sub * 8);
+            }
 #pragma unroll
-        for (int u = 0; u < UK; u++) {
-            int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            t       = t < t_last ? t : t_last;
-            vr(st, u) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+            for (int u = 0; u < UK; u++) {
+                int t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+                t       = t < t_last ? t : t_last;
+                vr(st, u) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+            }
         }
         mask_bits = 0u;
         if (p.masked_tokens && sub == 0) {
@@ -532,6 +553,268 @@ struct PsAttn {
         }
         fin = p.finished && p.finished[b];
         tl  = p.seq_len[b];
+    }
+    // ---- A3: the whole split on the two control waves -----------------------------------------------------------
+    // The split's rows are cut into 1-KiB blocks (64 / LPK keys each, the unit of one wave-wide request); control wave c
+    // owns blocks j = u * PS_NW + c * (PS_NW / PS_NC) + q  (u < UK, q < PS_NW / PS_NC): it requests their K rows into
+    // LDS block j of kbuf (the rows land as [key][DH] halves, lane i's 16 bytes at 16 i -- the order it reads them back
+    // in), their V rows into its register batches R0..R3, and later computes exactly those keys.
+    static constexpr int NBLK = UK * PS_NW / PS_NC;
+    static constexpr int BPC  = PS_NW / PS_NC;
+    template<typename ST>
+    __device__ __forceinline__ u32x4& vrow(ST& st, const int i)
+    {
+        return i < PS_U ? st.R0[i % PS_U] : i < 2 * PS_U ? st.R1[i % PS_U] : i < 3 * PS_U ? st.R2[i % PS_U] : st.R3[i % PS_U];
+    }
+    // `item`: false for a workgroup without a (row, head, split) -- it requests one cached row over and over (registers
+    // assigned under a condition would be carried around the layer loop)
+    template<typename ST>
+    __device__ __forceinline__ void issue_ctrl(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx,
+                                               ST& st, const unsigned kbuf_lds, const bool item)
+    {
+        static_assert(NBLK <= 32 && NBLK == PS_NBUF * PS_U, "V rows of a control wave fill its four register batches");
+        const int lane = tx & 63, c = tx >> 6;
+        const int sub = lane % LPK, grp = lane / LPK;
+        chunk = (((p.s_max + p.plan.nsplit - 1) / p.plan.nsplit) + 15) & ~15;
+        t_beg = sp * chunk;
+        const f16*  kc = lw.k_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
+        const auto* vc = PS_G(f16, lw.v_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
+        int t_last = t_beg + chunk - 1;
+        t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
+        t_last     = item ? t_last : t_beg;
+#pragma unroll
+        for (int i = 0; i < NBLK; i++) {
+            const int j = (i / BPC) * PS_NW + c * BPC + i % BPC;
+            int       t = t_beg + j * KPI + grp;
+            t           = t < t_last ? t : t_last;
+            ps_lds_dma16(kc + (size_t)t * DH + sub * 8, (unsigned)ps_rfl((int)(kbuf_lds + (unsigned)j * 1024u)));
+        }
+#pragma unroll
+        for (int i = 0; i < NBLK; i++) {
+            const int j = (i / BPC) * PS_NW + c * BPC + i % BPC;
+            int       t = t_beg + j * KPI + grp;
+            t           = t < t_last ? t : t_last;
+            vrow(st, i) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+        }
+        mask_bits = 0u;
+        if (p.masked_tokens && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < NBLK; i++) {
+                const int j = (i / BPC) * PS_NW + c * BPC + i % BPC;
+                int       t = t_beg + j * KPI + grp;
+                t           = t < t_last ? t : t_last;
+                mask_bits |= (p.masked_tokens[(size_t)b * p.s_max + t] ? 1u : 0u) << i;
+            }
+        }
+        rot_cs = 1.f;
+        rot_sn = 0.f;
+        if (p.rot > 0 && tx < p.rot / 2) {
+            rot_cs = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2];
+            rot_sn = p.rot_table[((size_t)b * (p.rot / 2) + tx) * 2 + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < NB2; k++) {
+            const int gi = tx + k * NSW;
+            bias2[k]     = 0u;
+            if (tx < NSW && gi < NQ) {
+                const int seg = gi / (DH / 2), i = gi % (DH / 2);
+                bias2[k] = *PS_G(unsigned, reinterpret_cast<const unsigned*>(lw.b_qkv + (size_t)seg * p.nh * DH + h * DH) + i);
+            }
+        }
+        fin = p.finished && p.finished[b];
+        tl  = p.seq_len[b];
+    }
+    // same arithmetic as compute() (decoder_masked_multihead_attention_template.hpp:1099-1919) on PS_NC waves; bar2 is the
+    // control waves' own barrier.  Returns false when the row is finished (nothing published).
+    template<typename ST, typename BAR>
+    __device__ __forceinline__ bool compute_ctrl(const PersistParams& p, PsLayerC& lw, char* smem, const char* kbuf, u64* gout,
+                                                 const unsigned tag, int h, int b, const int tx, ST& st, BAR&& bar2)
+    {
+        constexpr int NTC = PS_NC * 64;
+        const int     lane = tx & 63, c = tx >> 6;
+        const int     sub = lane % LPK, grp = lane / LPK;
+        if (fin) {
+            return false;  // :1176
+        }
+        int t_end = t_beg + chunk;
+        if (t_end > tl + 1) {
+            t_end = tl + 1;
+        }
+        if (t_beg > tl) {  // empty split
+            for (int d = tx; d < DH; d += NTC) {
+                st_granule(&gout[d], tag, 0.f);
+            }
+            if (tx == 0) {
+                st_granule(&gout[DH], tag, -INFINITY);
+                st_granule(&gout[DH + 1], tag, 0.f);
+            }
+            return true;
+        }
+        const bool owns_cur     = (tl >= t_beg && tl < t_end);
+        const int  t_cached_end = owns_cur ? tl : t_end;
+        f16*   s_q   = reinterpret_cast<f16*>(smem);
+        f16*   s_k   = s_q + DH;
+        f16*   s_v   = s_k + DH;
+        float* s_red = reinterpret_cast<float*>(s_v + DH);  // [2*NW + NW*DH] (sized for the eight-wave form)
+        float* s_p   = s_red + 2 * PS_NW + PS_NW * DH;      // [chunk]
+        bar2();  // q | k | v (+ bias) written by sweep_qkv
+        if (p.rot > 0 && tx < p.rot / 2) {
+            const int j = tx;
+            f16       a = s_q[j], c2 = s_q[j + p.rot / 2];
+            rotary_apply(a, c2, rot_cs, rot_sn);
+            s_q[j]             = a;
+            s_q[j + p.rot / 2] = c2;
+            if (owns_cur) {
+                f16 ka = s_k[j], kc2 = s_k[j + p.rot / 2];
+                rotary_apply(ka, kc2, rot_cs, rot_sn);
+                s_k[j]             = ka;
+                s_k[j + p.rot / 2] = kc2;
+            }
+        }
+        bar2();
+        if (owns_cur) {  // append to the cache (:1397, :1837)
+            for (int d = tx; d < DH; d += NTC) {
+                ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + d] = s_k[d];
+                ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + d] = s_v[d];
+            }
+        }
+        // Each control wave runs its own keys through the whole soft-max (scores in a wave-private part of s_p, its own
+        // maximum, sum and un-normalised output); the two partials are combined like the splits of a (row, head) are:
+        // no exchange between the waves before the end, no LDS crossbar in the reductions.
+        const float inv_sqrt_dh = rsqrtf((float)DH);
+        const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+        float       lmax        = -INFINITY;
+        static_assert(BPC == 4, "four key blocks per trip");
+#pragma unroll 1
+        for (int u = 0; u < UK; u++) {  // (rolled: nothing of it can be hoisted above the V rows' long lives)
+            const char* kb = kbuf + (size_t)(u * PS_NW + c * BPC) * 1024 + lane * 16;
+            f16x8       kv[BPC];
+#pragma unroll
+            for (int q = 0; q < BPC; q++) {
+                kv[q] = *reinterpret_cast<const f16x8*>(kb + q * 1024);
+            }
+#pragma unroll
+            for (int q = 0; q < BPC; q++) {
+                const int t = t_beg + (u * PS_NW + c * BPC + q) * KPI + grp;
+                float     a = 0.f;
+                a           = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[q][0], kv[q][1]}, a);
+                a           = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[q][2], kv[q][3]}, a);
+                a           = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[q][4], kv[q][5]}, a);
+                a           = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[q][6], kv[q][7]}, a);
+                a           = group_sum_dpp<LPK>(a) * inv_sqrt_dh;
+                const bool m = ((mask_bits >> (u * BPC + q)) & 1u) != 0u;
+                a            = m ? -INFINITY : a;
+                if (t < t_cached_end && sub == 0) {
+                    s_p[t - t_beg] = a;
+                    lmax           = fmaxf(lmax, a);
+                }
+            }
+        }
+        float cur_p = -INFINITY;  // wave 0: score of the current token (:1407-1437), from LDS
+        if (owns_cur && c == 0) {
+            float a = 0.f;
+            if (lane < LPK) {
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
+                const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
+                a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
+                a              = dot2(f16x2{q8[2], q8[3]}, f16x2{kv[2], kv[3]}, a);
+                a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
+                a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
+            }
+            cur_p = wave_sum_dpp(a) * inv_sqrt_dh;
+            lmax  = fmaxf(lmax, cur_p);
+        }
+        const float m_c = wave_max_dpp(lmax);
+        float       acc[8];
+        float       lsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            acc[e] = 0.f;
+        }
+#pragma unroll
+        for (int i0 = 0; i0 < NBLK; i0 += 4) {
+            float sc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int j = ((i0 + q) / BPC) * PS_NW + c * BPC + (i0 + q) % BPC;
+                const int t = t_beg + j * KPI + grp;
+                // (rows beyond tlength were fetched speculatively and may hold anything: weight 0)
+                sc[q] = (t < t_cached_end) ? s_p[t - t_beg] : -INFINITY;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float pt = (sc[q] == -INFINITY) ? 0.f : __expf(sc[q] - m_c);
+                lsum += (sub == 0) ? pt : 0.f;
+                const f16x8 vv = __builtin_bit_cast(f16x8, vrow(st, i0 + q));
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    acc[e] = (sc[q] == -INFINITY) ? acc[e] : fmaf(pt, (float)vv[e], acc[e]);
+                }
+            }
+        }
+        if (owns_cur && c == 0) {
+            const float pt = __expf(cur_p - m_c);
+            lsum += (lane == 0) ? pt : 0.f;
+            if (grp == 0) {
+                const f16x8 vv = *reinterpret_cast<const f16x8*>(s_v + sub * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    acc[e] = fmaf(pt, (float)vv[e], acc[e]);
+                }
+            }
+        }
+        const float l_c = wave_sum_dpp(lsum);
+        // un-normalised outputs of the wave's four key groups (DH = 64: eight groups, folded in pairs first) -> LDS
+        constexpr int NG4 = 4;
+        if constexpr (LPK == 8) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                acc[e] += dpp_read<0x128>(acc[e]);  // row_ror:8 -- the other key group of the row
+            }
+        }
+        float*    s_o = s_red + 2 * PS_NW;  // [NC][4][DH]
+        const int g4  = lane >> 4;
+        if (LPK == 16 || (lane & 8) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                s_o[(size_t)(c * NG4 + g4) * DH + sub * 8 + e] = acc[e];
+            }
+        }
+        if (lane == 0) {
+            s_red[c]         = m_c;
+            s_red[PS_NW + c] = l_c;
+        }
+        bar2();
+        float m_loc = s_red[0];
+#pragma unroll
+        for (int w = 1; w < PS_NC; w++) {
+            m_loc = fmaxf(m_loc, s_red[w]);
+        }
+        float wgt[PS_NC], ls = 0.f;
+#pragma unroll
+        for (int w = 0; w < PS_NC; w++) {
+            wgt[w] = (s_red[w] == -INFINITY) ? 0.f : __expf(s_red[w] - m_loc);
+            ls += wgt[w] * s_red[PS_NW + w];
+        }
+        for (int d = tx; d < DH; d += NTC) {
+            float o = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_NC; w++) {
+                float ow = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG4; g++) {
+                    ow += s_o[(size_t)(w * NG4 + g) * DH + d];
+                }
+                o += wgt[w] * ow;
+            }
+            st_granule(&gout[d], tag, o);
+        }
+        if (tx == 0) {
+            st_granule(&gout[DH], tag, m_loc);
+            st_granule(&gout[DH + 1], tag, ls);
+        }
+        bar2();  // the scratch is free (the merge of a split-0 workgroup reuses it)
+        return true;
     }
     // q/k/v of the current token: granules published by the QKV stage of THIS launch (pairs of halves); + bias -> LDS
     __device__ __forceinline__ void sweep_qkv(const PersistParams& p, char* smem, const unsigned tag, int h, int b, const int tx)
@@ -622,22 +905,26 @@ struct PsAttn {
         const float inv_sqrt_dh = rsqrtf((float)DH);
         const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
         float       lmax        = -INFINITY;
+        // (two passes: the UK dot products first, without control flow -- their dependent dot2 / DPP chains interleave --
+        // then the stores of the valid ones)
+        float sc[UK];
 #pragma unroll
         for (int u = 0; u < UK; u++) {
-            const int   t  = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             const f16x8 kv = __builtin_bit_cast(f16x8, kr(st, u));
             float       a  = 0.f;
             a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
             a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
             a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
             a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
-            a              = group_sum(a, LPK) * inv_sqrt_dh;
+            a              = group_sum_dpp<LPK>(a) * inv_sqrt_dh;
+            sc[u]          = ((mask_bits >> u) & 1u) != 0u ? -INFINITY : a;
+        }
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+            const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
             if (t < t_cached_end && sub == 0) {
-                const bool m   = ((mask_bits >> u) & 1u) != 0u;
-                s_p[t - t_beg] = m ? -INFINITY : a;
-                if (!m) {
-                    lmax = fmaxf(lmax, a);
-                }
+                s_p[t - t_beg] = sc[u];
+                lmax           = fmaxf(lmax, sc[u]);
             }
         }
         if (owns_cur && wid == 0) {  // current token from LDS (:1407-1437)
@@ -650,16 +937,21 @@ struct PsAttn {
                 a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
                 a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
             }
-            a = wave_sum(a) * inv_sqrt_dh;
+            a = wave_sum_dpp(a) * inv_sqrt_dh;
             if (lane == 0) {
                 s_p[tl - t_beg] = a;
                 lmax            = fmaxf(lmax, a);
             }
         }
-        lmax = wave_max(lmax);
+        lmax = wave_max_dpp(lmax);
         if (lane == 0) {
             s_red[wid] = lmax;
         }
+#ifdef PS_ATT_STAMPS
+        if (p.ts && lane == 0 && wid >= PS_NC) {
+            p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + wid) * 16 + 13] = wall_clock64();
+        }
+#endif
         __syncthreads();
         float m_loc = s_red[0];
 #pragma unroll
@@ -672,8 +964,13 @@ struct PsAttn {
             s_p[i]        = e;
             lsum += e;
         }
-        lsum = wave_sum(lsum);
+        lsum = wave_sum_dpp(lsum);
         __syncthreads();
+#ifdef PS_ATT_STAMPS
+        if (p.ts && lane == 0 && wid >= PS_NC) {
+            p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + wid) * 16 + 14] = wall_clock64();
+        }
+#endif
         if (lane == 0) {
             s_red[PS_NW + wid] = lsum;
         }
@@ -682,16 +979,25 @@ struct PsAttn {
         for (int j = 0; j < 8; j++) {
             acc[j] = 0.f;
         }
+        // (rows beyond tlength were fetched speculatively and may hold anything: weight 0 AND value 0, without control flow)
+        float pw[UK];
 #pragma unroll
         for (int u = 0; u < UK; u++) {
-            const int t = t_beg + u * PS_NW * KPI + wid * KPI + grp;
-            if (t < t_cached_end) {  // rows beyond tlength were fetched speculatively and may hold anything
-                const float pt = s_p[t - t_beg];
-                const f16x8 vv = __builtin_bit_cast(f16x8, vr(st, u));
+            const int  t     = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            const bool valid = t < t_cached_end;
+            const int  idx   = valid ? t - t_beg : 0;
+            pw[u]            = valid ? s_p[idx] : 0.f;
+        }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    acc[j] = fmaf(pt, (float)vv[j], acc[j]);
-                }
+        for (int u = 0; u < UK; u++) {
+            const int   t     = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            const bool  valid = t < t_cached_end;
+            const u32x4 raw   = vr(st, u);
+            const u32x4 vz    = {valid ? raw.x : 0u, valid ? raw.y : 0u, valid ? raw.z : 0u, valid ? raw.w : 0u};
+            const f16x8 vv    = __builtin_bit_cast(f16x8, vz);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                acc[j] = fmaf(pw[u], (float)vv[j], acc[j]);
             }
         }
         if (owns_cur && wid == 0 && grp == 0) {
@@ -704,10 +1010,13 @@ struct PsAttn {
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            for (int o = LPK; o < 64; o <<= 1) {
-                acc[j] += __shfl_xor(acc[j], o, 64);
-            }
+            acc[j] = across_groups_sum<LPK>(acc[j]);
         }
+#ifdef PS_ATT_STAMPS
+        if (p.ts && lane == 0 && wid >= PS_NC) {
+            p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + wid) * 16 + 15] = wall_clock64();
+        }
+#endif
         float* s_o = s_red + 2 * PS_NW;  // [NW][DH]
         if (grp == 0) {
 #pragma unroll
@@ -747,14 +1056,20 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
     const int ne = DH + 2, ns = p.plan.nsplit;
     const int ng = ns * ne;
     float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
-    ps_sweep<8>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
+#ifndef PS_MERGE_NPER
+#define PS_MERGE_NPER 8
+#endif
+    ps_sweep<PS_MERGE_NPER>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
+    if (p.ts && tx == 0) {  // (debug stamp 15: partials swept)
+        p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + 0) * 16 + 15] = wall_clock64();
+    }
     // weights (same wave: DS operations of one wave execute in order)
     float ms = -INFINITY, ls = 0.f;
     if (tx < ns) {
         ms = sval[tx * ne + DH];
         ls = sval[tx * ne + DH + 1];
     }
-    const float m  = wave_max(ms);
+    const float m  = wave_max_dpp(ms);
     const float w  = (ms == -INFINITY) ? 0.f : __expf(ms - m);
     float*      sw = sval + ns * ne;
     if (tx < ns) {
@@ -771,7 +1086,7 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
             o += sw[s2] * sval[s2 * ne + d];
         }
         const unsigned b0 = f16_bits((f16)(o * inv));
-        const unsigned b1 = __shfl_down(b0, 1, 64);
+        const unsigned b1 = next_lane_u32(b0);
         if ((d & 1) == 0) {
             st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
         }
@@ -798,7 +1113,7 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
                                                const size_t slab, const f16 o, const int c, const bool last)
 {
     const unsigned b0 = f16_bits(o);
-    const unsigned b1 = __shfl_down(b0, 1, 64);
+    const unsigned b1 = next_lane_u32(b0);
     if ((c & 1) == 0) {
         const size_t   gi   = oidx >> 1;
         const unsigned pair = b0 | (b1 << 16);
@@ -835,7 +1150,13 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
 // (see there); a separate instantiation so that the TP = 1 kernel's code is exactly what it was.
 // GROUP (test infrastructure, see engine.hip): all ranks of a LOCAL tensor-parallel group in ONE launch on one device --
 // workgroups [r * nb, (r + 1) * nb) are rank r -- so that every rank's workgroups are resident together by construction.
-template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false>
+// A3 ("attention apart", round 3; one row, short attention form): the attention leaves the streamer waves.  The two control
+// waves request the K rows of the workgroup's KV split by LDS-DMA (64 KiB of LDS, no registers) and its V rows into their own
+// register batches (idle between their P1 and P3 shares), sweep q/k/v, run the whole split on 128 threads and publish the
+// partial; the streamer waves go from the P1 epilogue straight to the mid sweep and the FFN2 stream: their window between
+// the two weight streams is one hop (mid) instead of hop + attention + mid sweep (11.4 -> ~6 us per layer, measured with a
+// timing probe before this was built: profiles/r03_notes.md).
+template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false, bool A3 = false>
 __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     const typename std::conditional<GROUP, PersistGroupParams, PersistParams>::type pa)
 {
@@ -866,7 +1187,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
 #ifndef PS_NOCARRY_ALL
 #define PS_NOCARRY_ALL 0
 #endif
-    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || PS_NOCARRY_ALL;
+#ifndef PS_PART3
+#define PS_PART3 0
+#endif
+    constexpr bool PART3 = PS_PART3 != 0 && M == 1 && !A3;
+    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || A3 || PS_NOCARRY_ALL;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB;
     const int     wid = threadIdx.x >> 6;
@@ -884,6 +1209,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         q += (size_t)p.plan.xs_halves * 2;
         s.part = reinterpret_cast<float*>(q);
         q += (size_t)PS_RMAX * PS_NW * M * 16 * 4;
+        s.part3 = s.part;
+        if constexpr (PART3) {
+            s.part3 = reinterpret_cast<float*>(q);
+            q += (size_t)PS_RMAX * PS_NW * M * 16 * 4;
+        }
         s.att = q;
         q += ps_att_bytes(DH, p.s_max, p.plan.nsplit);
         s.rt1 = reinterpret_cast<RunRec*>(q);
@@ -891,6 +1221,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         s.rt3 = reinterpret_cast<RunRec*>(q);
         q += sizeof(RunRec) * PS_RMAX;
         s.rsc = reinterpret_cast<f16*>(q);
+        q += PS_RMAX * 16 * 2;
+        s.rsc3 = reinterpret_cast<f16*>(q);
         q += PS_RMAX * 16 * 2;
         s.red = reinterpret_cast<float*>(q);
         q += 64 * 4;
@@ -903,6 +1235,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         s.bt1 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * (E1 / PS_U) * 4;
         s.bt3 = reinterpret_cast<unsigned*>(q);
+        q += (size_t)PS_NW * (E3 / PS_U) * 4;
+        s.kbuf = smem + (((size_t)(q - smem) + 1023) & ~(size_t)1023);
     }
     const int      step     = *p.d_step;
     const unsigned tag_base = (unsigned)step * 256u + 1u;
@@ -929,116 +1263,168 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     const int nB = rB1 - rB0, nA = rA1 - rA0;
     const int nruns1 = nq + (f1 - f0), nruns3 = nB + nA;
     const int n_items = p.B * p.nh * p.plan.nsplit;
-    if (threadIdx.x == 0) {
-        s.misc[0]  = 0;
-        s.misc[32] = 0;  // ctx arrival counter (+PS_NC per layer)
-        s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
+    // The run tables and the per-wave tile / batch tables depend on the plan and the workgroup only -- not on the layer, the
+    // token or the request.  Building them took 17.5 us of every launch (0.7 % of a token): the engine now builds them ONCE
+    // per plan with a launch over no layers (tab_mode 1: build, then copy the table region of LDS out) and every real launch
+    // copies them in (tab_mode 2: ~13 KB per workgroup from L2).  tab_mode 0 builds them in place as before.
+    const size_t tab_bytes = (size_t)(reinterpret_cast<char*>(s.bt3 + (size_t)PS_NW * (E3 / PS_U)) - reinterpret_cast<char*>(s.rt1));
+    if (p.tab_mode == 2) {
+        const auto* src = PS_G(u32x4, p.tab + (size_t)bid * tab_bytes);
+        u32x4*      dst = reinterpret_cast<u32x4*>(s.rt1);
+        for (int i = threadIdx.x; i < (int)(tab_bytes / 16); i += PS_NT) {
+            dst[i] = src[i];
+        }
     }
-    __syncthreads();
-    if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
-        const int  j   = threadIdx.x;
-        const bool seg = j >= nq;
-        const int  cg  = seg ? NT0 + f0 + (j - nq) : q0 + j;
-        const int  g   = seg ? cg - NT0 : cg;
-        RunRec     r;
-        r.tile0  = g * KT;
-        r.sel    = seg ? 1 : 0;
-        r.nt     = KT;
-        r.xoff   = seg ? M * (H + XPAD) : 0;
-        r.xsel   = 0;
-        r.rid    = cg;
-        r.grp    = g;
-        r.pad    = 0;
-        s.rt1[j] = r;
-    }
-    if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
-        const int  j     = threadIdx.x;
-        const bool isA   = j >= nB;
-        const int  idx   = isA ? rA0 + (j - nB) : rB0 + j;
-        const int  piece = idx / NG, g = idx % NG;
-        RunRec     r;
-        if (isA) {
-            const int t0 = piece * RLa;
-            r.tile0      = g * KT_a + t0;
-            r.sel        = 1;
-            r.nt         = (KT_a - t0 < RLa) ? KT_a - t0 : RLa;
-            r.xoff       = M * (Il + XPAD) + t0 * TK;
-            r.xsel       = 1;
-            r.rid        = NG * PB + idx;
-            if (piece == PA - 1) {  // owner of a group's last out-proj piece merges the group
-                const int k = atomicAdd(&s.misc[0], 1);
-                if (k < PS_MAXMERGE) {
-                    s.misc[1 + k] = g;
+    else {
+        PsStage sg1{}, sg3{};
+        int     mid_lo = 0, mid_hi = 0, ctx_lo = 0, ctx_hi = 0;
+        if (threadIdx.x == 0) {
+            s.misc[0]  = 0;
+            s.misc[32] = 0;  // ctx arrival counter (+PS_NC per layer)
+            s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
+            s.misc[34] = 0;  // A3: streamer-wave barrier (+(PS_NW - PS_NC) per layer)
+            s.misc[35] = 0;  // A3: control-wave barrier inside the attention
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
+            const int  j   = threadIdx.x;
+            const bool seg = j >= nq;
+            const int  cg  = seg ? NT0 + f0 + (j - nq) : q0 + j;
+            const int  g   = seg ? cg - NT0 : cg;
+            RunRec     r;
+            r.tile0  = g * KT;
+            r.sel    = seg ? 1 : 0;
+            r.nt     = KT;
+            r.xoff   = seg ? M * (H + XPAD) : 0;
+            r.xsel   = 0;
+            r.rid    = cg;
+            r.grp    = g;
+            r.pad    = 0;
+            s.rt1[j] = r;
+        }
+        if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
+            const int  j     = threadIdx.x;
+            const bool isA   = j >= nB;
+            const int  idx   = isA ? rA0 + (j - nB) : rB0 + j;
+            const int  piece = idx / NG, g = idx % NG;
+            RunRec     r;
+            if (isA) {
+                const int t0 = piece * RLa;
+                r.tile0      = g * KT_a + t0;
+                r.sel        = 1;
+                r.nt         = (KT_a - t0 < RLa) ? KT_a - t0 : RLa;
+                r.xoff       = M * (Il + XPAD) + t0 * TK;
+                r.xsel       = 1;
+                r.rid        = NG * PB + idx;
+                if (piece == PA - 1) {  // owner of a group's last out-proj piece merges the group
+                    const int k = atomicAdd(&s.misc[0], 1);
+                    if (k < PS_MAXMERGE) {
+                        s.misc[1 + k] = g;
+                    }
                 }
             }
+            else {
+                const int t0 = piece * RLb;
+                r.tile0      = g * KT_b + t0;
+                r.sel        = 0;
+                r.nt         = (KT_b - t0 < RLb) ? KT_b - t0 : RLb;
+                r.xoff       = t0 * TK;
+                r.xsel       = 0;
+                r.rid        = idx;
+            }
+            r.grp    = g;
+            r.pad    = 0;
+            s.rt3[j] = r;
         }
-        else {
-            const int t0 = piece * RLb;
-            r.tile0      = g * KT_b + t0;
-            r.sel        = 0;
-            r.nt         = (KT_b - t0 < RLb) ? KT_b - t0 : RLb;
-            r.xoff       = t0 * TK;
-            r.xsel       = 0;
-            r.rid        = idx;
+        __syncthreads();
+        {
+            int T1 = 0, T3 = 0;
+            for (int j = 0; j < nruns1; j++) {
+                T1 += s.rt1[j].nt;
+            }
+            bool fb = true, fa = true;
+            for (int j = 0; j < nruns3; j++) {
+                const RunRec r = s.rt3[j];
+                T3 += r.nt;
+                if (r.sel == 0) {
+                    const int lo = r.xoff, hi = r.xoff + r.nt * TK;
+                    mid_lo = fb ? lo : (lo < mid_lo ? lo : mid_lo);
+                    mid_hi = fb ? hi : (hi > mid_hi ? hi : mid_hi);
+                    fb     = false;
+                }
+                else {
+                    const int lo = r.xoff - M * (Il + XPAD), hi = lo + r.nt * TK;
+                    ctx_lo = fa ? lo : (lo < ctx_lo ? lo : ctx_lo);
+                    ctx_hi = fa ? hi : (hi > ctx_hi ? hi : ctx_hi);
+                    fa     = false;
+                }
+            }
+            T1 = ps_rfl(T1);
+            T3 = ps_rfl(T3);
+            mid_lo = ps_rfl(mid_lo);
+            mid_hi = ps_rfl(mid_hi);
+            ctx_lo = ps_rfl(ctx_lo);
+            ctx_hi = ps_rfl(ctx_hi);
+            const int w = ps_rfl(wid);
+            int       tb, te;
+            ps_wave_range(T1, w, p.plan.cs1, tb, te);
+            int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
+            sg1.lt   = s.lt1 + (size_t)w * E1;
+            sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
+            sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+            sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
+            ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
+                                sg1.nrot * PS_U * PS_NBUF);
+            ps_wave_range(T3, w, p.plan.cs3, tb, te);
+            ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
+            sg3.lt   = s.lt3 + (size_t)w * E3;
+            sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
+            sg3.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+            sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
+            ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
+                                sg3.nrot * PS_U * PS_NBUF);
+            sg1.xs0 = sg1.xs1 = H + XPAD;  // LDS rows of x are padded: see XPAD
+            sg3.xs0 = Il + XPAD;
+            sg3.xs1 = Hl + XPAD;
         }
-        r.grp    = g;
-        r.pad    = 0;
-        s.rt3[j] = r;
+        if ((threadIdx.x & 63) == 0) {  // (every later use reads these back from LDS: one source for both modes)
+            s.misc[40 + wid] = sg1.nrot;
+            s.misc[48 + wid] = sg3.nrot;
+        }
+        if (threadIdx.x == 0) {
+            s.misc[56] = mid_lo;
+            s.misc[57] = mid_hi;
+            s.misc[58] = ctx_lo;
+            s.misc[59] = ctx_hi;
+        }
+        if (p.tab_mode == 1) {
+            __syncthreads();
+            auto*        dst = (__attribute__((address_space(1))) u32x4*)(p.tab + (size_t)bid * tab_bytes);
+            const u32x4* src = reinterpret_cast<const u32x4*>(s.rt1);
+            for (int i = threadIdx.x; i < (int)(tab_bytes / 16); i += PS_NT) {
+                dst[i] = src[i];
+            }
+        }
     }
     __syncthreads();
     PsStage sg1{}, sg3{};
-    int     mid_lo = 0, mid_hi = 0, ctx_lo = 0, ctx_hi = 0;  // K ranges (halves) of mid / ctx this workgroup consumes
     {
-        int T1 = 0, T3 = 0;
-        for (int j = 0; j < nruns1; j++) {
-            T1 += s.rt1[j].nt;
-        }
-        bool fb = true, fa = true;
-        for (int j = 0; j < nruns3; j++) {
-            const RunRec r = s.rt3[j];
-            T3 += r.nt;
-            if (r.sel == 0) {
-                const int lo = r.xoff, hi = r.xoff + r.nt * TK;
-                mid_lo = fb ? lo : (lo < mid_lo ? lo : mid_lo);
-                mid_hi = fb ? hi : (hi > mid_hi ? hi : mid_hi);
-                fb     = false;
-            }
-            else {
-                const int lo = r.xoff - M * (Il + XPAD), hi = lo + r.nt * TK;
-                ctx_lo = fa ? lo : (lo < ctx_lo ? lo : ctx_lo);
-                ctx_hi = fa ? hi : (hi > ctx_hi ? hi : ctx_hi);
-                fa     = false;
-            }
-        }
-        T1 = ps_rfl(T1);
-        T3 = ps_rfl(T3);
-        mid_lo = ps_rfl(mid_lo);
-        mid_hi = ps_rfl(mid_hi);
-        ctx_lo = ps_rfl(ctx_lo);
-        ctx_hi = ps_rfl(ctx_hi);
         const int w = ps_rfl(wid);
-        int       tb, te;
-        ps_wave_range(T1, w, p.plan.cs1, tb, te);
-        int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
-        sg1.lt   = s.lt1 + (size_t)w * E1;
-        sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
-        sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
-        sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
-        ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
-                            sg1.nrot * PS_U * PS_NBUF);
-        ps_wave_range(T3, w, p.plan.cs3, tb, te);
-        ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
-        sg3.lt   = s.lt3 + (size_t)w * E3;
-        sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
-        sg3.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
-        sg3.nrot = sg3.nrot < 1 ? 1 : sg3.nrot;
-        ps_build_tables<TK>(s.rt3, nruns3, tb, te, s.lt3 + (size_t)w * E3, s.bt3 + (size_t)w * (E3 / PS_U),
-                            sg3.nrot * PS_U * PS_NBUF);
+        sg1.lt      = s.lt1 + (size_t)w * E1;
+        sg1.bt      = s.bt1 + (size_t)w * (E1 / PS_U);
+        sg3.lt      = s.lt3 + (size_t)w * E3;
+        sg3.bt      = s.bt3 + (size_t)w * (E3 / PS_U);
+        sg1.nrot    = ps_rfl(s.misc[40 + w]);
+        sg3.nrot    = ps_rfl(s.misc[48 + w]);
         sg1.xs0 = sg1.xs1 = H + XPAD;  // LDS rows of x are padded: see XPAD
         sg3.xs0 = Il + XPAD;
         sg3.xs1 = Hl + XPAD;
     }
-    __syncthreads();
+    const int mid_lo = ps_rfl(s.misc[56]), mid_hi = ps_rfl(s.misc[57]);  // K ranges (halves) of mid / ctx this workgroup consumes
+    const int ctx_lo = ps_rfl(s.misc[58]), ctx_hi = ps_rfl(s.misc[59]);
+    if (p.tab_mode == 1) {
+        return;  // the launch that only builds the tables
+    }
 
     // Control waves and streamer waves run SEPARATE instantiations of the layer loop (same barriers, in the same order):
     // with a shared body the register batches of the role that primes early stay live, as far as the compiler can tell,
@@ -1052,6 +1438,23 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             if (p.ts && lane == 0) {
                 p.ts[(((size_t)bid * p.L + l) * PS_NW + wid) * 16 + k] = wall_clock64();
             }
+        };
+        // A3: barrier of the control waves among themselves (LDS counter; DS operations of a wave execute in order)
+        int  cb_want      = 0;
+        auto ctrl_barrier = [&]() {
+            cb_want += PS_NC;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((tid & 63) == 0) {
+                atomicAdd(&s.misc[35], 1);
+            }
+            for (int spins = 0; ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[35]) < cb_want;) {
+                if (++spins > (PS_SPIN << 6)) {  // (bounded like every other wait of this kernel)
+                    __hip_atomic_store(p.err, 11, PS_RLX, PS_AGT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
         f16   r_sc1 = (f16)1.f, r_sc3 = (f16)1.f;  // scale of (run tid/16, column tid%16) of P1 / P3
@@ -1147,17 +1550,26 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         };
         auto setup_p3 = [&](const int l) {
             PsLayerC& lw = PS_LAYER(p, l);
-            if constexpr (INT8) {
-                if (tid < nruns3 * 16) {
-                    s.rsc[tid] = r_sc3;
+            if constexpr (A3 || PART3) {
+                // no workgroup barrier between here and the P3 stream: a wave zeroes the slots it flushes itself (the scales
+                // were stored before the barrier that ended P1)
+                for (int i = tid & 63; i < nruns3 * M * 16; i += 64) {
+                    s.part3[((size_t)(i / (M * 16)) * PS_NW + (tid >> 6)) * (M * 16) + i % (M * 16)] = 0.f;
                 }
             }
-            for (int i = tid; i < nruns3 * PS_NW * M * 16; i += PS_NT) {
-                s.part[i] = 0.f;
+            else {
+                if constexpr (INT8) {
+                    if (tid < nruns3 * 16) {
+                        s.rsc[tid] = r_sc3;
+                    }
+                }
+                for (int i = tid; i < nruns3 * PS_NW * M * 16; i += PS_NT) {
+                    s.part[i] = 0.f;
+                }
             }
             sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
             sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
-            st.bind(sg3, s.rsc, s.xs, s.part, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
+            st.bind(sg3, (A3 || PART3) ? s.rsc3 : s.rsc, s.xs, s.part3, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
         };
 
         load_sc1(p.l_begin);
@@ -1169,6 +1581,19 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             const int           lane = tid & 63, wid = tid >> 6;
             PsLayerC& lw  = PS_LAYER(p, l);
             const unsigned      tag = tag_base + (unsigned)l;
+            static_assert(!A3 || (M == 1 && UK == PS_U), "A3: one row, short attention form");
+            constexpr bool      A3F = A3;
+#ifndef PS_A3_KV_LATE
+#define PS_A3_KV_LATE 0
+#endif
+            // A3: the K/V rows are requested when the control waves have finished their P1 share (their register batches are
+            // free from there to their P3 share, and the rows land under the streamer waves' P1 tail), not next to the
+            // q/k/v polls, which would return behind them
+            using AttnA = PsAttn<DH, UK, PS_NC * 64>;
+            AttnA      at3;
+            const bool i_has = bid < n_items;
+            const int  i_sp = i_has ? bid % p.plan.nsplit : 0;
+            const int  i_h = i_has ? (bid / p.plan.nsplit) % p.nh : 0, i_b = i_has ? (bid / p.plan.nsplit) / p.nh : 0;
             stamp(l, 0);
             // =========================== S0: layer input -> xraw (control waves) =================================
             if constexpr (CTRL) {
@@ -1206,8 +1631,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                             }
                         }
                     }
-                    s0[m] = wave_sum(s0[m]);
-                    s1[m] = wave_sum(s1[m]);
+                    s0[m] = wave_sum_dpp(s0[m]);
+                    s1[m] = wave_sum_dpp(s1[m]);
                     if (lane == 0) {
                         s.red[(m * PS_NW + wid) * 2]     = s0[m];
                         s.red[(m * PS_NW + wid) * 2 + 1] = s1[m];
@@ -1248,6 +1673,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 stamp(l, 2);
                 __syncthreads();
                 st.template run<CTRL || !PS_FULL_P1>();
+                if constexpr (A3F && CTRL && !PS_A3_KV_LATE) {
+                    at3.issue_ctrl(p, lw, i_h, i_b, i_sp, tid, st,
+                                   (unsigned)(size_t)(__attribute__((address_space(3))) char*)s.kbuf, i_has);
+                }
                 stamp(l, 3);
                 __syncthreads();
                 // epilogue: qkv = y (bias is added by the attention), mid = gelu(y + b) ; pairs of halves -> granules
@@ -1275,7 +1704,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                             }
                         }
                         const unsigned b0 = f16_bits(o);
-                        const unsigned b1 = __shfl_down(b0, 1, 64);
+                        const unsigned b1 = next_lane_u32(b0);
                         if ((c & 1) == 0) {
                             // (two stores, not one through a selected pointer: the compiler turns that select into a
                             // table in scratch memory, and a kernel that uses scratch pays for it at every dispatch)
@@ -1288,6 +1717,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                         }
                     }
                 }
+                if constexpr ((A3 || PART3) && INT8) {
+                    if (tid < nruns3 * 16) {
+                        s.rsc3[tid] = r_sc3;
+                    }
+                }
                 stamp(l, 4);
             }
 
@@ -1295,7 +1729,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             asm volatile("" : "+v"(tid));
             // (EARLY: see PS_EARLY_P3; the long form's K/V rows occupy the register batches)
             constexpr int EARLY = (UK > PS_U) ? 0 : PS_EARLY_P3;
-            using Attn          = PsAttn<DH, UK, EARLY ? PS_NC * 64 : 3 * DH / 2>;
+            using Attn          = PsAttn<DH, UK, (EARLY || A3F) ? PS_NC * 64 : 3 * DH / 2>;
             Attn       at;
             const bool has_item = bid < n_items;
             int        a_sp = 0, a_h = 0, a_b = 0;
@@ -1305,7 +1739,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 a_h          = hb % p.nh;
                 a_b          = hb / p.nh;
             }
-            __syncthreads();  // part / scales reuse
+            if constexpr (!PART3) {
+                __syncthreads();  // part / scales reuse
+            }
             setup_p3(l);
             stamp(l, 5);
             bool live = false;
@@ -1316,7 +1752,51 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 // here all four weight batches, around the layer loop: 30 spilled VGPRs)
                 at.issue(p, lw, a_h, a_b, a_sp, tid, st);
             }
-            if constexpr (EARLY != 0) {
+            if constexpr (A3F) {
+                if constexpr (CTRL) {
+                    if constexpr (PS_A3_KV_LATE) {
+                        at3.issue_ctrl(p, lw, a_h, a_b, a_sp, tid, st,
+                                       (unsigned)(size_t)(__attribute__((address_space(3))) char*)s.kbuf, has_item);
+                    }
+                    if (has_item) {
+                        __builtin_amdgcn_s_setprio(2);  // (the streamer wave on this SIMD is in its weight stream)
+                        at3.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
+                        stamp(l, 6);
+                        ps_wait_vm<0>();  // this wave's K blocks have landed in LDS (the compiler does not know about them)
+                        live = at3.compute_ctrl(p, lw, s.att, s.kbuf, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st,
+                                                ctrl_barrier);
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                    stamp(l, 7);
+                }
+                else {
+                    // the streamer waves stage the K range of mid themselves and synchronise among themselves
+                    const int stid = tid - PS_NC * 64;
+                    ps_sweep<4>(p.gm + ((size_t)mid_lo >> 1), (mid_hi - mid_lo) >> 1, stid, (PS_NW - PS_NC) * 64, tag, p.err, 6,
+                                [&](const int i, const unsigned v) { reinterpret_cast<unsigned*>(s.xs + mid_lo)[i] = v; });
+                    stamp(l, 7);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        atomicAdd(&s.misc[34], 1);
+                    }
+                    const int want = (l - p.l_begin + 1) * (PS_NW - PS_NC);
+                    for (int spins = 0; ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[34]) < want;) {
+                        if (++spins > (PS_SPIN << 6)) {
+                            __hip_atomic_store(p.err, 12, PS_RLX, PS_AGT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    stamp(l, 8);
+                    load_p3_consts(l);
+                    st.prime_lo();
+                    if constexpr (PS_FULL_P3) {
+                        st.prime_hi();
+                    }
+                }
+            }
+            else if constexpr (EARLY != 0) {
                 if (has_item) {
                     at.issue(p, lw, a_h, a_b, a_sp, tid, st);
                 }
@@ -1343,32 +1823,54 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 stamp(l, 6);
                 live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
             }
-            if constexpr (CTRL) {
-                // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there).
-                // Before the barrier, i.e. before the streamer waves' prefetch burst (a sweep queued behind the burst
-                // took 5 us), and after the attention (ahead of it, it made the attention wait for the slowest FFN1)
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
-                                 p.err, 6, [&](const int i, const unsigned v) {
-                                     reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
-                                 });
-                }
-            }
-            stamp(l, 7);
-            __syncthreads();  // mid staged, attention scratch free
-            stamp(l, 8);
-            if constexpr (!CTRL) {
-                // (the constants of the layer's end -- residual bias, next layer's scales -- are fetched HERE and not in
-                // the P3 set-up: their table reads are synchronous round trips, and the set-up sits on the attention's
-                // critical path, ahead of the K/V request)
-                load_p3_consts(l);
-                // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
-                // and the control waves, which carry the attention's critical path, must not wait for it
-                if constexpr (EARLY == 0) {
-                    st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
-                    if constexpr (PS_FULL_P3) {
+            if constexpr (!A3F) {
+#ifndef PS_MID_ALL
+#define PS_MID_ALL 1
+#endif
+                // the K range of mid this workgroup's FFN2 pieces read -> LDS (published at the end of P1: long there), after
+                // the attention (ahead of it, it made the attention wait for the slowest FFN1).
+                // PS_MID_ALL 0: by the control waves, before the barrier, i.e. before the streamer waves' prefetch burst;
+                // >= 1: by all eight waves (a quarter of the passes per thread); 2 / 3: the streamer waves request half /
+                // all of their first rotation BEFORE their part of the sweep (their polls return behind it, when it has landed)
+                if constexpr (PS_MID_ALL >= 2 && !CTRL && EARLY == 0) {
+                    st.prime_lo();
+                    if constexpr (PS_MID_ALL == 3) {
                         st.prime_hi();
+                    }
+                }
+                if constexpr (PS_MID_ALL >= 1) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        ps_sweep<3>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NT, tag, p.err, 6,
+                                    [&](const int i, const unsigned v) {
+                                        reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
+                                    });
+                    }
+                }
+                else if constexpr (CTRL) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        ps_sweep<10>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NC * 64, tag,
+                                     p.err, 6, [&](const int i, const unsigned v) {
+                                         reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
+                                     });
+                    }
+                }
+                stamp(l, 7);
+                __syncthreads();  // mid staged, attention scratch free
+                stamp(l, 8);
+                if constexpr (!CTRL) {
+                    // (the constants of the layer's end -- residual bias, next layer's scales -- are fetched HERE and not in
+                    // the P3 set-up: their table reads are synchronous round trips, and the set-up sits on the attention's
+                    // critical path, ahead of the K/V request)
+                    load_p3_consts(l);
+                    // AFTER the barrier: issuing 32 KiB per wave takes ~5 us (the CU's memory pipeline throttles the issue)
+                    // and the control waves, which carry the attention's critical path, must not wait for it
+                    if constexpr (EARLY == 0 && PS_MID_ALL < 2) {
+                        st.prime_lo();  // the streamer waves issue no other load until the end of the P3 stream
+                        if constexpr (PS_FULL_P3) {
+                            st.prime_hi();
+                        }
                     }
                 }
             }
@@ -1412,7 +1914,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 }
             }
             stamp(l, 9);
-            st.template run<CTRL ? (PS_CTRL_EARLY != 2) : (EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
+            st.template run<CTRL ? (PS_CTRL_EARLY != 2) : ((!A3F && PS_MID_ALL >= 2) ? PS_MID_ALL != 3 : EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));
@@ -1425,13 +1927,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     float     v = 0.f;
 #pragma unroll
                     for (int w = 0; w < PS_NW; w++) {
-                        v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                        v += s.part3[((size_t)j * PS_NW + w) * (M * 16) + r];
                     }
                     st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
                 }
             }
             const int  nmerge = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
             const bool last   = (l == p.l_end - 1);
+            const bool lm_tail = !TP && p.lm_w != nullptr && p.l_end == p.L;  // the LM head follows in this launch
             // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
             const int inplace = (l > 0 && l < p.L - 1) ? 1 : 0;
             __syncthreads();  // part / scales are free: the streamer waves start the next layer's weight stream now
@@ -1501,12 +2004,12 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                         if constexpr (TP) {
                             ps_tp_exchange(p, tag, oidx, (size_t)M * H / 2, o, c, last);
                         }
-                        else if (last) {
+                        else if (last && !lm_tail) {
                             p.x_out[oidx] = o;
                         }
                         else {
                             const unsigned b0 = f16_bits(o);
-                            const unsigned b1 = __shfl_down(b0, 1, 64);
+                            const unsigned b1 = next_lane_u32(b0);
                             if ((c & 1) == 0) {
                                 st_granule_u32(&p.gx[oidx >> 1], tag, b0 | (b1 << 16));
                             }
@@ -1534,6 +2037,175 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 while (ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[33]) < want) {
                     __builtin_amdgcn_s_sleep(1);
                 }
+            }
+        }
+        // =========================== LM head (the launch that ran the last layer, one GPU) =============================
+        // final LayerNorm + logits = h . W^T over the [V][H] fp16 tensor, read in place (GptNeoX.cc:853-925; the same
+        // arithmetic as k_lm_head: lanes along k, 8 halves per lane and 512-half step, dot2 chains in k order, the same
+        // wave sum).  A workgroup takes V / NB consecutive rows, its waves consecutive row ranges: a wave's share is ONE
+        // contiguous byte range, streamed through the same four register batches as the weights; the streamer waves request
+        // their first rotation right here, while the control waves still merge and gather the last layer's x'.
+        if constexpr (!TP) {
+            if (p.lm_w != nullptr && p.l_end == p.L) {
+                asm volatile("" : "+v"(tid));
+                const int lane = tid & 63;
+                const int w    = ps_rfl(tid >> 6);
+                const int KL   = H / 512;  // wave-loads per row (the host checks H % 512 == 0)
+                const int V    = p.lm_rows;
+                const int wr0 = (int)((long)V * bid / NB), wr1 = (int)((long)V * (bid + 1) / NB);
+                const int ra = wr0 + (int)((long)(wr1 - wr0) * w / PS_NW), rb = wr0 + (int)((long)(wr1 - wr0) * (w + 1) / PS_NW);
+                const int nl = (rb - ra) * KL;  // wave-loads of this wave (may be 0)
+                const int nb = (nl + PS_U - 1) / PS_U;
+                const auto* base = (const __attribute__((address_space(1))) char*)p.lm_w
+                                   + (size_t)(ra < V ? ra : V - 1) * H * 2 + (size_t)lane * 16;
+                auto lm_load = [&](u32x4 (&r)[PS_U], const int b) {
+#pragma unroll
+                    for (int u = 0; u < PS_U; u++) {
+                        int n = b * PS_U + u;
+                        n     = n < nl ? n : (nl > 0 ? nl - 1 : 0);  // (padding: re-reads of the wave's last KiB, never consumed)
+                        r[u]  = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4*)(base + (size_t)n * 1024));
+                    }
+                };
+                const f16* hx = s.xs;  // [M][H + XPAD] normalised hidden state
+                float      lacc[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    lacc[m] = 0.f;
+                }
+                int  ci = 0, row = ra;
+                auto lm_consume = [&](const u32x4 (&r)[PS_U], const int b) {
+#pragma unroll
+                    for (int u = 0; u < PS_U; u++) {
+                        if (b * PS_U + u < nl) {  // (uniform)
+                            const f16x8 wv = __builtin_bit_cast(f16x8, r[u]);
+#pragma unroll
+                            for (int m = 0; m < M; m++) {
+                                const f16x8 xv = *reinterpret_cast<const f16x8*>(hx + (size_t)m * (H + XPAD) + ci * 512 + lane * 8);
+                                float       a  = lacc[m];
+                                a              = dot2(f16x2{wv[0], wv[1]}, f16x2{xv[0], xv[1]}, a);
+                                a              = dot2(f16x2{wv[2], wv[3]}, f16x2{xv[2], xv[3]}, a);
+                                a              = dot2(f16x2{wv[4], wv[5]}, f16x2{xv[4], xv[5]}, a);
+                                a              = dot2(f16x2{wv[6], wv[7]}, f16x2{xv[6], xv[7]}, a);
+                                lacc[m]        = a;
+                            }
+                            if (++ci == KL) {
+#pragma unroll
+                                for (int m = 0; m < M; m++) {
+                                    const float v = wave_sum(lacc[m]);
+                                    if (lane == 0) {
+                                        p.lm_logits[(size_t)m * p.lm_ldc + row] = v;
+                                    }
+                                    lacc[m] = 0.f;
+                                }
+                                ci = 0;
+                                row++;
+                            }
+                        }
+                    }
+                };
+                if constexpr (!CTRL) {
+                    lm_load(st.R0, 0);
+                    lm_load(st.R1, 1);
+                    lm_load(st.R2, 2);
+                    lm_load(st.R3, 3);
+                }
+                f16x8 fg[PS_NLN], fb[PS_NLN];
+#pragma unroll
+                for (int k = 0; k < PS_NLN; k++) {
+                    const int v = tid + k * PS_NT;
+                    const int o = (v * 8 < H) ? v * 8 : 0;
+                    fg[k]       = *PS_G(f16x8, p.lm_g + o);
+                    fb[k]       = *PS_G(f16x8, p.lm_b + o);
+                }
+                if constexpr (CTRL) {
+                    ps_sweep<20>(p.gx, M * H / 2, tid, PS_NC * 64, tag_base + (unsigned)(p.L - 1), p.err, 13,
+                                [&](const int i, const unsigned v) { reinterpret_cast<unsigned*>(s.xraw)[i] = v; });
+                }
+                __syncthreads();
+                {  // final LayerNorm (layernorm_kernels.cu:157-286 arithmetic, like the layers' and k_lm_head's)
+                    float s0[M], s1[M];
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        s0[m] = 0.f;
+                        s1[m] = 0.f;
+#pragma unroll
+                        for (int k = 0; k < PS_NLN; k++) {
+                            const int v = tid + k * PS_NT;
+                            if (v * 8 < H) {
+                                const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
+#pragma unroll
+                                for (int e = 0; e < 8; e++) {
+                                    const float f = (float)x8[e];
+                                    s0[m] += f;
+                                    s1[m] += f * f;
+                                }
+                            }
+                        }
+                        s0[m] = wave_sum_dpp(s0[m]);
+                        s1[m] = wave_sum_dpp(s1[m]);
+                        if (lane == 0) {
+                            s.red[(m * PS_NW + (tid >> 6)) * 2]     = s0[m];
+                            s.red[(m * PS_NW + (tid >> 6)) * 2 + 1] = s1[m];
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int w2 = 0; w2 < PS_NW; w2++) {
+                            a0 += s.red[(m * PS_NW + w2) * 2];
+                            a1 += s.red[(m * PS_NW + w2) * 2 + 1];
+                        }
+                        const float mean = a0 / (float)H;
+                        const float rstd = rsqrtf(a1 / (float)H - mean * mean + p.eps);
+                        const f16   mh = (f16)mean, rh = (f16)rstd;
+#pragma unroll
+                        for (int k = 0; k < PS_NLN; k++) {
+                            const int v = tid + k * PS_NT;
+                            if (v * 8 < H) {
+                                const f16x8 x8 = *reinterpret_cast<const f16x8*>(s.xraw + (size_t)m * H + v * 8);
+                                f16x8       o1;
+#pragma unroll
+                                for (int e = 0; e < 8; e++) {
+                                    o1[e] = (((x8[e] - mh) * rh) * fg[k][e]) + fb[k][e];
+                                }
+                                *reinterpret_cast<f16x8*>(s.xs + (size_t)m * (H + XPAD) + v * 8) = o1;
+                            }
+                        }
+                    }
+                }
+                if constexpr (CTRL) {
+                    lm_load(st.R0, 0);
+                    lm_load(st.R1, 1);
+                    lm_load(st.R2, 2);
+                    lm_load(st.R3, 3);
+                }
+                __syncthreads();
+                const int lastb = ((nb + PS_NBUF - 1) / PS_NBUF - 1) * PS_NBUF;  // (nb = 0: one rotation of padding)
+                for (int i = 0; i < (lastb < 0 ? 0 : lastb); i += PS_NBUF) {
+                    lm_consume(st.R0, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_load(st.R0, i + 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_consume(st.R1, i + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_load(st.R1, i + 5);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_consume(st.R2, i + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_load(st.R2, i + 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_consume(st.R3, i + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lm_load(st.R3, i + 7);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int lb = lastb < 0 ? 0 : lastb;
+                lm_consume(st.R0, lb);
+                lm_consume(st.R1, lb + 1);
+                lm_consume(st.R2, lb + 2);
+                lm_consume(st.R3, lb + 3);
             }
         }
     };

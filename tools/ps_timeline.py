@@ -8,12 +8,12 @@ NB, L, W, K = np.frombuffer(raw[:16], dtype=np.int32)
 ts = np.frombuffer(raw[16:], dtype=np.int64).reshape(NB, L, W, K).astype(np.float64) / 100.0  # us (100 MHz)
 names = ["layer top", "x gathered", "LN done (+ctrl prime)", "P1 run end", "P1 epilogue out", "P3 set up", "qkv swept",
          "attn computed", "barrier after attn", "P3 primed (ctrl: ctx swept+primed)", "P3 run end",
-         "pieces out + next setup", "x' merged", "attn merged (split-0 wgs)", "ctx swept"]
+         "pieces out + next setup", "x' merged", "attn merged (split-0 wgs)", "ctx swept", "partials swept (split-0 wgs)"]
 lay = int(sys.argv[2]) if len(sys.argv) > 2 else L // 2
 t0 = ts[:, lay, :, 0].min()
 print(f"--- layer {lay}: us since the first wave entered the layer; median over workgroups (max in brackets) per wave ---")
 print(f"{'':<36}" + "".join(f"   wave{w:<8d}" for w in range(W)))
-for k in range(15):
+for k in range(16 if lay > 0 else 15):
     row = []
     for w in range(W):
         v = ts[:, lay, w, k]
