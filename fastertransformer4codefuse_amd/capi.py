@@ -17,6 +17,8 @@ class FtcfError(RuntimeError):
 
 
 TOKEN_CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p)
+# ftcf_host_allgather_fn (include/ftcf.h): int (*)(void* user, const void* send, void* recv, size_t bytes_per_rank)
+HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class GptNeoXConfig(C.Structure):
@@ -66,7 +68,7 @@ EXPORTED = [
     "ftcf_fpA_intB_gemm", "ftcf_fp16_gemm", "ftcf_lm_head", "ftcf_layernorm", "ftcf_add_bias_attn_ffn_residual",
     "ftcf_masked_multihead_attention", "ftcf_masked_multihead_attention_workspace", "ftcf_context_attention",
     "ftcf_comm_get_unique_id", "ftcf_comm_init", "ftcf_comm_destroy", "ftcf_comm_local_unique_id",
-    "ftcf_comm_init_local", "ftcf_comm_allreduce_sum",
+    "ftcf_comm_init_local", "ftcf_comm_init_host_exchange", "ftcf_comm_allreduce_sum",
     "ftcf_comm_allgather", "ftcf_gptneox_create", "ftcf_gptneox_forward", "ftcf_gptneox_begin", "ftcf_gptneox_step", "ftcf_gptneox_finish",
     "ftcf_gptneox_get_stats",
     "ftcf_gptneox_set_profiling", "ftcf_gptneox_destroy",

@@ -111,6 +111,10 @@ struct LocalGroup {
 struct ftcf_comm {
     ncclComm_t                  comm = nullptr;
     std::shared_ptr<LocalGroup> local;
+    // host-exchange communicator (ftcf_comm_init_host_exchange): every exchange is an all-gather of host bytes by the caller
+    ftcf_host_allgather_fn      hx = nullptr;
+    void*                       hx_user = nullptr;
+    std::vector<char>           hx_send, hx_recv;
     int                         world = 1, rank = 0, device = 0;
     void*                       tmp = nullptr;  // local group: result buffer of the emulated all-reduce
     size_t                      tmp_bytes = 0;
@@ -128,6 +132,79 @@ struct ftcf_comm {
             throw Error(FTCF_ERR_COMM, std::string("RCCL error ") + ncclGetErrorString(_r) + " (" #expr ")");          \
         }                                                                                                              \
     } while (0)
+
+// ---- host-exchange communicator: all-gather of host bytes through the caller, collectives staged through host memory ----
+static void hx_allgather(ftcf_comm* c, const void* send, void* recv, size_t bytes)
+{
+    if (c->hx(c->hx_user, send, recv, bytes) != 0) {
+        throw Error(FTCF_ERR_COMM, "host-exchange communicator: the caller's all-gather failed");
+    }
+}
+static void hx_barrier(ftcf_comm* c)
+{
+    int              z = 0;
+    std::vector<int> all(c->world);
+    hx_allgather(c, &z, all.data(), sizeof(int));
+}
+// min (op 0) / max (op 1) of one int over the ranks
+static int hx_reduce_int(ftcf_comm* c, int v, int op)
+{
+    std::vector<int> all(c->world);
+    hx_allgather(c, &v, all.data(), sizeof(int));
+    int r = v;
+    for (int x : all) {
+        r = op ? std::max(r, x) : std::min(r, x);
+    }
+    return r;
+}
+// sum of a device buffer over the ranks: fp32 in rank order, rounded once -- the same bits on every rank
+static void hx_allreduce(ftcf_comm* c, void* buf, size_t count, bool fp16, hipStream_t s)
+{
+    const size_t bytes = count * (fp16 ? 2 : 4);
+    c->hx_send.resize(bytes);
+    c->hx_recv.resize(bytes * c->world);
+    FTCF_HIP_CHECK(hipMemcpyAsync(c->hx_send.data(), buf, bytes, hipMemcpyDeviceToHost, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    hx_allgather(c, c->hx_send.data(), c->hx_recv.data(), bytes);
+    if (fp16) {
+        const f16* all = reinterpret_cast<const f16*>(c->hx_recv.data());
+        f16*       out = reinterpret_cast<f16*>(c->hx_send.data());
+#pragma omp parallel for
+        for (long i = 0; i < (long)count; i++) {
+            float a = 0.f;
+            for (int r = 0; r < c->world; r++) {
+                a += (float)all[(size_t)r * count + i];
+            }
+            out[i] = (f16)a;
+        }
+    }
+    else {
+        const float* all = reinterpret_cast<const float*>(c->hx_recv.data());
+        float*       out = reinterpret_cast<float*>(c->hx_send.data());
+#pragma omp parallel for
+        for (long i = 0; i < (long)count; i++) {
+            float a = 0.f;
+            for (int r = 0; r < c->world; r++) {
+                a += all[(size_t)r * count + i];
+            }
+            out[i] = a;
+        }
+    }
+    FTCF_HIP_CHECK(hipMemcpyAsync(buf, c->hx_send.data(), bytes, hipMemcpyHostToDevice, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+}
+// in place: rank r's segment lives at offset r of buf
+static void hx_allgather_device(ftcf_comm* c, void* buf, size_t count_per_rank, size_t esz, hipStream_t s)
+{
+    const size_t seg = count_per_rank * esz;
+    c->hx_send.resize(seg);
+    c->hx_recv.resize(seg * c->world);
+    FTCF_HIP_CHECK(hipMemcpyAsync(c->hx_send.data(), (const char*)buf + (size_t)c->rank * seg, seg, hipMemcpyDeviceToHost, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+    hx_allgather(c, c->hx_send.data(), c->hx_recv.data(), seg);
+    FTCF_HIP_CHECK(hipMemcpyAsync(buf, c->hx_recv.data(), seg * c->world, hipMemcpyHostToDevice, s));
+    FTCF_HIP_CHECK(hipStreamSynchronize(s));
+}
 
 // Host wait on a stream that carries RCCL work (utils/nccl_utils.cc:215-272, ftNcclStreamSynchronize): instead of blocking
 // in hipStreamSynchronize -- where a dead or hung peer hangs this rank for good -- poll the stream and the communicator's
@@ -336,6 +413,11 @@ static void comm_barrier(ftcf_comm* c, hipStream_t s, int* d_scratch)
         c->local->barrier();
         return;
     }
+    if (c->hx) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        hx_barrier(c);
+        return;
+    }
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
     comm_stream_sync(c, s, "a tensor-parallel collective");
 }
@@ -343,6 +425,10 @@ static void comm_barrier(ftcf_comm* c, hipStream_t s, int* d_scratch)
 // all-reduce (min) of a host flag over the communicator
 static int comm_agree(ftcf_comm* c, int flag, hipStream_t s, int* d_scratch)
 {
+    if (c->hx) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        return hx_reduce_int(c, flag, 0);
+    }
     FTCF_HIP_CHECK(hipMemcpyAsync(d_scratch, &flag, sizeof(int), hipMemcpyHostToDevice, s));
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMin, c->comm, s));
     int out = 0;
@@ -365,6 +451,10 @@ static int comm_max(ftcf_comm* c, int v, hipStream_t s, int* d_scratch)
         }
         g.barrier();
         return m;
+    }
+    if (c->hx) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        return hx_reduce_int(c, v, 1);
     }
     FTCF_HIP_CHECK(hipMemcpyAsync(d_scratch, &v, sizeof(int), hipMemcpyHostToDevice, s));
     FTCF_NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, 1, ncclInt32, ncclMax, c->comm, s));
@@ -436,10 +526,16 @@ static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
     std::vector<Rec> recs(c->world);
     Rec*             d_recs = nullptr;
     FTCF_HIP_CHECK(hipMalloc((void**)&d_recs, sizeof(Rec) * c->world));
-    FTCF_HIP_CHECK(hipMemcpyAsync(d_recs + c->rank, &me, sizeof(Rec), hipMemcpyHostToDevice, s));
-    FTCF_NCCL_CHECK(ncclAllGather(d_recs + c->rank, d_recs, sizeof(Rec), ncclChar, c->comm, s));
-    FTCF_HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs, sizeof(Rec) * c->world, hipMemcpyDeviceToHost, s));
-    comm_stream_sync(c, s, "a tensor-parallel collective");
+    if (c->hx) {
+        FTCF_HIP_CHECK(hipStreamSynchronize(s));
+        hx_allgather(c, &me, recs.data(), sizeof(Rec));
+    }
+    else {
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_recs + c->rank, &me, sizeof(Rec), hipMemcpyHostToDevice, s));
+        FTCF_NCCL_CHECK(ncclAllGather(d_recs + c->rank, d_recs, sizeof(Rec), ncclChar, c->comm, s));
+        FTCF_HIP_CHECK(hipMemcpyAsync(recs.data(), d_recs, sizeof(Rec) * c->world, hipMemcpyDeviceToHost, s));
+        comm_stream_sync(c, s, "a tensor-parallel collective");
+    }
     int ok = 1;
     for (int r = 0; r < c->world; r++) {
         ok &= recs[r].ok;
@@ -578,6 +674,25 @@ extern "C" int ftcf_comm_init(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_
     });
 }
 
+extern "C" int ftcf_comm_init_host_exchange(int world_size, int rank, int device, ftcf_host_allgather_fn allgather, void* user,
+                                            ftcf_comm_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(out != nullptr && allgather != nullptr && world_size >= 1 && rank >= 0 && rank < world_size,
+                       "bad communicator args");
+        require_device();
+        FTCF_HIP_CHECK(hipSetDevice(device));
+        auto c     = std::make_unique<ftcf_comm>();
+        c->world   = world_size;
+        c->rank    = rank;
+        c->device  = device;
+        c->hx      = allgather;
+        c->hx_user = user;
+        hx_barrier(c.get());  // every rank is up and the callback works
+        *out = c.release();
+    });
+}
+
 extern "C" int ftcf_comm_destroy(ftcf_comm_t c)
 {
     return guarded([&] {
@@ -599,9 +714,13 @@ extern "C" int ftcf_comm_destroy(ftcf_comm_t c)
 extern "C" int ftcf_comm_allreduce_sum(ftcf_comm_t c, void* buf, size_t count, ftcf_dtype dtype, void* stream)
 {
     return guarded([&] {
-        FTCF_CHECK_ARG(c && (c->comm || c->local), "communicator not initialised");
+        FTCF_CHECK_ARG(c && (c->comm || c->local || c->hx), "communicator not initialised");
         if (c->local) {
             local_allreduce(c, buf, count, dtype == FTCF_FP16, (hipStream_t)stream);
+            return;
+        }
+        if (c->hx) {
+            hx_allreduce(c, buf, count, dtype == FTCF_FP16, (hipStream_t)stream);
             return;
         }
         FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, dtype == FTCF_FP16 ? ncclFloat16 : ncclFloat32, ncclSum,
@@ -612,9 +731,13 @@ extern "C" int ftcf_comm_allreduce_sum(ftcf_comm_t c, void* buf, size_t count, f
 extern "C" int ftcf_comm_allgather(ftcf_comm_t c, void* buf, size_t count_per_rank, ftcf_dtype dtype, void* stream)
 {
     return guarded([&] {
-        FTCF_CHECK_ARG(c && (c->comm || c->local), "communicator not initialised");
+        FTCF_CHECK_ARG(c && (c->comm || c->local || c->hx), "communicator not initialised");
         if (c->local) {
             local_allgather(c, buf, count_per_rank, dtype == FTCF_FP16, (hipStream_t)stream);
+            return;
+        }
+        if (c->hx) {
+            hx_allgather_device(c, buf, count_per_rank, dtype == FTCF_FP16 ? 2 : 4, (hipStream_t)stream);
             return;
         }
         const size_t esz = dtype == FTCF_FP16 ? 2 : 4;
@@ -1057,7 +1180,7 @@ struct ftcf_gptneox {
                 d_players   = c.take<PersistLayer>(L);
                 ps_tab      = c.take<char>(persist_table_bytes(pplan) * pplan.NB);
                 ps_tab_ready = false;
-                static const int lm_env = getenv("FTCF_PERSIST_LM") ? atoi(getenv("FTCF_PERSIST_LM")) : 1;
+                static const int lm_env = persist_lm_tail_built() && getenv("FTCF_PERSIST_LM") ? atoi(getenv("FTCF_PERSIST_LM")) : 0;
                 ps_lm_fused = lm_env != 0 && tpn == 1 && H % 512 == 0;
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
@@ -1132,9 +1255,13 @@ struct ftcf_gptneox {
     {
         if (cfg.tensor_para_size > 1) {
             Range r("ftcf.allreduce");
-            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local), "tensor_para_size > 1 needs a communicator");
+            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local || cfg.comm->hx), "tensor_para_size > 1 needs a communicator");
             if (cfg.comm->local) {
                 local_allreduce(cfg.comm, buf, count, true, stream);
+                return;
+            }
+            if (cfg.comm->hx) {
+                hx_allreduce(cfg.comm, buf, count, true, stream);
                 return;
             }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, stream));
@@ -1151,9 +1278,13 @@ struct ftcf_gptneox {
     {
         if (cfg.tensor_para_size > 1) {
             Range r("ftcf.allreduce");
-            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local), "tensor_para_size > 1 needs a communicator");
+            FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local || cfg.comm->hx), "tensor_para_size > 1 needs a communicator");
             if (cfg.comm->local) {
                 local_allreduce(cfg.comm, buf, count, false, stream);
+                return;
+            }
+            if (cfg.comm->hx) {
+                hx_allreduce(cfg.comm, buf, count, false, stream);
                 return;
             }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum, cfg.comm->comm, stream));
@@ -2054,6 +2185,9 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
             if (cfg.comm->local) {
                 local_allgather(cfg.comm, gather, (size_t)B * vl, false, stream);
             }
+            else if (cfg.comm->hx) {
+                hx_allgather_device(cfg.comm, gather, (size_t)B * vl, 4, stream);
+            }
             else {
                 FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
             }
@@ -2091,7 +2225,7 @@ int ftcf_gptneox::step(int max_steps)
         const bool with_decoder = !(S > 1 && step == S);
         // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
         // has been validated on a multi-GPU node (this round's boxes have one GPU)
-        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local)) && !a.debug_logits;
+        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local && !cfg.comm->hx)) && !a.debug_logits;
         if (graph_ok) {
             if (!ses.graph_exec) {
                 // capture ONE regular decode step (all pointers are fixed for the session, the step counter lives
@@ -2917,9 +3051,22 @@ struct ftcf_batcher {
         launch_dynamic_decode(sp, st, false);
         std::vector<int>     tok(B);
         std::vector<uint8_t> fin(B);
+        int                  gemm_err = 0;
         FTCF_HIP_CHECK(hipMemcpyAsync(tok.data(), d_tok, (size_t)B * 4, hipMemcpyDeviceToHost, st));
         FTCF_HIP_CHECK(hipMemcpyAsync(fin.data(), d_fin, (size_t)B, hipMemcpyDeviceToHost, st));
+        if (smallm_ws) {  // sticky flag of the burst GEMMs' in-launch split-K reduction (the engine's finish() reads its own)
+            FTCF_HIP_CHECK(hipMemcpyAsync(&gemm_err, reinterpret_cast<char*>(smallm_ws) + smallm_partial, sizeof(int),
+                                          hipMemcpyDeviceToHost, st));
+        }
         FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        if (gemm_err != 0) {
+            // the tokens of this step are not to be trusted: nothing is reported, the slots keep their state (lengths and
+            // draw counters advanced on the device: the requests cannot be resumed exactly), the flag is cleared for the caller's
+            // next attempt
+            FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
+            FTCF_HIP_CHECK(hipStreamSynchronize(st));
+            throw Error(-2, "batcher decode: a split-K reducer of the batched GEMM gave up waiting for its sibling workgroups");
+        }
         for (int si = 0; si < B; si++) {
             Slot& s = slots[si];
             if (!s.active) {
@@ -2981,7 +3128,26 @@ struct ftcf_batcher {
             waiting.pop_front();
         }
         if (!sis.empty()) {
-            admit(sis, rs, ev);
+            const size_t ev0 = ev.size();
+            try {
+                admit(sis, rs, ev);
+            }
+            catch (...) {
+                // the whole admission is rolled back: pages to the pool, slots free, the requests back at the head of the
+                // queue in their order, their events dropped (the caller sees the exception, not half an admission)
+                (void)hipDeviceSynchronize();
+                (void)hipGetLastError();
+                for (const int si : sis) {
+                    release(slots[si]);
+                    const uint8_t one8 = 1;
+                    (void)hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice);
+                }
+                for (size_t i = rs.size(); i-- > 0;) {
+                    waiting.push_front(std::move(rs[i]));
+                }
+                ev.resize(ev0);
+                throw;
+            }
         }
         host_max_top_k = 1;
         host_any_top_p = 0;

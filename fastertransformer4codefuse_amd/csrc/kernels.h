@@ -198,6 +198,7 @@ struct PersistPlan {
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
+    int    p3l;       // the control waves' P3 share is prefetched into LDS during the attention (one row, short form, TP = 1)
     int    a3;        // the attention runs on the control waves alone, K rows by LDS-DMA (one row, short form, TP = 1)
     size_t smem;
 };
@@ -246,6 +247,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
 bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp = 1);
 // bytes of the table region one workgroup stores / loads (PersistParams::tab holds NB of them)
 size_t      persist_table_bytes(const PersistPlan& pl);
+// is the LM-head tail compiled into the persistent kernel (an experiment build, -DPS_EXPERIMENTS)?
+bool        persist_lm_tail_built();
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
 // all ranks of a local group in one launch (grid = world * NB): residency of the whole group
 bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world);

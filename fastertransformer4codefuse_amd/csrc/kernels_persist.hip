@@ -2,6 +2,14 @@
 // TP = 1 instantiations.  The tensor-parallel instantiations live in kernels_persist_tp.hip (built in parallel).
 #include "persist_device.cuh"
 
+// A3 / P3L / the LM-head tail are measured experiments that did not pay (profiles/r03_notes.md): instantiated only with
+// -DPS_EXPERIMENTS, never selected otherwise
+#ifdef PS_EXPERIMENTS
+#define PS_EXPERIMENTS_ON 1
+#else
+#define PS_EXPERIMENTS_ON 0
+#endif
+
 namespace ftcf {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -97,33 +105,60 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (best > 1e29) {
         return pl;
     }
-    // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations
-    int e1 = 0, e3 = 0;
-    for (int b = 0; b < NB; b++) {
-        const int nr1 = (int)((long)NT0h * (b + 1) / NB) - (int)((long)NT0h * b / NB)
-                        + (int)((long)NFh * (b + 1) / NB) - (int)((long)NFh * b / NB);
-        const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
-        const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);
-        const int nB = rB1 - rB0, nA = rA1 - rA0;
-        auto nt1 = [&](int) { return KT; };
-        auto nt3 = [&](int j) {
-            if (j < nB) {
-                const int t0 = ((rB0 + j) / NG) * pl.RLb;
-                return std::min(pl.RLb, KT_b - t0);
+    // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations (e3c: control waves, P3)
+    int  e1 = 0, e3 = 0, e3c = 0;
+    auto count_entries = [&](const int c1, const int c3) {
+        e1 = e3 = e3c = 0;
+        for (int b = 0; b < NB; b++) {
+            const int nr1 = (int)((long)NT0h * (b + 1) / NB) - (int)((long)NT0h * b / NB)
+                            + (int)((long)NFh * (b + 1) / NB) - (int)((long)NFh * b / NB);
+            const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
+            const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);
+            const int nB = rB1 - rB0, nA = rA1 - rA0;
+            auto nt1 = [&](int) { return KT; };
+            auto nt3 = [&](int j) {
+                if (j < nB) {
+                    const int t0 = ((rB0 + j) / NG) * pl.RLb;
+                    return std::min(pl.RLb, KT_b - t0);
+                }
+                const int t0 = ((rA0 + j - nB) / NG) * pl.RLa;
+                return std::min(pl.RLa, KT_a - t0);
+            };
+            int T3 = 0;
+            for (int j = 0; j < nB + nA; j++) {
+                T3 += nt3(j);
             }
-            const int t0 = ((rA0 + j - nB) / NG) * pl.RLa;
-            return std::min(pl.RLa, KT_a - t0);
-        };
-        int T3 = 0;
-        for (int j = 0; j < nB + nA; j++) {
-            T3 += nt3(j);
+            for (int w = 0; w < PS_NW; w++) {
+                int tb, te;
+                ps_wave_range(nr1 * KT, w, c1, tb, te);
+                e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
+                ps_wave_range(T3, w, c3, tb, te);
+                const int en = ps_wave_entries(nB + nA, nt3, tb, te);
+                e3           = std::max(e3, en);
+                if (w < PS_NC) {
+                    e3c = std::max(e3c, en);
+                }
+            }
         }
-        for (int w = 0; w < PS_NW; w++) {
-            int tb, te;
-            ps_wave_range(nr1 * KT, w, cs1, tb, te);
-            e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
-            ps_wave_range(T3, w, cs3, tb, te);
-            e3 = std::max(e3, ps_wave_entries(nB + nA, nt3, tb, te));
+    };
+    count_entries(cs1, cs3);
+    // P3L (one row, not A3): the control waves' P3 share -- the ctx-dependent out-proj pieces at the end of the tile space --
+    // is requested into LDS (64 KiB, 32 tiles per control wave) by LDS-DMA during the attention, when the HBM has nothing else
+    // to do, and consumed from there when ctx arrives: the share is shrunk (cs3) until it fits
+    static const int p3l_env = PS_EXPERIMENTS_ON && getenv("FTCF_PERSIST_P3L") ? atoi(getenv("FTCF_PERSIST_P3L")) : 0;
+    pl.p3l = 0;
+    if (p3l_env != 0 && allow_a3 && M == 1 && pl.uk == PS_UK) {
+        int c3 = cs3;
+        while (c3 > 1 && e3c > PS_U * PS_NBUF) {
+            c3--;
+            count_entries(cs1, c3);
+        }
+        if (e3c <= PS_U * PS_NBUF) {
+            cs3    = c3;
+            pl.p3l = 1;
+        }
+        else {
+            count_entries(cs1, cs3);
         }
     }
     const int rot = PS_U * PS_NBUF;
@@ -139,10 +174,13 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
         return pl;
     }
     // A3 (the attention on the control waves, K rows by LDS-DMA): one row, the short attention form, and 64 KiB more LDS
-    static const int a3_env = getenv("FTCF_PERSIST_A3") ? atoi(getenv("FTCF_PERSIST_A3")) : 0;
-    pl.a3 = (a3_env != 0 && allow_a3 && M == 1 && pl.uk == PS_UK
+    static const int a3_env = PS_EXPERIMENTS_ON && getenv("FTCF_PERSIST_A3") ? atoi(getenv("FTCF_PERSIST_A3")) : 0;
+    pl.a3 = (a3_env != 0 && !pl.p3l && allow_a3 && M == 1 && pl.uk == PS_UK
              && ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, true) <= 160 * 1024) ? 1 : 0;
-    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, pl.a3 != 0);
+    if (pl.p3l && ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, true) > 160 * 1024) {
+        return pl;  // (cannot happen for a shape the plain kernel fits with 64 KiB to spare; the caller retries without P3L)
+    }
+    pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3, pl.a3 != 0 || pl.p3l != 0);
     if (pl.smem > 160 * 1024) {
         return pl;
     }
@@ -152,6 +190,11 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     return pl;
 }
 
+bool persist_lm_tail_built()
+{
+    return PS_LM_CODE != 0;
+}
+
 size_t persist_table_bytes(const PersistPlan& pl)
 {
     // rt1 | rt3 | rsc | rsc3 | red | misc | lt1 | lt3 | bt1 | bt3 (persist_device.cuh, the carve of the kernel's LDS)
@@ -159,16 +202,19 @@ size_t persist_table_bytes(const PersistPlan& pl)
            + (size_t)PS_NW * (pl.e1 + pl.e3) / PS_U * 4;
 }
 
-template<bool INT8, int M, int DH, int UK, bool A3 = false>
+template<bool INT8, int M, int DH, int UK, bool A3 = false, bool P3L = false>
 static const void* ps_kernel()
 {
-    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false, false, A3>);
+    return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false, false, A3, P3L>);
 }
-static const void* ps_kernel_for(bool int8, int M, int dh, int uk, bool a3)
+static const void* ps_kernel_for(bool int8, int M, int dh, int uk, bool a3, bool p3l = false)
 {
 #define PS_SEL(I8, MM, D)                                                                                              \
     if (int8 == I8 && M == MM && dh == D) {                                                                            \
-        if constexpr (MM == 1) {                                                                                       \
+        if constexpr (MM == 1 && PS_EXPERIMENTS_ON) {                                                                  \
+            if (p3l && uk == PS_UK) {                                                                                  \
+                return ps_kernel<I8, MM, D, PS_UK, false, true>();                                                     \
+            }                                                                                                          \
             if (a3 && uk == PS_UK) {                                                                                   \
                 return ps_kernel<I8, MM, D, PS_UK, true>();                                                            \
             }                                                                                                          \
@@ -219,7 +265,7 @@ bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_c
     if (tp > 1) {
         return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
     }
-    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk, pl.a3 != 0), pl, num_cu, pl.NB);
+    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk, pl.a3 != 0, pl.p3l != 0), pl, num_cu, pl.NB);
 }
 
 void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
@@ -228,7 +274,7 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0);
+    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0, p.plan.p3l != 0);
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
     FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;

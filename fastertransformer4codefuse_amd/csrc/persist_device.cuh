@@ -496,12 +496,16 @@ struct PsAttn {
 
     // loads that do not depend on this step's qkv: K/V rows of the whole fixed chunk, masks, lengths, rotary table
     template<typename ST>
-    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st)
+    __device__ __forceinline__ void issue(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st,
+                                          const bool item = true)
     {
-        issue_impl<true>(p, lw, h, b, sp, tx, st);
+        issue_impl<true>(p, lw, h, b, sp, tx, st, item);
     }
+    // `item` false: a workgroup without a (row, head, split) that must not assign the row registers under a condition (they
+    // would be carried around the layer loop): it requests ONE cached row over and over
     template<bool ROWS, typename ST>
-    __device__ __forceinline__ void issue_impl(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st)
+    __device__ __forceinline__ void issue_impl(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st,
+                                               const bool item = true)
     {
         const int lane = tx & 63, wid = tx >> 6;
         const int sub = lane % LPK, grp = lane / LPK;
@@ -513,6 +517,7 @@ struct PsAttn {
         // re-read its last row: a cache hit, not K/V traffic of the neighbouring split
         int t_last = t_beg + chunk - 1;
         t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
+        t_last     = item ? t_last : t_beg;
         if constexpr (ROWS) {
 #pragma unroll
             for (int u = 0; u < UK; u++) {
@@ -852,8 +857,26 @@ struct PsAttn {
             }
         }
     }
+    // the current token's rotated K and its V (LDS, left there by compute<false>) -> the cache (:1397, :1837)
+    __device__ __forceinline__ void append_current(const PersistParams& p, PsLayerC& lw, char* smem, int h, int b, const int tx)
+    {
+        if (fin || t_beg > tl) {
+            return;
+        }
+        int t_end = t_beg + chunk;
+        t_end     = t_end > tl + 1 ? tl + 1 : t_end;
+        if (tl >= t_beg && tl < t_end && tx < DH) {
+            const f16* s_k = reinterpret_cast<const f16*>(smem) + DH;
+            const f16* s_v = s_k + DH;
+            ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
+            ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
+        }
+    }
     // returns false when the row is finished (nothing published)
-    template<typename ST>
+    // APPEND false: the caller appends the current token's K / V to the cache itself, after the call (append_current) -- the
+    // attention then contains no global-memory operation before its last barrier, hence no vmcnt wait the compiler would
+    // place for one (P3L: such a wait would also wait for the LDS-DMA requests in flight)
+    template<bool APPEND = true, typename ST>
     __device__ __forceinline__ bool compute(const PersistParams& p, PsLayerC& lw, char* smem, u64* gout,
                                             const unsigned tag, int h, int b, const int tx, ST& st)
     {
@@ -898,7 +921,7 @@ struct PsAttn {
             }
         }
         __syncthreads();
-        if (owns_cur && tx < DH) {  // append to the cache (:1397, :1837)
+        if (APPEND && owns_cur && tx < DH) {  // append to the cache (:1397, :1837)
             ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
             ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
         }
@@ -1156,7 +1179,12 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
 // partial; the streamer waves go from the P1 epilogue straight to the mid sweep and the FFN2 stream: their window between
 // the two weight streams is one hop (mid) instead of hop + attention + mid sweep (11.4 -> ~6 us per layer, measured with a
 // timing probe before this was built: profiles/r03_notes.md).
-template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false, bool A3 = false>
+// P3L (round 3; one row, short attention form, not A3): the control waves' share of the P3 stream -- the out-proj pieces at the
+// end of the workgroup's tile space, which wait for ctx anyway -- is requested into LDS (kbuf, 32 tiles per control wave) by
+// LDS-DMA right after q/k/v are staged, eight requests per wave: it lands during the attention, when the K/V rows are in and
+// the HBM has nothing else to do, and is consumed from LDS the moment ctx arrives.  64 KiB per CU = 16 MB per layer leave
+// the P3 stream, and the control waves no longer finish it last.
+template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false, bool A3 = false, bool P3L = false>
 __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     const typename std::conditional<GROUP, PersistGroupParams, PersistParams>::type pa)
 {
@@ -1191,7 +1219,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
 #define PS_PART3 0
 #endif
     constexpr bool PART3 = PS_PART3 != 0 && M == 1 && !A3;
-    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || A3 || PS_NOCARRY_ALL;
+    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || A3 || P3L || PS_NOCARRY_ALL;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB;
     const int     wid = threadIdx.x >> 6;
@@ -1582,6 +1610,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             PsLayerC& lw  = PS_LAYER(p, l);
             const unsigned      tag = tag_base + (unsigned)l;
             static_assert(!A3 || (M == 1 && UK == PS_U), "A3: one row, short attention form");
+            static_assert(!P3L || (M == 1 && UK == PS_U && !A3 && !TP), "P3L: one row, short attention form, one GPU");
             constexpr bool      A3F = A3;
 #ifndef PS_A3_KV_LATE
 #define PS_A3_KV_LATE 0
@@ -1814,6 +1843,41 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
                 }
             }
+            else if constexpr (P3L) {
+                at.issue(p, lw, a_h, a_b, a_sp, tid, st, has_item);
+                if (has_item) {
+                    at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
+                    stamp(l, 6);
+                }
+                // q/k/v are in (nothing of this compute unit polls any more) and the K/V rows were requested long ago: the
+                // control waves' P3 tiles -> LDS now, PS_NC * 32 / PS_NW wave-wide requests per wave
+                __syncthreads();
+                // (hipcc does not know about the LDS-DMA requests below, and vmcnt counts them: its wait for the K/V rows --
+                // vmcnt(0), the rows being the youngest loads it knows -- would wait for all of them too.  Naming the rows as
+                // inputs here makes it place that wait BEFORE the requests, where the rows have long landed)
+                asm volatile("" ::"v"(at.kreg[0]), "v"(at.kreg[1]), "v"(at.kreg[2]), "v"(at.kreg[3]), "v"(at.kreg[4]), "v"(at.kreg[5]),
+                             "v"(at.kreg[6]), "v"(at.kreg[7]), "v"(at.vreg[0]), "v"(at.vreg[1]), "v"(at.vreg[2]), "v"(at.vreg[3]),
+                             "v"(at.vreg[4]), "v"(at.vreg[5]), "v"(at.vreg[6]), "v"(at.vreg[7]), "v"(at.mask_bits), "v"(at.tl),
+                             "v"(at.rot_cs), "v"(at.rot_sn));
+                {
+                    const unsigned kb = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s.kbuf;
+                    const int      w8 = ps_rfl(tid >> 6);
+#ifndef PS_P3L_DMA
+#define PS_P3L_DMA 1
+#endif
+#pragma unroll
+                    for (int k = 0; k < (PS_P3L_DMA ? PS_NC * PS_U * PS_NBUF / PS_NW : 0); k++) {
+                        const int      e   = w8 + k * PS_NW;
+                        const unsigned ent = (unsigned)ps_rfl((int)s.lt3[(size_t)(e / (PS_U * PS_NBUF)) * E3 + e % (PS_U * PS_NBUF)]);
+                        const char*    wb  = reinterpret_cast<const char*>((ent >> 31) ? lw.w_out : lw.w_ffn2);
+                        ps_lds_dma16(wb + ((size_t)(ent & 0x7fffffffu) * 64 + (tid & 63)) * 16, (unsigned)ps_rfl((int)(kb + (unsigned)e * 1024u)));
+                    }
+                }
+                if (has_item) {
+                    live = at.template compute<false>(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
+                    at.append_current(p, lw, s.att, a_h, a_b, tid);
+                }
+            }
             else if (has_item) {
                 // (issued here and not before the barrier above: K/V rows held across setup_p3 spill, measured)
                 if constexpr (!Attn::ALIAS) {
@@ -1857,7 +1921,10 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     }
                 }
                 stamp(l, 7);
-                __syncthreads();  // mid staged, attention scratch free
+                if constexpr (P3L) {
+                    ps_wait_vm<0>();  // this wave's LDS-DMA requests have landed (the compiler does not know about them)
+                }
+                __syncthreads();  // mid staged, attention scratch free (P3L: the control waves' P3 tiles are in LDS)
                 stamp(l, 8);
                 if constexpr (!CTRL) {
                     // (the constants of the layer's end -- residual bias, next layer's scales -- are fetched HERE and not in
@@ -1909,12 +1976,25 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                     atomicAdd(&s.misc[32], 1);  // DS operations of a wave execute in order: the writes above are visible
                 }
                 load_p3_consts(l);
-                if constexpr (PS_CTRL_EARLY == 0) {
+                if constexpr (P3L) {
+                    // the whole share out of LDS: a batch of tiles into a register batch, then the same consume as the stream's
+                    const int c0 = ps_rfl(tid >> 6) * (PS_U * PS_NBUF);
+                    for (int b2 = 0; b2 < sg3.nrot * PS_NBUF; b2++) {
+#pragma unroll
+                        for (int u = 0; u < PS_U; u++) {
+                            st.R0[u] = *reinterpret_cast<const u32x4*>(s.kbuf + ((size_t)(c0 + b2 * PS_U + u) * 64 + (tid & 63)) * 16);
+                        }
+                        st.consume(st.R0, b2);
+                    }
+                }
+                else if constexpr (PS_CTRL_EARLY == 0) {
                     st.prime_lo();
                 }
             }
             stamp(l, 9);
-            st.template run<CTRL ? (PS_CTRL_EARLY != 2) : ((!A3F && PS_MID_ALL >= 2) ? PS_MID_ALL != 3 : EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
+            if constexpr (!(CTRL && P3L)) {
+                st.template run<CTRL ? (PS_CTRL_EARLY != 2) : ((!A3F && PS_MID_ALL >= 2) ? PS_MID_ALL != 3 : EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
+            }
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));
@@ -2045,7 +2125,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         // wave sum).  A workgroup takes V / NB consecutive rows, its waves consecutive row ranges: a wave's share is ONE
         // contiguous byte range, streamed through the same four register batches as the weights; the streamer waves request
         // their first rotation right here, while the control waves still merge and gather the last layer's x'.
-        if constexpr (!TP) {
+// (compiled only with -DPS_EXPERIMENTS: the mere presence of this tail costs the layer loop 2 % -- hipcc's register
+// allocation of this kernel -- and the LM head streams at the same 6.6 TB/s inside or outside the launch: profiles/r03_notes.md)
+#ifdef PS_EXPERIMENTS
+#define PS_LM_CODE 1
+#else
+#define PS_LM_CODE 0
+#endif
+        if constexpr (!TP && PS_LM_CODE) {
             if (p.lm_w != nullptr && p.l_end == p.L) {
                 asm volatile("" : "+v"(tid));
                 const int lane = tid & 63;

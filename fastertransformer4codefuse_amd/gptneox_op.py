@@ -46,6 +46,13 @@ def init_tensor_parallel_comm(group, rank, world_size, device):
         return comm
     import torch.distributed as dist
     ids = np.zeros(capi.UNIQUE_ID_BYTES, dtype=np.uint8)
+    if os.environ.get("FTCF_TP_EXCHANGE", "") == "host":
+        # HOST-EXCHANGE communicator (include/ftcf.h ftcf_comm_init_host_exchange): no RCCL communicator at all -- the
+        # bootstrap, the hipIpc handles of the exchange windows, agreements and barriers (and, host staged, the prefill
+        # collectives) are all-gathers of host bytes over the caller's process group (gloo: CPU tensors).  What
+        # nccl_inherit_utils.cc:25-68 does with the caller's ProcessGroup for the bootstrap, taken one step further; it lets
+        # two PROCESSES share one device, i.e. the inter-process path of the in-kernel all-reduce run on a single-GPU box.
+        return _HostExchangeComm(group, rank, world_size, device).handle
     if os.environ.get("FTCF_FAKE_TP") == "1":
         # timing aid (bench.py --fake-tp N): ONE process runs rank 0's shard of a TP=N model over a 1-rank communicator --
         # the kernels and collectives of a rank are all launched, only the peers are missing (outputs are meaningless)
@@ -66,6 +73,31 @@ def init_tensor_parallel_comm(group, rank, world_size, device):
     capi.check(capi.lib().ftcf_comm_init(ids.ctypes.data_as(C.POINTER(C.c_uint8)), world_size, rank, device,
                                          C.byref(comm)))
     return comm
+
+
+class _HostExchangeComm:
+    """Owns the ctypes callback (it must outlive the communicator) of a host-exchange communicator."""
+    _alive = []
+
+    def __init__(self, group, rank, world_size, device):
+        import torch.distributed as dist
+        self.group, self.world = group, world_size
+
+        def allgather(_user, send, recv, nbytes):
+            try:
+                src = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+                out = torch.empty(nbytes * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, src, group=self.group)
+                C.memmove(recv, out.data_ptr(), nbytes * self.world)
+                return 0
+            except Exception as e:  # noqa: BLE001  (an exception must not unwind through the C caller)
+                print(f"[ftcf] host-exchange all-gather failed: {e!r}", flush=True)
+                return 1
+
+        self._cb = capi.HOST_ALLGATHER(allgather)
+        self.handle = C.c_void_p()
+        capi.check(capi.lib().ftcf_comm_init_host_exchange(world_size, rank, device, self._cb, None, C.byref(self.handle)))
+        _HostExchangeComm._alive.append(self)
 
 
 class GptNeoXOp:

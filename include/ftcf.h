@@ -116,6 +116,18 @@ int ftcf_comm_destroy(ftcf_comm_t comm);
 /* LOCAL GROUP (test infrastructure): the ranks of a tensor-parallel job inside ONE process on ONE device, each driven by
  * its own host thread.  Same engine code path as RCCL ranks (sharding, per-layer all-reduce, vocabulary split, in-kernel
  * exchange); the collectives are host-synchronous.  Lets a single-GPU box execute and check tensor_para_size > 1. */
+/* HOST-EXCHANGE communicator: one process per rank as with ftcf_comm_init, but every exchange between the ranks -- the
+ * bootstrap, the hipIpc handles of the exchange windows, agreements, barriers, and (staged through host memory) the
+ * all-reduce / all-gather of device buffers -- travels through ONE callback of the caller: an all-gather of host bytes
+ * over the caller's own process group (e.g. torch.distributed with gloo).  This is what nccl_inherit_utils.cc:25-68 does
+ * with the caller's ProcessGroup for the bootstrap, taken one step further: no RCCL communicator is created at all, so the
+ * ranks may share one device (the inter-PROCESS path of the in-kernel exchange -- IPC-mapped windows, hand-shake, system
+ * scope stores -- runs on a single-GPU box), and a box whose RCCL cannot initialise still gets tensor parallelism.  The
+ * decode all-reduce is in the persistent kernel's exchange windows as usual; prefill collectives are host staged (slow).
+ * allgather(user, send, recv, bytes): recv[r * bytes .. ] = rank r's send; returns 0 on success. */
+typedef int (*ftcf_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+int ftcf_comm_init_host_exchange(int world_size, int rank, int device, ftcf_host_allgather_fn allgather, void* user,
+                                 ftcf_comm_t* comm);
 int ftcf_comm_local_unique_id(uint8_t id[FTCF_UNIQUE_ID_BYTES]);
 int ftcf_comm_init_local(const uint8_t id[FTCF_UNIQUE_ID_BYTES], int world_size, int rank, int device, ftcf_comm_t* comm);
 /* ftNcclAllReduceSum / ftNcclAllGather (in place, fp16 / fp32) exposed for tests */

@@ -1,0 +1,46 @@
+"""One RANK of the two-PROCESS tensor-parallel test (tests/test_gpu_tp_process.py): its own process, its own HIP context,
+the same device 0 as its peer.  Builds its shard's GptNeoXOp over a HOST-EXCHANGE communicator (the caller's gloo group
+carries every exchange: include/ftcf.h ftcf_comm_init_host_exchange), runs the requests and stores what it produced.
+
+    python tests/tp_process_worker.py <rank> <world> <port> <model> <int8_mode> <out.npz>
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    rank, world, port, model, int8_mode, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    os.environ["FTCF_TP_EXCHANGE"] = "host"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)  # BOTH ranks on device 0: two processes, two address spaces, one GPU
+    from tests import gpu_helpers as gh
+    from tests.helpers import load_tiny, random_model, shard_weights
+    from tests.test_gpu_tp_process import MID, requests
+    if model == "tiny":
+        cfg, w, _ = load_tiny()
+    else:
+        cfg, w = MID, random_model(MID, seed=11)
+    op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD)
+    res = {}
+    for name, (ids, lens, n_out, kw) in requests(cfg, model).items():
+        r = gh.run_op(op, ids, lens, n_out, cfg["vocab_size"], **kw)
+        st = op.stats()
+        res[name + ".output_ids"] = r["output_ids"]
+        res[name + ".logits"] = r["logits"]
+        res[name + ".decode_path"] = np.array([st["decode_path"]])
+    np.savez(out, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
