@@ -326,7 +326,7 @@ def main():
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             # HBM traffic of that kernel from the PMC pass recorded under profiles/ (collected in its own rocprofv3 run, as
             # the counters cannot ride along with this timing run); only quoted when it was measured on this very config
-            traffic = None
+            traffic = traffic_source = None
             try:
                 import glob
                 pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1]))
@@ -334,10 +334,13 @@ def main():
                 if (ps["gemv_kind"] == 4 and a.dtype == c["dtype"] and world == c["tensor_parallel"] and a.layers == c["layers"]
                         and H == c["hidden"] and a.inter == c["inter"] and a.batch == 1):
                     traffic = pm["traffic_bytes_per_launch"]
+                    traffic_source = ("profiles/" + os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1])
+                                      + ": FETCH_SIZE x 2 (gfx950 correction) from a separate `rocprofv3 --pmc` pass over this very "
+                                        "command, NOT measured in this run")
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
                     "launches": ps["gemv_launches"],
                     "measured_over": f"{nprof} profiled decode steps (output tokens {pfirst}..{pfirst + nprof - 1}), "
                                      "HIP events on the engine's stream around every launch of that kernel"}

@@ -2,7 +2,8 @@
 
     op = GptNeoXOp(...)                       # fp16 / int8 engine, tensor_para_size 1
     cb = ContinuousBatcher(op, max_batch=8, page_tokens=64, num_pages=512, max_seq_len=2048)
-    rid = cb.submit(prompt_ids, max_new_tokens=128)          # greedy; top_k / top_p / temperature / seed optional
+    rid = cb.submit(prompt_ids, max_new_tokens=128)          # greedy; top_k / top_p / temperature / seed /
+                                                             # repetition_penalty / stop_words optional
     while cb.busy():
         for request_id, token, finished in cb.step():
             ...
@@ -35,12 +36,25 @@ class ContinuousBatcher:
         except Exception:
             pass
 
-    def submit(self, prompt_ids, max_new_tokens, top_k=0, top_p=0.0, temperature=1.0, seed=0):
+    def submit(self, prompt_ids, max_new_tokens, top_k=0, top_p=0.0, temperature=1.0, seed=0, repetition_penalty=1.0,
+               stop_words=None):
+        """stop_words: a list of token-id lists (each one a stop sequence), or None.  The request ends after a stop
+        sequence has been emitted (stop_criteria_kernels.cu:24-83), like GptNeoXOp.forward with stop_words_list."""
         ids = np.ascontiguousarray(prompt_ids, dtype=np.int32).reshape(-1)
         rid = C.c_long(0)
-        capi.check(capi.lib().ftcf_batcher_submit(self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), int(ids.size),
-                                                  int(max_new_tokens), int(top_k), C.c_float(top_p), C.c_float(temperature),
-                                                  C.c_ulonglong(int(seed)), C.byref(rid)))
+        sw, sw_len = None, 0
+        if stop_words:
+            flat = [t for w in stop_words for t in w]
+            sw_len = len(flat)
+            arr = np.zeros((2, sw_len), dtype=np.int32)  # to_word_list_format (codefuse_example.py:26-53)
+            arr[0] = flat
+            arr[1] = -1
+            arr[1, :len(stop_words)] = np.cumsum([len(w) for w in stop_words])
+            sw = np.ascontiguousarray(arr)
+        capi.check(capi.lib().ftcf_batcher_submit_ex(
+            self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), int(ids.size), int(max_new_tokens), int(top_k), C.c_float(top_p),
+            C.c_float(temperature), C.c_float(repetition_penalty), C.c_ulonglong(int(seed)),
+            sw.ctypes.data_as(C.POINTER(C.c_int)) if sw is not None else None, int(sw_len), C.byref(rid)))
         return int(rid.value)
 
     def step(self):

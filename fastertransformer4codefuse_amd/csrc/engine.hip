@@ -1151,7 +1151,7 @@ struct ftcf_gptneox {
             chunk_ws           = c.take<unsigned long long>(chunk_workspace_bytes(H, std::min(B, 4), 8) / 8);
             pplan = PersistPlan{};
             // With tensor parallelism the per-layer all-reduce happens INSIDE the persistent launch, through the ranks'
-            // exchange windows (persist_device.cuh ps_tp_exchange); where the windows are not available (peer mapping or
+            // exchange windows (persist_device.hip.h ps_tp_exchange); where the windows are not available (peer mapping or
             // hand-shake failed, FTCF_TP_PERSIST=0) the per-stage launches + RCCL all-reduce stay in charge.
             const int  tpn      = cfg.tensor_para_size;
             const bool tp_local = tpn > 1 && cfg.comm && cfg.comm->local;
@@ -2663,6 +2663,14 @@ __global__ void k_batcher_embed(f16* out, const f16* table, const int* tok, int 
         *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
     }
 }
+// d_tok[b] = the token the sampling kernels just wrote into slot b's history (time-major [max_len][B], position len[b])
+__global__ void k_batcher_last_token(int* tok, const int* hist, const int* len, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        tok[b] = hist[(size_t)len[b] * B + b];
+    }
+}
 __global__ void k_batcher_tick(DecodeState* gemm_state)
 {
     gemm_state->step = (gemm_state->step + 1) & 0x7ffff;  // part of the burst GEMMs' granule tags (19 bits)
@@ -2673,14 +2681,21 @@ struct ftcf_batcher {
         long             id;
         std::vector<int> prompt;
         int              max_new, top_k;
-        float            top_p, temperature;
+        float            top_p, temperature, repetition_penalty = 1.f;
         uint64_t         seed;
+        std::vector<std::vector<int>> stop;  // stop sequences (token ids)
     };
     struct Slot {
         bool             active = false;
         long             id = 0;
         int              len = 0, generated = 0, max_new = 0;
         std::vector<int> pages;
+        // the request's own token history (prompt + generated) and stop sequences: the stop criterion
+        // (stop_criteria_kernels.cu:24-83: finished AFTER the sequence has been emitted) is the scheduler's, on the host,
+        // which sees every token anyway
+        std::vector<int>              hist;
+        std::vector<std::vector<int>> stop;
+        float                         repetition_penalty = 1.f;
     };
     ftcf_gptneox* e = nullptr;
     int           max_batch = 0, P = 0, num_pages = 0, max_pages = 0, max_len = 0;
@@ -2692,7 +2707,9 @@ struct ftcf_batcher {
     int *     d_pt = nullptr, *d_len = nullptr, *d_tok = nullptr, *d_topk = nullptr, *d_zero = nullptr, *d_prompt = nullptr, *d_plen = nullptr,
         *d_pout = nullptr, *d_pseq = nullptr, *d_pages_tmp = nullptr;
     uint8_t*     d_fin = nullptr;
-    float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr;
+    float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr, *d_rep = nullptr;
+    int*         d_hist = nullptr;  // [max_len + 1][max_batch] time-major token history of the slots (repetition penalty)
+    int *        d_sw = nullptr;    // admission: stop words of the ragged batch, the reference's [n][2][Lw] layout
     uint64_t *   d_seed = nullptr, *d_draws = nullptr;
     DecodeState *d_state = nullptr, *d_gstate = nullptr;
     void*        samp_ws = nullptr;
@@ -2764,6 +2781,9 @@ struct ftcf_batcher {
         d_ptopp = dmalloc<float>(B);
         d_temp = dmalloc<float>(B);
         d_cum = dmalloc<float>(B);
+        d_rep = dmalloc<float>(B);
+        d_hist = dmalloc<int>((size_t)(max_len + 2) * B);
+        d_sw = dmalloc<int>(B * 2 * STOP_LW);
         d_seed = dmalloc<uint64_t>(B);
         d_draws = dmalloc<uint64_t>(B);
         d_state = dmalloc<DecodeState>(1);
@@ -2790,8 +2810,14 @@ struct ftcf_batcher {
         }
     }
 
-    long submit(const int* ids, int n, int max_new, int top_k, float top_p, float temperature, uint64_t seed)
+    static constexpr int STOP_LW = 64;  // total stop-word tokens per request (the [2][Lw] word list of the admission)
+    long submit(const int* ids, int n, int max_new, int top_k, float top_p, float temperature, uint64_t seed,
+                float repetition_penalty = 1.f, const int* stop_words = nullptr, int stop_len = 0)
     {
+        FTCF_CHECK_ARG(repetition_penalty > 0.f, "repetition_penalty must be positive");
+        FTCF_CHECK_ARG(stop_len >= 0 && stop_len <= STOP_LW && (stop_len == 0 || stop_words), "bad stop word list");
+        FTCF_CHECK_ARG((size_t)max_len * 8 <= 60 * 1024 || repetition_penalty == 1.f,
+                       "max_seq_len too large for the repetition-penalty staging buffer");
         FTCF_CHECK_ARG(ids && n >= 1 && max_new >= 1, "empty prompt or max_new_tokens < 1");
         FTCF_CHECK_ARG(n + max_new <= max_len && n <= max_prompt, "prompt + max_new_tokens exceed the batcher's max_seq_len");
         FTCF_CHECK_ARG((n + max_new + P - 1) / P <= num_pages, "the request needs more pages than the pool has");
@@ -2807,6 +2833,17 @@ struct ftcf_batcher {
         r.top_p = top_p;
         r.temperature = temperature;
         r.seed = seed;
+        r.repetition_penalty = repetition_penalty;
+        // to_word_list_format (codefuse_example.py:26-53): [0][..] flat ids, [1][..] cumulative end offsets, -1 padded
+        for (int i = 0, start = 0; i < stop_len; i++) {
+            const int end = stop_words[stop_len + i];
+            if (end < 0) {
+                break;
+            }
+            FTCF_CHECK_ARG(end > start && end <= stop_len, "bad stop word offsets");
+            r.stop.emplace_back(stop_words + start, stop_words + end);
+            start = end;
+        }
         waiting.push_back(std::move(r));
         return waiting.back().id;
     }
@@ -2816,6 +2853,16 @@ struct ftcf_batcher {
         int  token, finished;
     };
 
+    // stop_criteria_kernels.cu:24-83: does the history END with one of the request's stop sequences?
+    static bool hits_stop_word(const Slot& s)
+    {
+        for (const auto& wd : s.stop) {
+            if (!wd.empty() && s.hist.size() >= wd.size() && std::equal(wd.begin(), wd.end(), s.hist.end() - wd.size())) {
+                return true;
+            }
+        }
+        return false;
+    }
     void release(Slot& s)
     {
         for (int pg : s.pages) {
@@ -2836,7 +2883,9 @@ struct ftcf_batcher {
             S = std::max(S, (int)r.prompt.size());
         }
         std::vector<int>      ids((size_t)n * S, e->cfg.end_id), lens(n), topk(n);
-        std::vector<float>    topp(n), temp(n);
+        std::vector<float>    topp(n), temp(n), rep(n);
+        bool                  any_stop = false;
+        std::vector<int>      sw((size_t)n * 2 * STOP_LW, 0);
         std::vector<uint64_t> seed(n);
         for (int i = 0; i < n; i++) {
             const Request& r = rs[i];
@@ -2845,7 +2894,20 @@ struct ftcf_batcher {
             topk[i] = r.top_k;
             topp[i] = r.top_p;
             temp[i] = r.temperature;
+            rep[i]  = r.repetition_penalty;
             seed[i] = r.seed;
+            {  // the request's stop sequences in the reference's word-list layout (the engine samples the FIRST token)
+                int* ids_row = sw.data() + (size_t)i * 2 * STOP_LW;
+                int* off_row = ids_row + STOP_LW;
+                std::fill(off_row, off_row + STOP_LW, -1);
+                int pos = 0, k = 0;
+                for (const auto& wd : r.stop) {
+                    std::copy(wd.begin(), wd.end(), ids_row + pos);
+                    pos += (int)wd.size();
+                    off_row[k++] = pos;
+                    any_stop = true;
+                }
+            }
             Slot&     s = slots[sis[i]];
             const int need = (lens[i] + r.max_new + P - 1) / P;
             s.pages.clear();
@@ -2869,6 +2931,13 @@ struct ftcf_batcher {
         a.n_top_p = n;
         a.temperature = temp.data();
         a.n_temperature = n;
+        a.repetition_penalty = rep.data();
+        a.n_repetition_penalty = n;
+        if (any_stop) {
+            FTCF_HIP_CHECK(hipMemcpy(d_sw, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+            a.stop_words_list = d_sw;
+            a.stop_words_len = STOP_LW;
+        }
         a.random_seed = seed.data();
         a.n_random_seed = n;
         a.output_ids = d_pout;
@@ -2901,6 +2970,14 @@ struct ftcf_batcher {
             FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopk + si, &ptk, 4, hipMemcpyHostToDevice, st));
             FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopp + si, &r.top_p, 4, hipMemcpyHostToDevice, st));
             FTCF_HIP_CHECK(hipMemcpyAsync(d_temp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_rep + si, &r.repetition_penalty, 4, hipMemcpyHostToDevice, st));
+            // the slot's token history, time-major column si: prompt, then the first token
+            s.hist.assign(r.prompt.begin(), r.prompt.end());
+            s.hist.push_back(first);
+            s.stop = r.stop;
+            s.repetition_penalty = r.repetition_penalty;
+            FTCF_HIP_CHECK(hipMemcpy2DAsync(d_hist + si, (size_t)max_batch * 4, s.hist.data(), 4, 4, s.hist.size(),
+                                            hipMemcpyHostToDevice, st));
             FTCF_HIP_CHECK(hipMemcpyAsync(d_seed + si, &r.seed, 8, hipMemcpyHostToDevice, st));
             FTCF_HIP_CHECK(hipMemcpyAsync(d_draws + si, &one, 8, hipMemcpyHostToDevice, st));  // draw 0 went to the first token
             FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, &zf, 4, hipMemcpyHostToDevice, st));
@@ -2911,7 +2988,7 @@ struct ftcf_batcher {
             s.len = len;
             s.generated = 1;
             s.max_new = r.max_new;
-            const int done = (first == e->cfg.end_id || s.generated >= s.max_new) ? 1 : 0;
+            const int done = (first == e->cfg.end_id || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
             ev.push_back(Event{r.id, first, done});
             if (done) {
                 const uint8_t one8 = 1;
@@ -3027,7 +3104,6 @@ struct ftcf_batcher {
         sp.B = B;
         sp.V = V;
         sp.max_input_len = 0;
-        sp.total_len = 1;
         sp.end_id = e->cfg.end_id;
         sp.input_lengths = d_zero;
         sp.top_k = d_topk;
@@ -3037,9 +3113,14 @@ struct ftcf_batcher {
         sp.random_seed = d_seed;
         sp.draw_counter = d_draws;
         sp.apply_temperature = host_any_temperature ? 1 : 0;
-        sp.apply_repetition = 0;
+        sp.apply_repetition = host_any_repetition ? 1 : 0;  // (BaseSamplingLayer.cc:283-313: skipped when every row has 1.0)
+        sp.repetition_penalty = d_rep;
         sp.return_cum_log_probs = 1;
-        sp.output_ids = d_tok;  // "time-major [total, B]" with total = 1: the sampled token of slot b lands in d_tok[b]
+        // every slot has its own step: its history is column b of the time-major d_hist, positions [0, len[b]]; the sampled
+        // token goes to position len[b] + 1 (the penalty of sampling_penalty_kernels.cu:367-425 reads the whole history)
+        sp.output_ids = d_hist;
+        sp.row_len = d_len;
+        sp.total_len = max_len + 2;
         sp.finished = d_fin;
         sp.seq_len = d_len;     // + 1 per sampled token: the slot's length
         sp.cum_log_probs = d_cum;
@@ -3049,6 +3130,7 @@ struct ftcf_batcher {
         sp.max_top_k = host_max_top_k;
         sp.any_top_p = host_any_top_p;
         launch_dynamic_decode(sp, st, false);
+        hipLaunchKernelGGL(k_batcher_last_token, dim3(1), dim3(64), 0, st, d_tok, d_hist, d_len, B);
         std::vector<int>     tok(B);
         std::vector<uint8_t> fin(B);
         int                  gemm_err = 0;
@@ -3074,7 +3156,8 @@ struct ftcf_batcher {
             }
             s.len += 1;
             s.generated += 1;
-            const int done = (fin[si] || s.generated >= s.max_new) ? 1 : 0;
+            s.hist.push_back(tok[si]);
+            const int done = (fin[si] || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
             ev.push_back(Event{s.id, tok[si], done});
             if (done) {
                 if (!fin[si]) {
@@ -3087,7 +3170,7 @@ struct ftcf_batcher {
     }
 
     int  host_max_top_k = 1, host_any_top_p = 0;
-    bool host_any_temperature = false;
+    bool host_any_temperature = false, host_any_repetition = false;
     std::vector<int>   slot_topk;
     std::vector<float> slot_temp;
 
@@ -3152,8 +3235,10 @@ struct ftcf_batcher {
         host_max_top_k = 1;
         host_any_top_p = 0;
         host_any_temperature = false;
+        host_any_repetition = false;
         for (int si = 0; si < max_batch; si++) {
             if (slots[si].active) {
+                host_any_repetition |= (slots[si].repetition_penalty != 1.f);
                 host_max_top_k = std::max(host_max_top_k, slot_topk[si]);
                 host_any_top_p |= (slot_topk[si] == 0);
                 host_any_temperature |= (slot_temp[si] != 1.f);
@@ -3179,6 +3264,16 @@ extern "C" int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int 
     return guarded([&] {
         FTCF_CHECK_ARG(b && request_id, "NULL argument");
         *request_id = b->submit(prompt_ids, prompt_len, max_new_tokens, top_k, top_p, temperature, (uint64_t)seed);
+    });
+}
+extern "C" int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k,
+                                      float top_p, float temperature, float repetition_penalty, unsigned long long seed,
+                                      const int* stop_words, int stop_len, long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit(prompt_ids, prompt_len, max_new_tokens, top_k, top_p, temperature, (uint64_t)seed,
+                                repetition_penalty, stop_words, stop_len);
     });
 }
 extern "C" int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events)

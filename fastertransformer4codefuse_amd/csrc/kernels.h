@@ -321,6 +321,9 @@ struct SamplingParams {
     DecodeState*    state;
     int*            h_flags;  // pinned host mirror: [0] = all_finished, [1] = step that produced it
     void*           ws;       // workspace (see sampling_workspace_bytes)
+    // continuous batching: every row has its OWN step -- row b's token history is output_ids[0 .. row_len[b]] (time-major
+    // as always), the new token goes to position row_len[b] + 1.  NULL: the batch-wide state->step
+    const int*      row_len;
 };
 // beam search (beam_width > 1): OnlineBeamSearchLayer semantics, rows bb = batch * K + beam
 constexpr int BEAM_MAX_K = 64;  // online_softmax_beamsearch_kernels.cu:691-695

@@ -15,7 +15,7 @@
 //
 // Cache layout (engine private): K and V both [B, nh, s_max, dh] fp16, dh contiguous: one wave-load = 1 KiB of
 // consecutive keys.  Roofline: HBM (decode: 4*t*dh*nh bytes per layer per row).
-#include "attn_device.cuh"
+#include "attn_device.hip.h"
 
 namespace ftcf {
 
@@ -551,7 +551,7 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
 // ---------------------------------------------------------------------------------------------------------------
 // Paged decoder attention (the continuous-batching front end, engine.hip `ftcf_batcher`): the K/V of a
 // sequence live in fixed-size pages of a pool shared by all sequences, [page][head][P tokens][dh], found through the
-// sequence's page table.  Same arithmetic as mmha_partial with one split (attn_device.cuh): half q/k/v + bias, NeoX rotary
+// sequence's page table.  Same arithmetic as mmha_partial with one split (attn_device.hip.h): half q/k/v + bias, NeoX rotary
 // at position = number of cached tokens, fp32 scores, exp against the row maximum, fp32 PV, one normalisation with the
 // reference's +1e-6 (decoder_masked_multihead_attention_template.hpp:1632).  One workgroup per (head, slot); a sequence's
 // length is its own (no padding, no masks: a slot's tokens are dense from position 0).

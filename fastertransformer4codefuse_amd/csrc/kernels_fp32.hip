@@ -8,7 +8,7 @@
 // xf32 / tf32 truncation); attention and the LM head are plain VALU kernels.  No weight re-layout: the caller's row-major
 // [K, N] matrices and the [V, H] head are read in place.  int8_mode is a half-only feature of the reference
 // (CutlassFpAIntBGemmRunner<half, uint8_t>) and is refused for fp32.
-#include "attn_device.cuh"
+#include "attn_device.hip.h"
 #include "ftcf_common.h"
 #include "kernels.h"
 

@@ -7,8 +7,8 @@
 // The streaming blocks come first in the grid: they are few (1.25 per CU) and long running, so every CU starts pulling
 // weights at once and the many short attention workgroups fill the remaining wave slots around them (measured:
 // attention-first leaves one slot per CU for the weight stream until the attention blocks retire, 30.7 us vs ...).
-#include "attn_device.cuh"
-#include "gemv_device.cuh"
+#include "attn_device.hip.h"
+#include "gemv_device.hip.h"
 
 namespace ftcf {
 

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, 
 // workgroup's x slice (16 rows x slice_k, through LDS once): one round trip per workgroup, the whole matrix is in flight
 // at once and the launch lasts about bytes / HBM rate -- IF a workgroup's slot (registers, LDS) is handed to the next
 // workgroup as soon as its weights have arrived.  Hence the shape of the split-K reduction: partial sums travel as 8-byte
-// {tag, value} granules (attn_device.cuh; one relaxed agent-scope store each, the data is its own flag), every workgroup
+// {tag, value} granules (attn_device.hip.h; one relaxed agent-scope store each, the data is its own flag), every workgroup
 // but the one that owns the LAST slice of a column block leaves right after issuing its stores, and that last one --
 // dispatched after all of its siblings -- polls their granules, adds them in slice order (deterministic) and applies the
 // epilogue.  (The first version took a ticket per workgroup after waiting for its stores to complete: two more memory

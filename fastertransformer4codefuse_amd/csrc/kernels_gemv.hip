@@ -11,7 +11,7 @@
 // non-temporal), 8 tiles are kept in flight per wave while the previous 8 are consumed from registers.
 #include <cmath>
 
-#include "gemv_device.cuh"
+#include "gemv_device.hip.h"
 
 namespace ftcf {
 

@@ -1,6 +1,6 @@
-// Host side of the persistent decode layers (device code: persist_device.cuh): plan, residency check, launchers of the
+// Host side of the persistent decode layers (device code: persist_device.hip.h): plan, residency check, launchers of the
 // TP = 1 instantiations.  The tensor-parallel instantiations live in kernels_persist_tp.hip (built in parallel).
-#include "persist_device.cuh"
+#include "persist_device.hip.h"
 
 // A3 / P3L / the LM-head tail are measured experiments that did not pay (profiles/r03_notes.md): instantiated only with
 // -DPS_EXPERIMENTS, never selected otherwise
@@ -197,7 +197,7 @@ bool persist_lm_tail_built()
 
 size_t persist_table_bytes(const PersistPlan& pl)
 {
-    // rt1 | rt3 | rsc | rsc3 | red | misc | lt1 | lt3 | bt1 | bt3 (persist_device.cuh, the carve of the kernel's LDS)
+    // rt1 | rt3 | rsc | rsc3 | red | misc | lt1 | lt3 | bt1 | bt3 (persist_device.hip.h, the carve of the kernel's LDS)
     return 2 * sizeof(RunRec) * PS_RMAX + 2 * PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (pl.e1 + pl.e3) * 4
            + (size_t)PS_NW * (pl.e1 + pl.e3) / PS_U * 4;
 }

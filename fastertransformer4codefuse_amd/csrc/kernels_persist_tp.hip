@@ -1,8 +1,8 @@
-// Tensor-parallel instantiations of the persistent decode layers (persist_device.cuh): the product kernel of a rank
+// Tensor-parallel instantiations of the persistent decode layers (persist_device.hip.h): the product kernel of a rank
 // (in-launch all-reduce through the ranks' exchange windows) and the local-group kernel that runs all ranks of a job in one
 // launch on one device (test infrastructure).  K/V register depth PS_UK only: a shard has 1/TP of the heads, so the KV
 // splits are TP times finer than on one GPU and the short form covers the same contexts.
-#include "persist_device.cuh"
+#include "persist_device.hip.h"
 
 namespace ftcf {
 

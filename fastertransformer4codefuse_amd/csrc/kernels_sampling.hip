@@ -26,7 +26,9 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
     return z ^ (z >> 31);
 }
 // identical to oracle/ftcf_oracle.c orc_uniform: (0,1].  The reference draws from curand XORWOW
-// (sampling_topk_kernels.cu:32-65,283): only the distribution is reproducible, greedy is unaffected.
+// (sampling_topk_kernels.cu:32-65,283): only the distribution is reproducible, greedy is unaffected.  Like the reference's
+// curand_init(seed, 0, 0) per row, the stream depends on the row's SEED and draw count only, never on where the row sits
+// in a batch (`row` is 0 at every call site): a request samples the same tokens alone, in any batch, in any batcher slot.
 __device__ __forceinline__ float ftcf_uniform(uint64_t seed, uint64_t row, uint64_t draw)
 {
     const uint64_t z = splitmix64(seed ^ splitmix64(row * 0x632be59bd9b4e019ULL + draw));
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
     const int        b    = blockIdx.x;
     const int        V    = p.V;
     float*           l    = p.logits + (size_t)b * V;
-    const int        step = p.state->step;
+    const int        step = p.row_len ? p.row_len[b] + 1 : p.state->step;
     const int        tid = threadIdx.x, nt = blockDim.x;
 
     // K15 select_optional_last_tokens: first generated step only (DynamicDecodeLayer.cc:250-267)
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
     __shared__ int   s_pick[2];
     const int        b = blockIdx.x;
     const int        V = p.V;
-    const int        step = p.state->step;
+    const int        step = p.row_len ? p.row_len[b] + 1 : p.state->step;
     int*             out_id = p.output_ids + (size_t)step * p.B + b;
     if (p.finished[b]) {
         if (threadIdx.x == 0) {
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
                 sv[i] = u;
                 ssum += u;
             }
-            const float u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
+            const float u01 = ftcf_uniform(p.random_seed[b], 0, p.draw_counter[b]);
             p.draw_counter[b] += 1;
             float rnd  = u01 * p.top_p_topk[b] * ssum;  // :283
             int   pick = k - 1;
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
         // flat distribution -- falls back to extracting one maximum of the remaining row per pass.
         const float thr = p.top_p_topp[b];
         if (threadIdx.x == 0) {
-            const float u01 = ftcf_uniform(p.random_seed[b], (uint64_t)b, p.draw_counter[b]);
+            const float u01 = ftcf_uniform(p.random_seed[b], 0, p.draw_counter[b]);
             p.draw_counter[b] += 1;
             s_rnd = u01 * thr;
         }

@@ -27,8 +27,8 @@
 #pragma once
 #include <type_traits>
 
-#include "attn_device.cuh"
-#include "gemv_device.cuh"
+#include "attn_device.hip.h"
+#include "gemv_device.hip.h"
 
 namespace ftcf {
 
@@ -458,7 +458,7 @@ __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 
 // ---------------------------------------------------------------------------------------------------------------
 // attention of one (row b, head h, split sp) on the whole 8-wave workgroup
-// (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.cuh::mmha_partial)
+// (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.hip.h::mmha_partial)
 // ---------------------------------------------------------------------------------------------------------------
 template<int DH, int UK, int NSW = 3 * DH / 2>
 struct PsAttn {

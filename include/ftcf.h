@@ -236,6 +236,14 @@ int ftcf_batcher_create(ftcf_gptneox_t engine, int max_batch, int page_tokens, i
 /* prompt_ids: HOST array.  (top_k, top_p) = (0, 0) is greedy, as in the reference's sampling layer. */
 int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k, float top_p,
                         float temperature, unsigned long long seed, long* request_id);
+/* The same with the request's repetition penalty (sampling_penalty_kernels.cu:367-425: every token of prompt + output so
+ * far, once) and stop words: `stop_words` is a HOST int array [2][stop_len] in the reference's to_word_list_format layout
+ * (codefuse_example.py:26-53: row 0 the words' ids back to back, row 1 their cumulative end offsets, -1 padded), or NULL.
+ * A request ends AFTER a stop sequence has been emitted (stop_criteria_kernels.cu:24-83): the event of its last token
+ * carries finished = 1.  stop_len <= 64. */
+int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k, float top_p,
+                           float temperature, float repetition_penalty, unsigned long long seed, const int* stop_words,
+                           int stop_len, long* request_id);
 /* One scheduler iteration: one decode step for the running sequences, then admissions (prefill + first token).  Returns one
  * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch. */
 int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events);

@@ -816,7 +816,7 @@ void orc_dynamic_decode(float* logits, int B, int V, int step, int max_input_len
                     val2[i] = u;
                     ssum += u;
                 }
-                float u01  = orc_uniform(sp->random_seed ? sp->random_seed[b] : 0, (uint64_t)b, draw_counter[b]++);
+                float u01  = orc_uniform(sp->random_seed ? sp->random_seed[b] : 0, 0, draw_counter[b]++);
                 float rnd  = u01 * p_topk[b] * ssum; /* :283 */
                 int   pick = k - 1;
                 for (int i = 0; i < k; i++) {
@@ -839,7 +839,7 @@ void orc_dynamic_decode(float* logits, int B, int V, int step, int max_input_len
             else {
                 /* TopPSamplingLayer.cu runSampling: softmax always, then kernels/sampling_topp_kernels.cu:802-1000 */
                 softmax_endmask(l, V, fin, end_id);
-                float u01 = orc_uniform(sp->random_seed ? sp->random_seed[b] : 0, (uint64_t)b, draw_counter[b]++);
+                float u01 = orc_uniform(sp->random_seed ? sp->random_seed[b] : 0, 0, draw_counter[b]++);
                 float thr = p_topp[b];
                 int   best = 0;
                 for (int j = 1; j < V; j++) {

@@ -176,3 +176,98 @@ def test_cancel_returns_the_pages_and_leaves_the_others_untouched(gh):
             got.setdefault(rid, []).append(tok)
     assert got[b] == ref and c not in got and len(got[a]) == 2
     assert cb.status() == {"waiting": 0, "running": 0, "free_pages": 12}
+
+
+def _oracle_alone(model, prompt, n_new, end_id, **kw):
+    """What `orc.Model.generate` -- the CPU restatement of the reference -- produces for this request by itself, cut where the
+    batcher's stream of it ends: at end_id, or after an emitted stop sequence (stop_criteria_kernels.cu:24-83)."""
+    from oracle import oracle as orc
+    stop = kw.pop("stop_words", None)
+    sw = None
+    if stop:
+        flat = [t for w in stop for t in w]
+        sw = np.zeros((1, 2, len(flat)), np.int32)
+        sw[0, 0] = flat
+        sw[0, 1] = -1
+        sw[0, 1, :len(stop)] = np.cumsum([len(w) for w in stop])
+    sp = orc.Sampling(1, stop_words=sw, **kw)
+    o = model.generate(np.asarray(prompt, np.int32)[None, :], [len(prompt)], n_new, sampling=sp)
+    toks = o["output_ids"][0, len(prompt):].tolist()
+    hist, out = list(prompt), []
+    for t in toks:
+        out.append(t)
+        hist.append(t)
+        if t == end_id or any(len(hist) >= len(w) and hist[-len(w):] == list(w) for w in (stop or [])):
+            break
+    return out
+
+
+def test_every_request_matches_the_oracle_with_penalty_and_stop_words(gh):
+    """The checker of the batcher is no longer only the engine: every request -- greedy, with a repetition penalty, with stop
+    words, with top-k sampling -- is generated by the CPU oracle alone and compared token for token with the stream the
+    batcher produced for it while it shared slots, pages and decode steps with the others."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    from oracle import oracle as orc
+    from tests.helpers import weight_list_to_layers
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    layers, glob = weight_list_to_layers(cfg, w)
+    model = orc.Model(dict(cfg, fp16=1), layers, glob)
+    op = gh.make_op(cfg, w)
+    # prompts and penalties whose greedy trajectories keep a top-2 margin above 9e-3 of max|logit| in the oracle (checked
+    # when the test was written; the fp16 engine is within 5e-3 of it): a near tie would test the tie, not the batcher
+    rng, rng2 = np.random.RandomState(17), np.random.RandomState(5)
+    r19 = rng.randint(3, V, size=19).tolist()
+    r7 = rng.randint(3, V, size=7).tolist()
+    xs = [rng2.randint(3, V, size=int(rng2.randint(5, 24))).tolist() for _ in range(4)]
+    pb = z["prompt_b"].tolist()
+    # stop sequences taken from what the request generates WITHOUT them: one single-token, one two-token sequence
+    free0 = _oracle_alone(model, pb, 12, end_id, top_k=1)
+    free3 = _oracle_alone(model, pb, 12, end_id, top_k=1, repetition_penalty=1.3)
+    reqs = [dict(prompt=pb, n=12, kw=dict(top_k=1), stop_words=[[free0[4]]]),
+            dict(prompt=xs[3], n=10, kw=dict(top_k=1, repetition_penalty=1.5)),
+            dict(prompt=r19, n=9, kw=dict(top_k=1)),
+            dict(prompt=pb, n=12, kw=dict(top_k=1, repetition_penalty=1.3), stop_words=[[7, 8, 9], free3[5:7]]),
+            dict(prompt=xs[0], n=8, kw=dict(top_k=1, repetition_penalty=0.8)),
+            dict(prompt=r7, n=6, kw=dict(top_k=1, repetition_penalty=0.8))]
+    ref = [_oracle_alone(model, r["prompt"], r["n"], end_id, stop_words=r.get("stop_words"), **r["kw"]) for r in reqs]
+    assert len(ref[0]) == 5 and len(ref[3]) == 7  # the stop sequences really end those two requests early
+    cb = ContinuousBatcher(op, max_batch=3, page_tokens=8, num_pages=24, max_seq_len=64)
+    ids = {}
+    arrivals = {0: [0, 1], 1: [2], 3: [3, 4], 6: [5]}
+    got, it = {}, 0
+    while arrivals or cb.busy():
+        for k in arrivals.pop(it, []):
+            r = reqs[k]
+            kw = dict(r["kw"])
+            ids[cb.submit(r["prompt"], r["n"], top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 0.0),
+                          temperature=kw.get("temperature", 1.0), seed=kw.get("random_seed", 0),
+                          repetition_penalty=kw.get("repetition_penalty", 1.0), stop_words=r.get("stop_words"))] = k
+        for rid, tok, fin in cb.step():
+            got.setdefault(ids[rid], []).append(tok)
+        it += 1
+        assert it < 1000
+    for k in range(len(reqs)):
+        assert got[k] == ref[k], (k, got[k], ref[k])
+    assert cb.status()["free_pages"] == 24
+
+
+def test_a_seeded_sampling_request_is_the_same_alone_and_in_a_busy_batcher(gh):
+    """The uniform draws depend on the request's seed and draw count only (curand_init(seed, 0, 0) per row in the reference:
+    sampling_topk_kernels.cu:32-65), not on the admission row or the slot a request lands in."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V = cfg["vocab_size"]
+    op = gh.make_op(cfg, w)
+    prompt = z["prompt"].tolist()
+    kw = dict(top_k=8, top_p=0.95, temperature=1.1, seed=77)
+    cb = ContinuousBatcher(op, max_batch=4, page_tokens=8, num_pages=32, max_seq_len=64)
+    rid = cb.submit(prompt, 10, **kw)
+    alone = cb.run_all()[rid]
+    rng = np.random.RandomState(2)
+    for i in range(3):  # occupy slots 0..2 first: the request lands in slot 3 and is admitted as a later row of a batch
+        cb.submit(rng.randint(3, V, size=11 + i).tolist(), 14, top_k=1)
+    cb.step()
+    rid2 = cb.submit(prompt, 10, **kw)
+    busy = cb.run_all()[rid2]
+    assert busy == alone, (busy, alone)

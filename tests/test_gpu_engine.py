@@ -138,12 +138,16 @@ def test_sampling_topk_topp_penalties_follow_oracle(gh, tiny):
     r = gh.run_op(op, ids, [16] * B, 8, cfg["vocab_size"], **kw)
     sp = orc.Sampling(B, **kw)
     o = orc.Model(dict(cfg, fp16=1), layers, glob).generate(ids, [16] * B, 8, sampling=sp, return_logits=True)
-    # identical uniforms + (value desc, index asc) ordering on both sides -> identical draws unless fp16-level logit
-    # noise moves a cumulative boundary: require agreement on the large majority of positions
-    # (one of the three rows may leave the oracle's trajectory at any step -- after that its draws condition on another
-    # history -- so the bound is "at most one row, or late divergences": 64 of 72 positions)
-    agree = (r["output_ids"] == o["output_ids"]).mean()
-    assert agree > 0.85, agree
+    # identical uniforms + (value desc, index asc) ordering on both sides -> identical draws unless fp16-level logit noise
+    # moves a cumulative boundary; a row that leaves the oracle's trajectory conditions on another history from there on.
+    # Stated per row (round 2 accepted 85 % of all positions): at least two of the three rows are identical to the oracle's
+    # from the first to the last token, and the third agrees at least on its first generated token (same history, same
+    # uniform, logits within 5e-3).  The kernels themselves are checked exactly, on the GPU's own logits, by
+    # test_sampling_kernels_reproduce_the_oracle_given_the_same_logits.
+    same = [r["output_ids"][b].tolist() == o["output_ids"][b].tolist() for b in range(B)]
+    assert sum(same) >= B - 1, (same, r["output_ids"], o["output_ids"])
+    for b in range(B):
+        assert r["output_ids"][b, 16] == o["output_ids"][b, 16], (b, r["output_ids"][b], o["output_ids"][b])
 
 
 def test_stop_words_optional_last_tokens_and_callback(gh, tiny):

@@ -128,7 +128,7 @@ def test_two_processes_fall_back_together_when_the_windows_are_refused(gh, tmp_p
     outs = [str(tmp_path / f"r{r}.npz") for r in range(2)]
     procs = []
     for r in range(2):
-        env = dict(os.environ, FTCF_PERSIST_NB="128", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, FTCF_PERSIST_NB="128", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", FTCF_TEST_EXPECT_FALLBACK="1")
         if r == 1:
             env["FTCF_TP_WINDOWS"] = "0"
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tp_process_worker.py"), str(r), "2", port, "tiny",

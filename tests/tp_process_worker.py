@@ -29,14 +29,29 @@ def main():
         cfg, w, _ = load_tiny()
     else:
         cfg, w = MID, random_model(MID, seed=11)
-    op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD)
-    res = {}
-    for name, (ids, lens, n_out, kw) in requests(cfg, model).items():
-        r = gh.run_op(op, ids, lens, n_out, cfg["vocab_size"], **kw)
-        st = op.stats()
-        res[name + ".output_ids"] = r["output_ids"]
-        res[name + ".logits"] = r["logits"]
-        res[name + ".decode_path"] = np.array([st["decode_path"]])
+    # Two processes on one GPU run concurrently in practice but nothing guarantees it: when the peer's kernel is not
+    # scheduled next to this one, the bounded hand-off gives up, every rank learns of it, the request is replayed on the
+    # collective path and the engine stays there (the designed fall-back).  The test is about the in-kernel path, so a
+    # run in which a one- or two-row request left it is repeated with fresh engines, up to three times.
+    reqs = requests(cfg, model)
+    for attempt in range(3):
+        op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD)
+        res = {}
+        left = 0
+        for name, (ids, lens, n_out, kw) in reqs.items():
+            r = gh.run_op(op, ids, lens, n_out, cfg["vocab_size"], **kw)
+            st = op.stats()
+            res[name + ".output_ids"] = r["output_ids"]
+            res[name + ".logits"] = r["logits"]
+            res[name + ".decode_path"] = np.array([st["decode_path"]])
+            if ids.shape[0] <= 2 and st["decode_path"] != 1 and os.environ.get("FTCF_TEST_EXPECT_FALLBACK") != "1":
+                left = 1
+        flag = torch.tensor([left])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        res["attempts"] = np.array([attempt + 1])
+        del op
+        if int(flag.item()) == 0:
+            break
     np.savez(out, **res)
     dist.barrier()
     dist.destroy_process_group()
