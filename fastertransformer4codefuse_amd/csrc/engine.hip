@@ -1061,6 +1061,12 @@ struct ftcf_gptneox {
         }
         if (stream) {
             (void)hipStreamDestroy(stream);
+            for (int c = 0; c < 2; c++) {
+                if (ov_done[c]) {
+                    (void)hipEventDestroy(ov_done[c]);
+                    (void)hipEventDestroy(ov_red[c]);
+                }
+            }
             if (side) {
                 (void)hipStreamDestroy(side);
                 (void)hipEventDestroy(ev_fork);
@@ -1251,20 +1257,21 @@ struct ftcf_gptneox {
                       &smallm_seq);
     }
 
-    void allreduce(f16* buf, size_t count)
+    void allreduce(f16* buf, size_t count, hipStream_t on = nullptr)
     {
         if (cfg.tensor_para_size > 1) {
             Range r("ftcf.allreduce");
+            hipStream_t st = on ? on : stream;
             FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local || cfg.comm->hx), "tensor_para_size > 1 needs a communicator");
             if (cfg.comm->local) {
-                local_allreduce(cfg.comm, buf, count, true, stream);
+                local_allreduce(cfg.comm, buf, count, true, st);
                 return;
             }
             if (cfg.comm->hx) {
-                hx_allreduce(cfg.comm, buf, count, true, stream);
+                hx_allreduce(cfg.comm, buf, count, true, st);
                 return;
             }
-            FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, stream));
+            FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, st));
         }
     }
 
@@ -1372,8 +1379,86 @@ struct ftcf_gptneox {
 
     // GptNeoXContextDecoder::forward (GptNeoXContextDecoder.cc:283-507), parallel residual only
     // B prompt rows; their K/V go to cache rows b * tile of a cache with B * tile rows (beam search: tile = beam_width)
+    // Prompt phase under tensor parallelism with the per-layer all-reduce OVERLAPPED (GptNeoXContextDecoder.cc:462-465 calls
+    // ftNcclAllReduceSum on the compute stream, nothing runs under it).  The prompt is cut into two micro-batches -- whole
+    // sequences when there are several (their attention is independent), the first and the second half of the tokens of a
+    // single sequence (every GEMM / LayerNorm / residual is row wise, and the second half's attention reads the first half's
+    // K/V from the cache, where the first half's attention call has put them).  A layer runs micro-batch 0, then 1, on the
+    // engine stream; each micro-batch's all-reduce goes to the side stream behind an event, and the NEXT layer's work on that
+    // micro-batch waits for it: the reduction of one half runs under the GEMMs of the other.  Same arithmetic per row as
+    // context_decoder (the all-reduce sums the same values): results are bit-identical to the un-overlapped path.
+    hipEvent_t ov_done[2] = {nullptr, nullptr}, ov_red[2] = {nullptr, nullptr};
+    bool context_decoder_overlapped(int B, int S, const int* input_lengths, int s_max)
+    {
+        const int env = getenv("FTCF_PREFILL_OVERLAP") ? atoi(getenv("FTCF_PREFILL_OVERLAP")) : 1;  // (read per request: the tests flip it)
+        static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;
+        if (!env || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side || valu_form) {
+            return false;
+        }
+        // micro-batches: rows [r0[c], r1[c]) of the [B * S] row space; sequences [b0, b1) x tokens [s0, s1)
+        int b0[2] = {0, 0}, b1[2] = {B, B}, s0[2] = {0, 0}, s1[2] = {S, S};
+        if (B >= 2) {
+            b1[0] = b0[1] = B / 2;
+        }
+        else {
+            const int cut = (S / 2) / 64 * 64;
+            if (cut < 64) {
+                return false;  // too short to be worth two micro-batches
+            }
+            s1[0] = s0[1] = cut;
+        }
+        Range r("ftcf.GptNeoXContextDecoder.overlapped");
+        const size_t cache_l = (size_t)B * nhl * s_max * dh;
+        for (int c = 0; c < 2; c++) {
+            if (!ov_done[c]) {
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&ov_done[c], hipEventDisableTiming));
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&ov_red[c], hipEventDisableTiming));
+            }
+        }
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            for (int c = 0; c < 2; c++) {
+                const size_t row0 = (size_t)b0[c] * S + s0[c];
+                const int    m    = (B >= 2) ? (b1[c] - b0[c]) * S : s1[c] - s0[c];
+                if (l > 0) {
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ov_red[c], 0));  // this micro-batch's x has been reduced
+                }
+                f16* X = px + row0 * H;
+                launch_residual_dual_ln(X, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm + row0 * H,
+                                        pnrm2 + row0 * H, m, H, 1e-5f, stream);
+                gemm(pnrm + row0 * H, w.qkv, nullptr, 0, pqkv + row0 * 3 * hl, m, 3 * hl, H);
+                if (B >= 2) {
+                    const size_t cb = (size_t)b0[c] * nhl * s_max * dh;
+                    launch_context_attention(pqkv + row0 * 3 * hl, w.qkv.bias, input_lengths + b0[c], k_cache + l * cache_l + cb,
+                                             v_cache + l * cache_l + cb, b1[c] - b0[c], S, nhl, dh, cfg.rotary_embedding_dim, s_max,
+                                             pctx + row0 * hl, stream, 1);
+                }
+                else {
+                    launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, 1, S, nhl,
+                                             dh, cfg.rotary_embedding_dim, s_max, pctx, stream, 1, s0[c], s1[c]);
+                }
+                gemm(pctx + row0 * hl, w.attn_out, nullptr, 0, patt + row0 * H, m, H, hl);
+                gemm(pnrm2 + row0 * H, w.ffn1, w.ffn1.bias, 1, pmid + row0 * il, m, il, H);
+                gemm(pmid + row0 * il, w.ffn2, nullptr, 0, pffn + row0 * H, m, H, il);
+                launch_add_bias_attn_ffn_residual(X, pffn + row0 * H, patt + row0 * H, X, w.ffn2.bias, m, H, cfg.tensor_para_size,
+                                                  1, true, stream);
+                FTCF_HIP_CHECK(hipEventRecord(ov_done[c], stream));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(side, ov_done[c], 0));
+                allreduce(X, (size_t)m * H, side);
+                FTCF_HIP_CHECK(hipEventRecord(ov_red[c], side));
+            }
+        }
+        for (int c = 0; c < 2; c++) {
+            FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ov_red[c], 0));
+        }
+        return true;
+    }
+
     void context_decoder(int B, int S, const int* input_lengths, int s_max, int tile)
     {
+        if (tile == 1 && context_decoder_overlapped(B, S, input_lengths, s_max)) {
+            return;
+        }
         Range r("ftcf.GptNeoXContextDecoder");
         const int    M       = B * S;
         const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;

@@ -155,7 +155,8 @@ void   launch_step_prologue(f16* out, const f16* table, const int* output_ids, c
                             const int* pad_count, int B, int H, int rot, hipStream_t s);
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
-                                hipStream_t s, int cache_row_mult = 1);  // K/V of prompt row b live in cache row b * mult
+                                hipStream_t s, int cache_row_mult = 1, int s_lo = 0,
+                                int s_hi = -1);  // K/V of prompt row b live in cache row b * mult
 
 // paged decoder attention (continuous batching front end): per-slot page tables into a shared K/V pool
 struct MmhaPagedParams {

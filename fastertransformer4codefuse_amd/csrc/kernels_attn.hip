@@ -139,11 +139,13 @@ void launch_mmha(const MmhaParams& p, hipStream_t s)
 template<bool VEC>
 __global__ __launch_bounds__(256) void k_qkv_bias_rotary_cache(f16* qkv, const f16* __restrict__ qkv_bias,
                                                                const int* __restrict__ input_lengths, f16* k_cache,
-                                                               f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm)
+                                                               f16* v_cache, int S, int nh, int dh, int rot, int s_max, int crm,
+                                                               int s_lo, int ns)
 {
+    // (token range [s_lo, s_lo + ns) of every sequence: the whole prompt, or one micro-batch of a chunked prompt phase)
     __shared__ float s_cs[128], s_sn[128];
-    const int  row = blockIdx.x;
-    const int  b = row / S, s = row % S;
+    const int  b = blockIdx.x / ns, s = s_lo + blockIdx.x % ns;
+    const int  row = b * S + s;
     const int  hl = nh * dh, half = rot / 2;
     const bool valid = s < input_lengths[b];
     if ((int)threadIdx.x < half) {
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
                                                                 const int* __restrict__ input_lengths,
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
-                                                                f16* __restrict__ ctx, float qk_scale, int crm)
+                                                                f16* __restrict__ ctx, float qk_scale, int crm, int s_lo)
 {
     constexpr int KT  = 64;        // keys per tile
     constexpr int LDK = DH + 8;    // sK row (halves): rows start in different banks
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
     __shared__ __attribute__((aligned(16))) f16 sVt[DH * LDV];
     __shared__ __attribute__((aligned(16))) f16 sP[4][16 * LDP];
 
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = s_lo + blockIdx.x * 64;  // (s_lo: first query row of a chunked prompt phase)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int hl  = nh * DH;
@@ -507,23 +509,29 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
 
 void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                               f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx, hipStream_t s,
-                              int cache_row_mult)
+                              int cache_row_mult, int s_lo, int s_hi)
 {
+    // [s_lo, s_hi): the query / new-key rows of this call (a micro-batch of a chunked prompt phase: the keys below s_lo are
+    // in the cache already); default the whole prompt
+    s_hi = s_hi < 0 ? S : s_hi;
+    FTCF_CHECK_ARG(s_lo >= 0 && s_lo < s_hi && s_hi <= S, "bad token range");
+    const int ns = s_hi - s_lo;
     FTCF_CHECK_ARG(dh == 64 || dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(S <= s_max, "prompt longer than the cache");
     FTCF_CHECK_ARG(rot <= 256, "rotary_embedding_dim must be <= 256");
     if (rot % 16 == 0) {
-        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<true>, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
-                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<true>, dim3(B * ns), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
+                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult, s_lo, ns);
     }
     else {
-        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<false>, dim3(B * S), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
-                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult);
+        hipLaunchKernelGGL(k_qkv_bias_rotary_cache<false>, dim3(B * ns), dim3(256), 0, s, const_cast<f16*>(qkv), qkv_bias,
+                           input_lengths, k_cache, v_cache, S, nh, dh, rot, s_max, cache_row_mult, s_lo, ns);
     }
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
     static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
     if (valu_form) {
+        FTCF_CHECK_ARG(s_lo == 0 && s_hi == S, "the VALU form of the prompt attention takes whole prompts");
         dim3 grid((S + 15) / 16, nh, B);
         if (dh == 128) {
             hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
@@ -535,14 +543,14 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
         }
     }
     else {
-        dim3 grid((S + 63) / 64, nh, B);
+        dim3 grid((ns + 63) / 64, nh, B);
         if (dh == 128) {
             hipLaunchKernelGGL(k_context_attention_mfma<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale, cache_row_mult);
+                               nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);
         }
         else {
             hipLaunchKernelGGL(k_context_attention_mfma<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale, cache_row_mult);
+                               nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);
         }
     }
     FTCF_HIP_CHECK(hipGetLastError());

@@ -144,3 +144,34 @@ def test_sampling_and_stop_criteria_agree_across_ranks(gh):
     for r in range(1, 4):
         assert res[r]["output_ids"].tolist() == res[0]["output_ids"].tolist()
         np.testing.assert_array_equal(res[r]["cum_log_probs"], res[0]["cum_log_probs"])
+
+
+@pytest.mark.parametrize("shape", ["one_long_prompt", "four_prompts"])
+def test_prompt_phase_with_overlapped_all_reduce_is_bit_identical(gh, monkeypatch, shape):
+    """The prompt phase under tensor parallelism cuts the prompt into two micro-batches (halves of the tokens of one sequence
+    -- the second half's attention reads the first half's K/V from the cache -- or halves of the sequences) and sends each
+    micro-batch's per-layer all-reduce to a side stream, under the other micro-batch's GEMMs (GptNeoXContextDecoder.cc:462-465
+    has it on the compute stream).  Every row sees the same arithmetic: tokens AND logits must equal the un-overlapped
+    path's (FTCF_PREFILL_OVERLAP=0) bit for bit, and match the TP = 1 engine."""
+    cfg = MID
+    w = random_model(cfg, seed=21)
+    rng = np.random.RandomState(9)
+    if shape == "one_long_prompt":
+        S, lens = 333, [333]       # cut at 128: micro-batches of 128 and 205 tokens
+    else:
+        S, lens = 70, [70, 33, 70, 51]
+    B = len(lens)
+    ids = rng.randint(3, cfg["vocab_size"], size=(B, S)).astype(np.int32)
+    for b, n in enumerate(lens):
+        ids[b, n:] = cfg["end_id"]
+    out = 4
+    monkeypatch.setenv("FTCF_PREFILL_OVERLAP", "1")
+    ov = run_tp(gh, cfg, w, 2, 0, ids, lens, out, top_k=1)
+    monkeypatch.setenv("FTCF_PREFILL_OVERLAP", "0")
+    plain = run_tp(gh, cfg, w, 2, 0, ids, lens, out, top_k=1)
+    for r in range(2):
+        assert ov[r]["output_ids"].tolist() == plain[r]["output_ids"].tolist()
+        np.testing.assert_array_equal(ov[r]["logits"], plain[r]["logits"])
+    op1 = gh.make_op(cfg, w)
+    r1 = gh.run_op(op1, ids, lens, out, cfg["vocab_size"], top_k=1)
+    check_against(r1["output_ids"], r1["logits"], ov[0], S, f"overlapped prefill {shape} vs tp1 engine")
