@@ -141,10 +141,17 @@ template<int DH, bool BEAMS = false>
 __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u64* gout, const unsigned tag, int h,
                                              int b, int sp)
 {
-    constexpr int LPK = DH / 8;    // lanes per key/value row (16 B each)
-    constexpr int KPI = 64 / LPK;  // rows per wave-load
+    // lanes per key/value row (16 B each): DH / 8 of them carry data, rounded up to a power of two so that the groups tile a
+    // wave -- the reference's head sizes 48, 80, 96, 144 ... 224 (DecoderSelfAttentionLayer.cc:280-282) leave lanes of a
+    // group idle (they re-read the group's first piece and contribute zeros)
+    static_assert(DH % 8 == 0 && DH >= 32 && DH <= 256, "size_per_head: a multiple of 8 in [32, 256]");
+    constexpr int NSUB = DH / 8;
+    constexpr int LPK  = NSUB <= 4 ? 4 : NSUB <= 8 ? 8 : NSUB <= 16 ? 16 : 32;
+    constexpr int KPI  = 64 / LPK;  // rows per wave-load
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int sub = lane % LPK, grp = lane / LPK;
+    const int  grp = lane / LPK;
+    const bool act = (lane % LPK) < NSUB;
+    const int  sub = act ? lane % LPK : 0;
     const int chunk = (((p.s_max + p.nsplit - 1) / p.nsplit) + 15) & ~15;
     const int t_beg = sp * chunk;
     const f16* kc = p.k_cache + ((size_t)b * p.nh + h) * p.s_max * DH;
@@ -199,7 +206,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     }
     // padding mask of the rows this lane scores, fetched with the same round trip (not inside the qk loop)
     unsigned mask_bits = 0u;
-    if (fast && p.masked_tokens && sub == 0) {
+    if (fast && p.masked_tokens && (lane % LPK) == 0) {
 #pragma unroll
         for (int u = 0; u < UK; u++) {
             int t = t_beg + u * 4 * KPI + wid * KPI + grp;
@@ -271,7 +278,11 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     }
 
     const float inv_sqrt_dh = rsqrtf((float)DH);  // DecoderSelfAttentionLayer.cc:118 with q_scaling 1
-    const f16x8 qv  = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+    f16x8       qv  = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+    if (!act) {
+        qv = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const bool     sub0 = (lane % LPK) == 0;
     const uint8_t* mask = p.masked_tokens ? p.masked_tokens + (size_t)b * p.s_max : nullptr;
 
     // ---- phase 1: qk for the cached keys (fp32 accumulate, MMHA_USE_FP32_ACUM_FOR_FMA) ----
@@ -324,7 +335,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
         a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
         a              = group_sum(a, LPK) * inv_sqrt_dh;
-        if (t < t_cached_end && sub == 0) {
+        if (t < t_cached_end && sub0) {
             const bool m = (u_fast >= 0) ? ((mask_bits >> u_fast) & 1u) != 0u : (mask && mask[t]);
             s_p[t - t_beg] = m ? -INFINITY : a;  // masked keys get probability 0 (:1570,:1610-1622)
             if (!m) {
@@ -343,7 +354,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     }
     if (owns_cur && wid == 0) {  // current token from LDS (:1407-1437)
         float a = 0.f;
-        if (lane < LPK) {
+        if (lane < NSUB) {
             const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
             const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
             a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
@@ -400,7 +411,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     else {
         stream_rows(vc, [&](const u32x4 raw, const int t) { pv_one(raw, t); });
     }
-    if (owns_cur && wid == 0 && grp == 0) {
+    if (owns_cur && wid == 0 && grp == 0 && act) {
         const float pt = s_p[tl - t_beg];
         const f16x8 vv = *reinterpret_cast<const f16x8*>(s_v + sub * 8);
 #pragma unroll
@@ -416,7 +427,7 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
         }
     }
     float* s_o = s_red + 8;  // [4][DH]
-    if (grp == 0) {
+    if (grp == 0 && act) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             s_o[wid * DH + sub * 8 + j] = acc[j];

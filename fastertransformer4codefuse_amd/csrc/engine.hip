@@ -1390,7 +1390,11 @@ struct ftcf_gptneox {
     hipEvent_t ov_done[2] = {nullptr, nullptr}, ov_red[2] = {nullptr, nullptr};
     bool context_decoder_overlapped(int B, int S, const int* input_lengths, int s_max)
     {
-        const int env = getenv("FTCF_PREFILL_OVERLAP") ? atoi(getenv("FTCF_PREFILL_OVERLAP")) : 1;  // (read per request: the tests flip it)
+        // OPT-IN (FTCF_PREFILL_OVERLAP=1; read per request, the tests flip it): on the one GPU the builder has, one rank's shard of
+        // the 1024-token prompt phase takes 19.1 -> 27.6 ms (TP 2) / 10.3 -> 18.3 ms (TP 8) in two micro-batches -- GEMMs of 512
+        // rows fill the chip worse than GEMMs of 1024 (profiles/r03_faketp_prefill.txt) -- and what the overlap hides (40 all-reduces
+        // of 10 MiB over xGMI) cannot be measured without the peers.  Whoever has the node should measure both.
+        const int env = getenv("FTCF_PREFILL_OVERLAP") ? atoi(getenv("FTCF_PREFILL_OVERLAP")) : 0;
         static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;
         if (!env || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side || valu_form) {
             return false;
@@ -1575,7 +1579,7 @@ struct ftcf_gptneox {
         Range r("ftcf.GptNeoXDecoder");
         const double wbytes  = int8 ? 1.0 : 2.0;
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
-        const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual;
+        const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual && (dh == 64 || dh == 128);
         stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
@@ -2501,7 +2505,10 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
             FTCF_CHECK_ARG(e->dh >= 32 && e->dh <= 256 && e->dh % 2 == 0, "size_per_head must be even, 32..256");
         }
         else {
-            FTCF_CHECK_ARG(e->dh == 64 || e->dh == 128, "size_per_head must be 64 or 128");
+            // the reference's list (DecoderSelfAttentionLayer.cc:280-282).  64 and 128 run every decode path; the other sizes
+            // take the general path (one attention launch per layer): the persistent and the fused per-stage kernels, and the
+            // paged attention of the batcher, keep their two tuned lane layouts
+            FTCF_CHECK_ARG(mmha_head_size_supported(e->dh), "size_per_head must be one of 32, 48, 64, 80, 96, 128, 144, 160, 192, 224, 256");
             FTCF_CHECK_ARG(e->H % 64 == 0 && e->hl % 64 == 0 && e->il % 64 == 0,
                            "hidden, local hidden and local inter sizes must be multiples of 64");
         }
@@ -2831,8 +2838,8 @@ struct ftcf_batcher {
     void init(ftcf_gptneox* eng, int mb, int page_tokens, int pages, int max_seq_len)
     {
         e = eng;
-        FTCF_CHECK_ARG(!e->fp32 && e->cfg.tensor_para_size == 1 && e->cfg.use_gptj_residual,
-                       "the batcher serves fp16 / int8 engines with parallel residual and tensor_para_size 1");
+        FTCF_CHECK_ARG(!e->fp32 && e->cfg.tensor_para_size == 1 && e->cfg.use_gptj_residual && (e->dh == 64 || e->dh == 128),
+                       "the batcher serves fp16 / int8 engines with parallel residual, tensor_para_size 1 and size_per_head 64 / 128");
         FTCF_CHECK_ARG(mb >= 1 && mb <= 64 && page_tokens >= 8 && pages >= 1 && max_seq_len >= 2, "bad batcher geometry");
         FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
         max_batch = mb;

@@ -148,6 +148,7 @@ size_t mmha_workspace_bytes(int B, int nh, int dh, int nsplit);
 int    mmha_pick_nsplit(int B, int nh, int s_max);
 size_t mmha_smem_bytes(int dh, int s_max, int nsplit);
 void   launch_mmha(const MmhaParams& p, hipStream_t s);
+bool   mmha_head_size_supported(int dh);  // the reference's list (DecoderSelfAttentionLayer.cc:280-282)
 // {cos, sin}(pos * 10000^(-2j/rot)), pos = step - 1 - pad_count[b], once per token (decoder_masked_multihead_attention_utils.h:1325-1329)
 void   launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s);
 // launch_step_embedding + launch_rotary_table in one launch

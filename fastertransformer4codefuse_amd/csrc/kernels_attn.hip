@@ -103,28 +103,38 @@ void launch_rotary_table(float* table, const int* d_step, const int* pad_count, 
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
+// the reference's head sizes (DecoderSelfAttentionLayer.cc:280-282)
+#define FTCF_HEAD_SIZES(X) X(32) X(48) X(64) X(80) X(96) X(128) X(144) X(160) X(192) X(224) X(256)
+bool mmha_head_size_supported(int dh)
+{
+#define X(D) if (dh == D) { return true; }
+    FTCF_HEAD_SIZES(X)
+#undef X
+    return false;
+}
+
 void launch_mmha(const MmhaParams& p, hipStream_t s)
 {
-    FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
+    FTCF_CHECK_ARG(mmha_head_size_supported(p.dh), "size_per_head must be one of 32, 48, 64, 80, 96, 128, 144, 160, 192, 224, 256");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh, "rotary_embedding_dim must be even and <= size_per_head");
     const size_t smem = mmha_smem_bytes(p.dh, p.s_max, p.nsplit);
     dim3         grid(p.nh, p.B, p.nsplit);
     FTCF_CHECK_ARG(p.nsplit >= 1 && p.nsplit <= 16 && p.gran != nullptr, "bad split-KV configuration");
     if (p.cache_indir) {  // beam search
         FTCF_CHECK_ARG(p.beam_width > 1 && p.B % p.beam_width == 0, "cache indirection needs rows = batch * beam_width");
-        if (p.dh == 128) {
-            hipLaunchKernelGGL((k_mmha_split<128, true>), grid, dim3(256), smem, s, p);
-        }
-        else {
-            hipLaunchKernelGGL((k_mmha_split<64, true>), grid, dim3(256), smem, s, p);
-        }
     }
-    else if (p.dh == 128) {
-        hipLaunchKernelGGL((k_mmha_split<128, false>), grid, dim3(256), smem, s, p);
+    const bool beams = p.cache_indir != nullptr;
+#define X(D)                                                                                                           \
+    if (p.dh == D) {                                                                                                   \
+        if (beams) {                                                                                                   \
+            hipLaunchKernelGGL((k_mmha_split<D, true>), grid, dim3(256), smem, s, p);                                  \
+        }                                                                                                              \
+        else {                                                                                                         \
+            hipLaunchKernelGGL((k_mmha_split<D, false>), grid, dim3(256), smem, s, p);                                 \
+        }                                                                                                              \
     }
-    else {
-        hipLaunchKernelGGL((k_mmha_split<64, false>), grid, dim3(256), smem, s, p);
-    }
+    FTCF_HEAD_SIZES(X)
+#undef X
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
@@ -358,18 +368,22 @@ __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict
 // the accumulator layout (a row lives in 16 lanes x 4 key groups), P rounded to half (the reference's softmax output
 // type) and turned into the A operand through a wave-private LDS tile, O += P V with V staged TRANSPOSED in LDS (the B
 // operand wants 8 consecutive keys of one output dim per lane).  Tiles above the diagonal of a wave are skipped.
-template<int DH>
+// DH: any of the reference's head sizes (a multiple of 16; the d steps of Q K^T are padded with zeros to a multiple of 32).
+// KT: keys per tile, 64, or 32 for the sizes above 128 (LDS: K tile + transposed V tile + P tiles <= 64 KB of static LDS).
+template<int DH, int KT = 64>
 __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __restrict__ qkv,
                                                                 const int* __restrict__ input_lengths,
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
                                                                 f16* __restrict__ ctx, float qk_scale, int crm, int s_lo)
 {
-    constexpr int KT  = 64;        // keys per tile
-    constexpr int LDK = DH + 8;    // sK row (halves): rows start in different banks
+    static_assert(DH % 16 == 0 && (KT == 32 || KT == 64), "head size: a multiple of 16");
+    constexpr int ND  = (DH + 31) / 32;  // d steps of Q K^T
+    constexpr int DHK = ND * 32;         // K tile row, padded to whole d steps (the tail holds zeros)
+    constexpr int NKG = KT / 16;         // key groups of a tile
+    constexpr int LDK = DHK + 8;   // sK row (halves): rows start in different banks
     constexpr int LDV = KT + 8;    // sVt row: Vt[d][key]
     constexpr int LDP = KT + 8;    // sP row: P[row][key]
-    constexpr int ND  = DH / 32;   // d steps of Q K^T
     constexpr int NO  = DH / 16;   // output column groups
     __shared__ __attribute__((aligned(16))) f16 sK[KT * LDK];
     __shared__ __attribute__((aligned(16))) f16 sVt[DH * LDV];
@@ -391,7 +405,13 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
         const f16* qp = qkv + ((size_t)b * S + qrow) * 3 * hl + h * DH + g * 8;
 #pragma unroll
         for (int s2 = 0; s2 < ND; s2++) {
-            qf[s2] = *reinterpret_cast<const f16x8*>(qp + s2 * 32);
+            qf[s2] = (s2 * 32 + g * 8 < DH) ? *reinterpret_cast<const f16x8*>(qp + s2 * 32) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    if constexpr (DHK != DH) {  // zero tail of the K tile's rows, once (the staging below rewrites [0, DH) only)
+        for (int i = threadIdx.x; i < KT * (DHK - DH) / 8; i += 256) {
+            const int r = i / ((DHK - DH) / 8), ch = i % ((DHK - DH) / 8);
+            *reinterpret_cast<u32x4*>(&sK[r * LDK + DH + ch * 8]) = u32x4{0u, 0u, 0u, 0u};
         }
     }
     const f16* kc = k_cache + ((size_t)b * crm * nh + h) * s_max * DH;
@@ -435,9 +455,9 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
             continue;  // above this wave's diagonal (the barriers above are still taken by every wave)
         }
         // ---- S = Q K^T : sc[kg][j] = score of row g*4+j and key k0 + kg*16 + c ----
-        f32x4 sc[4];
+        f32x4 sc[NKG];
 #pragma unroll
-        for (int kg = 0; kg < 4; kg++) {
+        for (int kg = 0; kg < NKG; kg++) {
             sc[kg] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < ND; s2++) {
@@ -449,10 +469,10 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int qi = q0 + wid * 16 + g * 4 + j;
-            float     sv[4];
+            float     sv[NKG];
             float     mt = -INFINITY;
 #pragma unroll
-            for (int kg = 0; kg < 4; kg++) {
+            for (int kg = 0; kg < NKG; kg++) {
                 const int  key   = k0 + kg * 16 + c;
                 const bool valid = (key <= qi) && (qi < len);
                 sv[kg]           = valid ? qk_scale * sc[kg][j] : -INFINITY;
@@ -466,7 +486,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
             const float al = (m_run[j] == -INFINITY) ? 0.f : __expf(m_run[j] - mn);
             float       ls = 0.f;
 #pragma unroll
-            for (int kg = 0; kg < 4; kg++) {
+            for (int kg = 0; kg < NKG; kg++) {
                 const float e = (sv[kg] == -INFINITY || mn == -INFINITY) ? 0.f : __expf(sv[kg] - mn);
                 ls += e;
                 sPw[(g * 4 + j) * LDP + kg * 16 + c] = (f16)e;
@@ -516,7 +536,7 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     s_hi = s_hi < 0 ? S : s_hi;
     FTCF_CHECK_ARG(s_lo >= 0 && s_lo < s_hi && s_hi <= S, "bad token range");
     const int ns = s_hi - s_lo;
-    FTCF_CHECK_ARG(dh == 64 || dh == 128, "size_per_head must be 64 or 128");
+    FTCF_CHECK_ARG(mmha_head_size_supported(dh), "size_per_head must be one of 32, 48, 64, 80, 96, 128, 144, 160, 192, 224, 256");
     FTCF_CHECK_ARG(S <= s_max, "prompt longer than the cache");
     FTCF_CHECK_ARG(rot <= 256, "rotary_embedding_dim must be <= 256");
     if (rot % 16 == 0) {
@@ -531,7 +551,7 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
     static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
     if (valu_form) {
-        FTCF_CHECK_ARG(s_lo == 0 && s_hi == S, "the VALU form of the prompt attention takes whole prompts");
+        FTCF_CHECK_ARG(s_lo == 0 && s_hi == S && (dh == 64 || dh == 128), "the VALU form of the prompt attention takes whole prompts and head sizes 64 / 128");
         dim3 grid((S + 15) / 16, nh, B);
         if (dh == 128) {
             hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
@@ -544,14 +564,13 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     }
     else {
         dim3 grid((ns + 63) / 64, nh, B);
-        if (dh == 128) {
-            hipLaunchKernelGGL(k_context_attention_mfma<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);
-        }
-        else {
-            hipLaunchKernelGGL(k_context_attention_mfma<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S,
-                               nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);
-        }
+#define X(D)                                                                                                           \
+    if (dh == D) {                                                                                                     \
+        hipLaunchKernelGGL((k_context_attention_mfma<D, (D > 128 ? 32 : 64)>), grid, dim3(256), 0, s, qkv, input_lengths,\
+                           k_cache, v_cache, S, nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);                       \
+    }
+        FTCF_HEAD_SIZES(X)
+#undef X
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }

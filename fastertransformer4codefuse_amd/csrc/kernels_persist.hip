@@ -184,7 +184,9 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (pl.smem > 160 * 1024) {
         return pl;
     }
-    static const int qrot = getenv("FTCF_PERSIST_QROT") ? atoi(getenv("FTCF_PERSIST_QROT")) : 0;
+    // (round 3, on the kernel with the DPP reductions: the light share on the odd XCDs -- rotation 1 or 3 -- measures 2468-2469 us per
+    // launch against 2480-2486 with it on the even ones, in two builds: profiles/r03_notes.md)
+    static const int qrot = getenv("FTCF_PERSIST_QROT") ? atoi(getenv("FTCF_PERSIST_QROT")) : 1;
     pl.qrot = ((qrot % NB) + NB) % NB;
     pl.ok = 1;
     return pl;

@@ -475,7 +475,15 @@ void orc_mmha_step_beam(const float* qkv, const float* qkv_bias, float* k_cache,
             /* P.V with fp32 accumulation in V_PER_ITER thread groups, then a tree reduction whose upper half
              * passes through T shared memory (:1692-1696, :1866-1890). */
             int threads = (tl < 32) ? 64 : ((tl < 2048) ? 128 : 256);
-            int tpv     = fp16 ? (dh * 2 / 16) : (dh * 4 / 16); /* THREADS_PER_VALUE */
+            /* THREADS_PER_VALUE comes from Dh_MAX, the head size rounded up to a power of two: the dispatch of
+             * decoder_masked_multihead_attention.cu:29-59 launches <T, Dh, Dh_MAX> = <48, 64>, <80, 128>, <144, 256> ... and
+             * the template sizes its thread groups by Dh_MAX (…template.hpp:1112), so V_PER_ITER is a power of two for
+             * every head size and the tree below never drops a group */
+            int dh_max = 32;
+            while (dh_max < dh) {
+                dh_max *= 2;
+            }
+            int tpv = fp16 ? (dh_max * 2 / 16) : (dh_max * 4 / 16); /* THREADS_PER_VALUE */
             if (tpv < 1) {
                 tpv = 1;
             }

@@ -172,6 +172,39 @@ def test_stop_words_optional_last_tokens_and_callback(gh, tiny):
     assert r2["output_ids"].tolist() == o2["output_ids"].tolist()
 
 
+@pytest.mark.parametrize("dh", [48, 80, 96, 160, 256])
+def test_other_head_sizes_run_the_general_path_against_the_oracle(gh, dh):
+    """size_per_head outside {64, 128} (the reference dispatches 32 ... 256, decoder_masked_multihead_attention.cu:29-59): the
+    engine takes the general path -- one attention launch per layer, lane groups padded to a power of two -- for one row and
+    for a ragged batch, fp16 and int8; tokens and logits against the oracle."""
+    cfg = dict(head_num=4, size_per_head=dh, inter_size=4 * 64 * 4, num_layer=2, vocab_size=512, rotary_dim=16, start_id=0,
+               end_id=2)
+    if (4 * dh) % 64:
+        pytest.skip("hidden size must be a multiple of 64")
+    for int8_mode in (0, 1):
+        w = random_model(cfg, seed=300 + dh, std=0.05)
+        layers, glob = weight_list_to_layers(cfg, w)
+        lay = quantize_layers(layers) if int8_mode else layers
+        rng = np.random.RandomState(dh)
+        S, out = 19, 6
+        ids = rng.randint(3, cfg["vocab_size"], size=(3, S)).astype(np.int32)
+        lens = [S, 11, 4]
+        for b, n in enumerate(lens):
+            ids[b, n:] = cfg["end_id"]
+        op = gh.make_op(cfg, w, int8_mode=int8_mode)
+        o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode), lay, glob).generate(ids, lens, out, return_logits=True)
+        for B in (1, 3):
+            r = gh.run_op(op, ids[:B], lens[:B], out, cfg["vocab_size"], top_k=1)
+            assert op.stats()["decode_path"] == 2
+            for b in range(B):
+                for t in range(out):
+                    _logit_close(r["logits"][t, b], o["logits"][t, b])
+                    if r["output_ids"][b, lens[b] + t] != o["output_ids"][b, lens[b] + t]:
+                        top2 = np.sort(o["logits"][t, b])[-2:]
+                        assert top2[1] - top2[0] < 2 * LOGIT_FRAC * np.abs(o["logits"][t, b]).max(), "token flip without a near tie"
+                        break
+
+
 def test_engine_is_deterministic_across_calls(gh, tiny):
     cfg, w, layers, glob, z = tiny
     op = gh.make_op(cfg, w, int8_mode=1)

@@ -172,10 +172,18 @@ def test_layernorm_and_residual_match_oracle_rounding_points():
             np.testing.assert_array_equal(o2.cpu().float().numpy(), ref)  # elementwise: bit exact
 
 
-@pytest.mark.parametrize("dh,nh,rot", [(128, 5, 32), (64, 4, 16)])
-@pytest.mark.parametrize("tl,s_max", [(0, 1024), (1, 1024), (31, 1024), (100, 1024), (700, 1024), (5000, 6000), (4099, 4100)])
+# every head size of the reference (DecoderSelfAttentionLayer.cc:280-282): 64 / 128 on the whole (tl, s_max) grid, the others
+# -- lane groups with idle lanes (48, 80, 96, 144 ... 224) or other group widths (32, 256) -- on a short and a looped case
+_MMHA_CASES = [(dh, nh, rot, tl, s_max) for (dh, nh, rot) in [(128, 5, 32), (64, 4, 16)]
+               for (tl, s_max) in [(0, 1024), (1, 1024), (31, 1024), (100, 1024), (700, 1024), (5000, 6000), (4099, 4100)]]
+_MMHA_CASES += [(dh, 3, rot, tl, s_max) for (dh, rot) in [(32, 32), (48, 16), (80, 80), (96, 24), (144, 64), (160, 32), (192, 192),
+                                                          (224, 56), (256, 128)]
+                for (tl, s_max) in [(100, 1024), (2500, 2600)]]
+
+
+@pytest.mark.parametrize("dh,nh,rot,tl,s_max", _MMHA_CASES)
 def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl, s_max):
-    """s_max 1024: every KV split fits the all-in-registers form; 6000 / 4100: the looped form (384 / 272 keys per split)."""
+    """s_max 1024: every KV split fits the all-in-registers form; 6000 / 4100 / 2600: the looped form."""
     rng = np.random.RandomState(tl + dh)
     B = 3
     hl = nh * dh
@@ -211,7 +219,8 @@ def test_masked_multihead_attention_matches_oracle(dh, nh, rot, tl, s_max):
     assert np.all(got[2] == 0)  # finished row untouched
 
 
-@pytest.mark.parametrize("dh,nh,rot", [(128, 3, 32), (64, 4, 16)])
+@pytest.mark.parametrize("dh,nh,rot", [(128, 3, 32), (64, 4, 16), (32, 2, 32), (48, 3, 16), (80, 2, 80), (96, 2, 24), (144, 2, 64),
+                                       (160, 2, 32), (192, 2, 192), (224, 1, 56), (256, 2, 128)])
 def test_context_attention_matches_oracle(dh, nh, rot):
     rng = np.random.RandomState(11)
     B, S, s_max = 2, 70, 96
