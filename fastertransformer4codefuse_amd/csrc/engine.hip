@@ -23,6 +23,7 @@
 #include "ftcf_common.h"
 #include "host_quant.h"
 #include "kernels.h"
+#include "layers.hip.h"
 
 using namespace ftcf;
 
@@ -923,16 +924,8 @@ extern "C" int ftcf_context_attention(const void* qkv, const void* qkv_bias, con
 // the engine
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-
-struct DenseWeight {  // layers/DenseWeight.h:29-66
-    const void* kernel = nullptr;  // tiled (int8 or fp16)
-    const f16*  scale  = nullptr;  // weight_only_quant_scale
-    const f16*  bias   = nullptr;
-};
-struct LayerWeights {  // models/gptneox/GptNeoXDecoderLayerWeight.h
-    const f16 *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-    DenseWeight qkv, attn_out, ffn1, ffn2;
-};
+// (DenseWeight / LayerWeights and the host-side layer units DecoderSelfAttentionLayer, GptContextAttentionLayer, FfnLayer,
+// DynamicDecodeLayer: layers.hip.h)
 
 struct DeviceBuffer {
     void*  ptr = nullptr;
@@ -1242,8 +1235,30 @@ struct ftcf_gptneox {
     }
 
     // ---- FfnLayer / attention projections over M rows (general path) ----
-    void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k)
+    // ---- host-side layer units (layers.hip.h), bound to this engine's GEMM dispatch -----------------------------------
+    DecoderSelfAttentionLayer self_attention_layer;
+    GptContextAttentionLayer  context_attention_layer;
+    FfnLayer                  ffn_layer;
+    DynamicDecodeLayer        dynamic_decode_layer;
+    bool                      layers_bound = false;
+    void bind_layers()
     {
+        if (layers_bound) {
+            return;
+        }
+        // (row-count dispatch of gemm(); `slot` is unused here: the burst kernel's four workspace regions are only in flight
+        // together on the two-stream branch form, which names its regions itself)
+        GemmFn g = [this](const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k, hipStream_t s,
+                          int) { gemm(A, w, bias, act, C, m, n, k, s); };
+        self_attention_layer    = DecoderSelfAttentionLayer{g, H, hl};
+        context_attention_layer = GptContextAttentionLayer{g, H, hl, nhl, dh, cfg.rotary_embedding_dim};
+        ffn_layer               = FfnLayer{g, H, il};
+        layers_bound            = true;
+    }
+
+    void gemm(const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int m, int n, int k, hipStream_t on = nullptr)
+    {
+        hipStream_t stream = on ? on : this->stream;  // (the layer units pass the stream they were given)
         // 5..SMALLM_MAX_ROWS rows (batched decode steps off the branch form, short prompt phases): the burst kernel, 16 rows
         // per launch.  13B int8 prefill, ms: 17 tokens 12.5 -> 6.6, 33..48: 16.3 -> 9.6 (above that the tiled GEMM is as fast).
         if (smallm_ws && m > 4 && m <= SMALLM_MAX_ROWS && gemm_smallm_workspace_bytes(16, n, k, int8) <= smallm_partial) {
@@ -1412,6 +1427,7 @@ struct ftcf_gptneox {
             s1[0] = s0[1] = cut;
         }
         Range r("ftcf.GptNeoXContextDecoder.overlapped");
+        bind_layers();
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         for (int c = 0; c < 2; c++) {
             if (!ov_done[c]) {
@@ -1430,20 +1446,17 @@ struct ftcf_gptneox {
                 f16* X = px + row0 * H;
                 launch_residual_dual_ln(X, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm + row0 * H,
                                         pnrm2 + row0 * H, m, H, 1e-5f, stream);
-                gemm(pnrm + row0 * H, w.qkv, nullptr, 0, pqkv + row0 * 3 * hl, m, 3 * hl, H);
-                if (B >= 2) {
+                if (B >= 2) {  // whole sequences [b0, b1): the attention layer on their rows of every buffer
                     const size_t cb = (size_t)b0[c] * nhl * s_max * dh;
-                    launch_context_attention(pqkv + row0 * 3 * hl, w.qkv.bias, input_lengths + b0[c], k_cache + l * cache_l + cb,
-                                             v_cache + l * cache_l + cb, b1[c] - b0[c], S, nhl, dh, cfg.rotary_embedding_dim, s_max,
-                                             pctx + row0 * hl, stream, 1);
+                    context_attention_layer.forward(pnrm + row0 * H, pqkv + row0 * 3 * hl, pctx + row0 * hl, patt + row0 * H, w,
+                                                    input_lengths + b0[c], k_cache + l * cache_l + cb, v_cache + l * cache_l + cb,
+                                                    b1[c] - b0[c], S, s_max, 1, stream);
                 }
-                else {
-                    launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, 1, S, nhl,
-                                             dh, cfg.rotary_embedding_dim, s_max, pctx, stream, 1, s0[c], s1[c]);
+                else {  // tokens [s0, s1) of the one sequence: the earlier tokens' K/V are in the cache
+                    context_attention_layer.forward(pnrm, pqkv, pctx, patt, w, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l,
+                                                    1, S, s_max, 1, stream, s0[c], s1[c]);
                 }
-                gemm(pctx + row0 * hl, w.attn_out, nullptr, 0, patt + row0 * H, m, H, hl);
-                gemm(pnrm2 + row0 * H, w.ffn1, w.ffn1.bias, 1, pmid + row0 * il, m, il, H);
-                gemm(pmid + row0 * il, w.ffn2, nullptr, 0, pffn + row0 * H, m, H, il);
+                ffn_layer.forward(pnrm2 + row0 * H, pmid + row0 * il, pffn + row0 * H, w, m, stream);
                 launch_add_bias_attn_ffn_residual(X, pffn + row0 * H, patt + row0 * H, X, w.ffn2.bias, m, H, cfg.tensor_para_size,
                                                   1, true, stream);
                 FTCF_HIP_CHECK(hipEventRecord(ov_done[c], stream));
@@ -1464,6 +1477,7 @@ struct ftcf_gptneox {
             return;
         }
         Range r("ftcf.GptNeoXContextDecoder");
+        bind_layers();
         const int    M       = B * S;
         const size_t cache_l = (size_t)B * tile * nhl * s_max * dh;
         // parallel-residual layers: both LayerNorms in one pass, fused with the previous layer's residual when no collective
@@ -1479,18 +1493,15 @@ struct ftcf_gptneox {
                 launch_residual_dual_ln(px, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm, pnrm2,
                                         M, H, 1e-5f, stream);
             }
-            gemm(pnrm, w.qkv, nullptr, 0, pqkv, M, 3 * hl, H);
-            launch_context_attention(pqkv, w.qkv.bias, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B,
-                                     S, nhl, dh, cfg.rotary_embedding_dim, s_max, pctx, stream, tile);
-            gemm(pctx, w.attn_out, nullptr, 0, patt, M, H, hl);
+            context_attention_layer.forward(pnrm, pqkv, pctx, patt, w, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, B, S,
+                                            s_max, tile, stream);
             if (!cfg.use_gptj_residual) {
                 // sequential residual (GptNeoXContextDecoder.cc:401-418,463-470): the TensorParallel layers reduce their
                 // own outputs; h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h
                 allreduce(patt, (size_t)M * H);
                 launch_add_bias_residual(patt, px, patt, w.attn_out.bias, M, H, stream);
                 launch_layernorm(patt, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
-                gemm(pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
-                gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
+                ffn_layer.forward(pnrm, pmid, pffn, w, M, stream);
                 allreduce(pffn, (size_t)M * H);
                 launch_add_bias_residual(px, pffn, patt, w.ffn2.bias, M, H, stream);
                 continue;
@@ -1498,8 +1509,7 @@ struct ftcf_gptneox {
             if (!dual) {
                 launch_layernorm(px, w.ln2_g, w.ln2_b, pnrm, M, H, 1e-5f, true, stream);
             }
-            gemm(dual ? pnrm2 : pnrm, w.ffn1, w.ffn1.bias, 1, pmid, M, il, H);
-            gemm(pmid, w.ffn2, nullptr, 0, pffn, M, H, il);
+            ffn_layer.forward(dual ? pnrm2 : pnrm, pmid, pffn, w, M, stream);
             // layer_input == layer_output for every layer with padding removal -> fp32-sum variant (:311-322,:445-461)
             if (dual && tp1) {
                 const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
@@ -1577,6 +1587,7 @@ struct ftcf_gptneox {
     void decoder(int B, int s_max)
     {
         Range r("ftcf.GptNeoXDecoder");
+        bind_layers();
         const double wbytes  = int8 ? 1.0 : 2.0;
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
         const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual && (dh == 64 || dh == 128);
@@ -1642,14 +1653,11 @@ struct ftcf_gptneox {
                 if (!cfg.use_gptj_residual) {
                     // sequential residual (GptNeoXDecoder.cc:313-331,362-367): h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h
                     launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
-                    gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
-                    launch_mmha(mp, stream);
-                    gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
+                    self_attention_layer.forward(nrm, qkv, ctx, att, w, mp, B, stream);
                     allreduce(att, (size_t)B * H);
                     launch_add_bias_residual(att, x, att, w.attn_out.bias, B, H, stream);
                     launch_layernorm(att, w.ln2_g, w.ln2_b, nrm, B, H, 1e-5f, true, stream);
-                    gemm(nrm, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
-                    gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                    ffn_layer.forward(nrm, mid, ffn, w, B, stream);
                     allreduce(ffn, (size_t)B * H);
                     launch_add_bias_residual(x, ffn, att, w.ffn2.bias, B, H, stream);
                     continue;
@@ -1687,13 +1695,17 @@ struct ftcf_gptneox {
                             }, s);
                         }
                     };
+                    // the attention layer on the engine stream, the FFN layer on the side stream: the same two layer units, their
+                    // GEMMs bound to the burst kernel with one workspace region per GEMM of the layer
+                    const size_t offs[4] = {o_qkv, o_f1, o_out, o_f2};
+                    GemmFn burst = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int, int n, int k,
+                                       hipStream_t s, int slot) { one(SmallmDesc{A, dw.kernel, dw.scale, bias, act, C, n, k}, offs[slot], s); };
+                    const DecoderSelfAttentionLayer attn_b{burst, H, hl};
+                    const FfnLayer                  ffn_b{burst, H, il};
                     FTCF_HIP_CHECK(hipEventRecord(ev_fork, stream));
                     FTCF_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
-                    one(SmallmDesc{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H}, o_qkv, stream);
-                    one(SmallmDesc{nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}, o_f1, side);
-                    launch_mmha(mp, stream);
-                    one(SmallmDesc{mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}, o_f2, side);
-                    one(SmallmDesc{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl}, o_out, stream);
+                    attn_b.forward(nrm, qkv, ctx, att, w, mp, B, stream);
+                    ffn_b.forward(nrm2, mid, ffn, w, B, side);
                     FTCF_HIP_CHECK(hipEventRecord(ev_join, side));
                     FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_join, 0));
                 }
@@ -1711,11 +1723,8 @@ struct ftcf_gptneox {
                           [&] { launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, stream, &state->step, &smallm_seq); });
                 }
                 else {
-                    gemm(nrm, w.qkv, nullptr, 0, qkv, B, 3 * hl, H);
-                    launch_mmha(mp, stream);
-                    gemm(ctx, w.attn_out, nullptr, 0, att, B, H, hl);
-                    gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, B, il, H);
-                    gemm(mid, w.ffn2, nullptr, 0, ffn, B, H, il);
+                    self_attention_layer.forward(nrm, qkv, ctx, att, w, mp, B, stream);
+                    ffn_layer.forward(nrm2, mid, ffn, w, B, stream);
                 }
                 if (dual && tp1) {
                     const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
@@ -2287,11 +2296,10 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
                                           (size_t)B * V * 4, hipMemcpyDeviceToDevice, stream));
         }
     if (ses.K > 1) {
-        launch_beam_search(ses.bp, stream);
-        launch_decode_finish(ses.sp, stream);
+        dynamic_decode_layer.forward(ses.bp, ses.sp, stream);
     }
     else {
-        launch_dynamic_decode(ses.sp, stream);
+        dynamic_decode_layer.forward(ses.sp, stream);
     }
 }
 
@@ -3103,9 +3111,6 @@ struct ftcf_batcher {
             FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
         }
         hipLaunchKernelGGL(k_batcher_tick, dim3(1), dim3(1), 0, st, d_gstate);
-        auto gemm = [&](const f16* A, const DenseWeight& w, const f16* bias, int act, f16* C, int n, int k) {
-            gemm_dispatch(A, w.kernel, w.scale, bias, act, C, B, n, k, int8, st, nullptr, 0, e->num_cu);
-        };
         for (int l = 0; l < L; l++) {
             const LayerWeights& w = e->layers[l];
             if (!dual) {
@@ -3146,13 +3151,13 @@ struct ftcf_batcher {
                                                  &smallm_seq, off);
                     }
                 };
+                const size_t offs[4] = {o_qkv, o_f1, o_out, o_f2};
+                GemmFn burst = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int, int n, int k,
+                                   hipStream_t s2, int slot) { one(SmallmDesc{A, dw.kernel, dw.scale, bias, act, C, n, k}, offs[slot], s2); };
                 FTCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
                 FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-                one(SmallmDesc{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H}, o_qkv, st);
-                one(SmallmDesc{nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}, o_f1, e->side);
-                launch_mmha_paged(mp, max_len, st);
-                one(SmallmDesc{mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}, o_f2, e->side);
-                one(SmallmDesc{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl}, o_out, st);
+                DecoderSelfAttentionLayer{burst, H, hl}.forward_paged(nrm, qkv, ctx, att, w, mp, max_len, B, st);
+                FfnLayer{burst, H, il}.forward(nrm2, mid, ffn, w, B, e->side);
                 FTCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
                 FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
             }
@@ -3166,11 +3171,12 @@ struct ftcf_batcher {
                 launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
             }
             else {
-                gemm(nrm, w.qkv, nullptr, 0, qkv, 3 * hl, H);
-                launch_mmha_paged(mp, max_len, st);
-                gemm(ctx, w.attn_out, nullptr, 0, att, H, hl);
-                gemm(nrm2, w.ffn1, w.ffn1.bias, 1, mid, il, H);
-                gemm(mid, w.ffn2, nullptr, 0, ffn, H, il);
+                GemmFn plain = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int m, int n, int k,
+                                   hipStream_t s2, int) {
+                    gemm_dispatch(A, dw.kernel, dw.scale, bias, act, C, m, n, k, int8, s2, nullptr, 0, e->num_cu);
+                };
+                DecoderSelfAttentionLayer{plain, H, hl}.forward_paged(nrm, qkv, ctx, att, w, mp, max_len, B, st);
+                FfnLayer{plain, H, il}.forward(nrm2, mid, ffn, w, B, st);
             }
             // (every slot's hidden state is recomputed from its token each step: the residual never aliases across steps,
             // so the fp32-sum variant of the context decoder applies to all layers)
@@ -3221,7 +3227,7 @@ struct ftcf_batcher {
         sp.ws = samp_ws;
         sp.max_top_k = host_max_top_k;
         sp.any_top_p = host_any_top_p;
-        launch_dynamic_decode(sp, st, false);
+        DynamicDecodeLayer{}.forward(sp, st, false);  // (the stop / length criteria are the scheduler's: no finish step)
         hipLaunchKernelGGL(k_batcher_last_token, dim3(1), dim3(64), 0, st, d_tok, d_hist, d_len, B);
         std::vector<int>     tok(B);
         std::vector<uint8_t> fin(B);
