@@ -1154,7 +1154,9 @@ struct ftcf_gptneox {
             // hand-shake failed, FTCF_TP_PERSIST=0) the per-stage launches + RCCL all-reduce stay in charge.
             const int  tpn      = cfg.tensor_para_size;
             const bool tp_local = tpn > 1 && cfg.comm && cfg.comm->local;
-            if (persist && !fp32 && K == 1 && B <= 2 && cfg.use_gptj_residual && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
+            // (L <= 255: the hand-off tags carry the layer in their low byte; tpn <= 8: the exchange-window table of the kernel)
+            if (persist && !fp32 && K == 1 && B <= 2 && cfg.use_gptj_residual && L <= 255 && tpn <= PERSIST_MAX_TP
+                && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, tpn == 1);
@@ -2005,7 +2007,8 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     const bool want_tp = tpn > 1 && persist && persist_tp && K == 1 && B <= 2 && cfg.use_gptj_residual && tpn <= PERSIST_MAX_TP;
     if (want_tp) {
         // (collective: every rank sees the same request shape) room for two rows: [tp][2 * H / 2] granules
-        comm_ensure_window(cfg.comm, (size_t)tpn * H * 8, stream);
+        // (two planes by layer parity: persist_device.hip.h ps_tp_exchange)
+        comm_ensure_window(cfg.comm, (size_t)2 * tpn * H * 8, stream);
     }
     plan(B, S, total, K);
     if (want_tp && pplan.ok) {
@@ -2016,7 +2019,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
             FTCF_HIP_CHECK(hipMemsetAsync(tp_scratch, 0, 256, stream));
         }
         comm_barrier(cfg.comm, stream, tp_scratch);
-        FTCF_HIP_CHECK(hipMemsetAsync(cfg.comm->win[cfg.tensor_para_rank], 0, (size_t)tpn * H * 8, stream));
+        FTCF_HIP_CHECK(hipMemsetAsync(cfg.comm->win[cfg.tensor_para_rank], 0, (size_t)2 * tpn * H * 8, stream));
         comm_barrier(cfg.comm, stream, tp_scratch);
     }
 

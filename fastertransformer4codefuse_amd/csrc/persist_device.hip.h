@@ -1140,13 +1140,18 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
     if ((c & 1) == 0) {
         const size_t   gi   = oidx >> 1;
         const unsigned pair = b0 | (b1 << 16);
+        // Two planes, by layer parity (the tag's low bit is the layer's, tag = step * 256 + 1 + l): a peer writes plane
+        // parity(l) again at layer l + 2 only, and it cannot finish layer l + 1 without THIS rank's layer l + 1 partial,
+        // which this rank produces after it has read layer l -- so a slot is never overwritten under a reader that was
+        // delayed (with one plane a peer a full layer ahead could, and the reader would spin until it gave up).
+        const size_t plane = (size_t)((tag - 1u) & 1u) * (size_t)p.tp * slab;
         for (int r2 = 0; r2 < p.tp; r2++) {
-            __hip_atomic_store((gu64*)(p.xw[r2] + (size_t)p.tp_rank * slab + gi), ((u64)tag << 32) | (u64)pair, PS_RLX,
+            __hip_atomic_store((gu64*)(p.xw[r2] + plane + (size_t)p.tp_rank * slab + gi), ((u64)tag << 32) | (u64)pair, PS_RLX,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
         float lo = 0.f, hi = 0.f;
         for (int r2 = 0; r2 < p.tp; r2++) {
-            const gu64* src = (const gu64*)(p.xw[p.tp_rank] + (size_t)r2 * slab + gi);
+            const gu64* src = (const gu64*)(p.xw[p.tp_rank] + plane + (size_t)r2 * slab + gi);
             u64         v;
             int         sp2 = 0;
             for (;;) {
