@@ -789,7 +789,8 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
         // the sorted candidates (TOPP_K per slice): every candidate ABOVE the largest value a slice may have left out
         // (v_cut = max over the slices that supplied all TOPP_K of their smallest candidate) is at its exact place of the
         // full order, so the same fp32 additions happen in the same order.  Only a walk that gets past v_cut -- a nearly
-        // flat distribution -- falls back to extracting one maximum of the remaining row per pass.
+        // flat distribution -- falls back to sorting the whole row in the workspace (bitonic network, below) and walking it from the
+        // start.
         const float thr = p.top_p_topp[b];
         if (threadIdx.x == 0) {
             const float u01 = ftcf_uniform(p.random_seed[b], 0, p.draw_counter[b]);
