@@ -789,9 +789,10 @@ extern "C" int ftcf_fp16_rowmajor_to_tiled(const void* w, size_t K, size_t N, vo
 // ---------------------------------------------------------------------------------------------------------------
 // kernel-level entry points
 // ---------------------------------------------------------------------------------------------------------------
+static float* abi_gemm_workspace(int m, hipStream_t s);
 static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m,
                           int n, int k, bool int8, hipStream_t s, float* smallm_ws = nullptr, size_t smallm_partial = 0,
-                          int num_cu = 256, const int* d_step = nullptr, unsigned* smallm_seq = nullptr)
+                          int num_cu = 256, const int* d_step = nullptr, unsigned* smallm_seq = nullptr, float* tiled_ws = nullptr)
 {
     if (m <= 4) {
         SplitKParams p{};
@@ -813,8 +814,29 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
                            smallm_seq);
     }
     else {
-        launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s);
+        launch_gemm_tiled(A, W, scale, bias, act, C, m, n, k, int8, s, tiled_ws);
     }
+}
+
+// the stand-alone GEMM entry points carry no workspace argument (the reference's runner takes one from its caller:
+// fpA_intB_gemm.h gemm(..., workspace_ptr, workspace_bytes)): one split-K workspace per (device, stream) that has called with
+// 17..256 rows, kept for the life of the process
+static float* abi_gemm_workspace(int m, hipStream_t s)
+{
+    if (m <= 16) {
+        return nullptr;
+    }
+    static std::mutex                                    mu;
+    static std::map<std::pair<int, hipStream_t>, float*> ws;
+    int                                                  dev = 0;
+    FTCF_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    float*&                     p = ws[{dev, s}];
+    if (!p) {
+        FTCF_HIP_CHECK(hipMalloc(&p, gemm_tiled_workspace_bytes()));
+        FTCF_HIP_CHECK(hipMemset(p, 0, gemm_tiled_workspace_bytes()));
+    }
+    return p;
 }
 
 extern "C" int ftcf_fpA_intB_gemm(const void* A, const int8_t* B, const void* scales, const void* bias, ftcf_act act,
@@ -824,7 +846,7 @@ extern "C" int ftcf_fpA_intB_gemm(const void* A, const int8_t* B, const void* sc
         require_device();
         FTCF_CHECK_ARG(k % 64 == 0 && n % 16 == 0 && m >= 1, "fpA_intB GEMM needs k % 64 == 0, n % 16 == 0");
         gemm_dispatch((const f16*)A, B, (const f16*)scales, (const f16*)bias, (int)act, (f16*)C, m, n, k, true,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, nullptr, 0, 256, nullptr, nullptr, abi_gemm_workspace(m, (hipStream_t)stream));
     });
 }
 extern "C" int ftcf_fp16_gemm(const void* A, const void* W, const void* bias, ftcf_act act, void* C, int m, int n,
@@ -834,7 +856,7 @@ extern "C" int ftcf_fp16_gemm(const void* A, const void* W, const void* bias, ft
         require_device();
         FTCF_CHECK_ARG(k % 64 == 0 && n % 16 == 0 && m >= 1, "fp16 GEMM needs k % 64 == 0, n % 16 == 0");
         gemm_dispatch((const f16*)A, W, nullptr, (const f16*)bias, (int)act, (f16*)C, m, n, k, false,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, nullptr, 0, 256, nullptr, nullptr, abi_gemm_workspace(m, (hipStream_t)stream));
     });
 }
 static void lm_head_dispatch(const f16* A, const f16* W, float* logits, int m, int n, int k, int ldc, hipStream_t s)
@@ -1009,6 +1031,7 @@ struct ftcf_gptneox {
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
+    float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..256 rows (short prompt phases)
     size_t    smallm_partial = 0;
     unsigned  smallm_seq = 0;       // launch counter: part of the granule tag of its in-launch reduction
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
@@ -1195,6 +1218,8 @@ struct ftcf_gptneox {
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
             smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
+            const bool tiled_rows = (prefill_m > 16 && prefill_m <= 256) || (B > 16 && B <= 256);
+            tiled_ws              = (!fp32 && tiled_rows) ? c.take<float>(gemm_tiled_workspace_bytes() / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
             masked             = c.take<uint8_t>((size_t)B * s_max);
@@ -1268,6 +1293,10 @@ struct ftcf_gptneox {
                 launch_gemm_smallm(A + (size_t)r0 * k, w.kernel, w.scale, bias, act, C + (size_t)r0 * n, smallm_ws, smallm_partial,
                                    std::min(16, m - r0), n, k, int8, num_cu, stream, &state->step, &smallm_seq);
             }
+            return;
+        }
+        if (m > 16) {
+            launch_gemm_tiled(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, tiled_ws);
             return;
         }
         gemm_dispatch(A, w.kernel, w.scale, bias, act, C, m, n, k, int8, stream, nullptr, smallm_partial, num_cu, &state->step,
@@ -1748,11 +1777,13 @@ struct ftcf_gptneox {
     // shard); B = 2: 4.13 vs 3.85; B = 3: 4.64 vs 3.65; B = 4: 5.78 vs 3.73 -- the m = 2..4 forms of the GEMV kernels stream
     // at a fraction of the m = 1 rate.  FTCF_STAGE_MAX_ROWS (<= 4) overrides, the tests use it to keep those forms covered.
     int STAGE_MAX_ROWS = 1;
-    // Rows up to which the batched decode GEMMs run the burst kernel, 16 rows per launch (the weights are then read
-    // ceil(B / 16) times).  Above 16 rows the alternative is the prefill-shaped tiled GEMM, which at these row counts is a
-    // few dozen workgroups streaming their weight panels serially: 13B int8, ms per step, tiled vs chunked burst:
-    // bs = 24: 13.8 vs 6.7; 32: 13.9 vs 7.2; 48: - vs 10.5; 64: 19.4 vs 13.7 (FTCF_SMALLM_MAX_ROWS overrides).
-    int SMALLM_MAX_ROWS = 64;
+    // Rows up to which the batched decode GEMMs (and short prompt phases) run the burst kernel, 16 rows per launch (the weights
+    // are then read ceil(B / 16) times).  Above 16 rows the alternative is the tiled GEMM in its split-K form (64-row tiles cut
+    // along K, four k-steps of weights and activations in flight): 13B int8, ms per decode step, chunked burst vs split-K tiled:
+    // bs = 24: 6.8 vs 6.4; 32: 7.4 vs 6.5; 48: 10.2 vs 7.5; 64: 13.6 vs 8.7 -- and prompt phases of 17 / 33 / 64 tokens
+    // 7.0 / 10.2 / 13.8 vs 6.0 / 6.2 / 6.5 ms.  (Round 2's tiled GEMM without the split: 13.8 ms at bs = 24, 19.4 at 64.)
+    // FTCF_SMALLM_MAX_ROWS overrides (<= 256; the chunked form stays covered by the tests through it).
+    int SMALLM_MAX_ROWS = 16;
 
     // decoder attention of rows [r0, r0 + M) of the batch (KV cache [L][B][nh][s_max][dh]); `salt` makes the granule
     // tags of every launch of a token distinct
@@ -2071,6 +2102,10 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     FTCF_HIP_CHECK(hipEventRecord(e0, stream));
     FTCF_HIP_CHECK(hipMemsetAsync(mmha_ws, 0, mmha_workspace_bytes(B, nhl, dh, nsplit), stream));
     FTCF_HIP_CHECK(hipMemsetAsync(chunk_ws, 0, chunk_workspace_bytes(H, std::min(B, 4), 8), stream));
+    if (tiled_ws) {  // tickets of the split-K tiles (re-armed by every launch; a failed request may leave one drawn)
+        FTCF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tiled_ws) + gemm_tiled_workspace_bytes() - gemm_tiled_ticket_bytes(), 0,
+                                      gemm_tiled_ticket_bytes(), stream));
+    }
     if (smallm_ws) {
         // granules of the batched-decode GEMMs' in-launch reduction: their tags repeat from request to request
         FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), stream));
@@ -2817,6 +2852,7 @@ struct ftcf_batcher {
     DecodeState *d_state = nullptr, *d_gstate = nullptr;
     void*        samp_ws = nullptr;
     float*       smallm_ws = nullptr;
+    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..256 rows)
     size_t       smallm_partial = 0;
     unsigned     smallm_seq = 0;
     long         gemm_steps = 0;
@@ -2903,6 +2939,9 @@ struct ftcf_batcher {
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(bc, il, H, i8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, i8) + gemm_smallm_workspace_bytes(bc, H, il, i8);
             smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
+        }
+        if (max_batch > 16 && max_batch <= 256) {
+            tiled_ws = dmalloc<float>(gemm_tiled_workspace_bytes() / 4);
         }
         std::vector<uint8_t> fin(max_batch, 1);
         FTCF_HIP_CHECK(hipMemcpy(d_fin, fin.data(), max_batch, hipMemcpyHostToDevice));
@@ -3176,7 +3215,8 @@ struct ftcf_batcher {
             else {
                 GemmFn plain = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int m, int n, int k,
                                    hipStream_t s2, int) {
-                    gemm_dispatch(A, dw.kernel, dw.scale, bias, act, C, m, n, k, int8, s2, nullptr, 0, e->num_cu);
+                    gemm_dispatch(A, dw.kernel, dw.scale, bias, act, C, m, n, k, int8, s2, nullptr, 0, e->num_cu, nullptr, nullptr,
+                                  s2 == st ? tiled_ws : nullptr);
                 };
                 DecoderSelfAttentionLayer{plain, H, hl}.forward_paged(nrm, qkv, ctx, att, w, mp, max_len, B, st);
                 FfnLayer{plain, H, il}.forward(nrm2, mid, ffn, w, B, st);

@@ -67,8 +67,12 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
 
 // ---- MFMA GEMM (prefill / batched decode) : kernels_gemm.hip ----
 // C[m,n] = A[m,k] x W(tiled)  (+bias, gelu) ; int8: fused fp32 epilogue ; fp16: half epilogue
-void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
-                       int k, bool int8, hipStream_t s);
+// `workspace` (gemm_tiled_workspace_bytes(), zeroed once; NULL = none): lets m <= 256 cut the K extent of its few tiles into
+// slices reduced inside the launch.  One workspace serves one stream.
+size_t gemm_tiled_workspace_bytes();
+size_t gemm_tiled_ticket_bytes();  // the workspace's tail
+void   launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
+                         int k, bool int8, hipStream_t s, float* workspace = nullptr);
 // batched decode GEMM for m <= 16 rows (HBM bound forms); with a `workspace` (>= gemm_smallm_workspace_bytes of this
 // GEMM) the burst form runs: K slices of 20 tiles, every wave requests its whole slice at once
 // at once; `workspace` = [partial_bytes of split-K partial sums][gemm_smallm_ticket_bytes(), zeroed once before the first

@@ -16,6 +16,10 @@
 namespace ftcf {
 
 constexpr int GEMM_KSTEP = 64;
+// split-K form of the tiled GEMM (short prompt phases): partial tiles [tile][slice] of 64 x 256 fp32 + one ticket per tile
+constexpr size_t GEMM_SPLITK_WS    = (size_t)48 << 20;
+constexpr size_t GEMM_SPLITK_TILES = 4096;
+constexpr int    GEMM_SPLITK_MAX_M = 256;
 
 // one 16-byte weight fragment against the 16 rows of x in LDS (xr: this lane's row lane&15, k group lane>>4)
 template<bool INT8>
@@ -51,11 +55,22 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 // MFMA peak at m = 1024); NG = 2 halves that.  Block tile: (RG*16) x (WAVES * NG * 16); the waves of a workgroup share the A
 // tile in LDS, so WAVES = 8 halves the number of workgroups re-reading A from L2 (prefill is L2-traffic bound: at m = 1024
 // a 128 x 128 tile moves 1.2 GB of A and 0.6 GB of weights through the L2 for the QKV GEMM).
-template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false>
-__global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
+//
+// SPLITK (short prompt phases, 17..256 rows: HBM bound work on too few tiles to fill 256 CUs -- n = 5120 at 64 < m <= 128 is
+// 40 workgroups): the K extent of a block tile is cut into KS slices, one workgroup each (all on the tile's XCD).  Every
+// workgroup stores its fp32 accumulators in MFMA fragment order (16 B per lane, one coalesced wave store per fragment) and takes
+// a ticket; the one that takes the tile's last ticket adds the KS partial tiles IN SLICE ORDER (deterministic) and applies the
+// epilogue.  Agent-scope fences on both sides of the ticket (release: L2 write-back, acquire: L2 invalidate -- the XCDs' L2s are
+// not coherent with each other) make the partials visible wherever the last workgroup runs; it re-arms the ticket.
+template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false, bool SPLITK = false, int D = 0>
+#ifndef GEMM_DEEP_WGS
+#define GEMM_DEEP_WGS 1
+#endif
+__global__ __launch_bounds__(64 * WAVES, D > 0 && INT8 ? GEMM_DEEP_WGS * WAVES / 4 : 1) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
                                                     int act, f16* __restrict__ C, int m, int n, int k, int gx = 0,
-                                                    int gy = 0)
+                                                    int gy = 0, int KS = 1, int ks_per = 0, f32x4* __restrict__ ws = nullptr,
+                                                    unsigned* __restrict__ tickets = nullptr)
 {
     constexpr int BM   = RG * 16;
     constexpr int NTHR = 64 * WAVES;
@@ -63,13 +78,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y, kz = 0;
     if constexpr (XCD) {
         // 1-D grid; workgroup b runs on XCD b % 8.  The gy row blocks of one weight panel go to ONE XCD, in consecutive
         // slots (they run together and share the panel through that XCD's L2 instead of fetching it 8 times over the fabric)
         const int b = blockIdx.x, c = b & 7, sl = b >> 3;
-        bx          = (sl / gy) * 8 + c;
-        by          = sl % gy;
+        if constexpr (SPLITK) {
+            const int rem = sl % (gy * KS);
+            bx            = (sl / (gy * KS)) * 8 + c;
+            by            = rem % gy;
+            kz            = rem / gy;
+        }
+        else {
+            bx = (sl / gy) * 8 + c;
+            by = sl % gy;
+        }
         if (bx >= gx) {
             return;
         }
@@ -77,7 +100,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
     const int m0 = by * BM;
     const int nt0 = (bx * WAVES + wid) * NG;  // first column group of this wave
     const int NT = n / 16;
-    const int  ksteps = k / GEMM_KSTEP;
+    const int  ks0    = SPLITK ? kz * ks_per : 0;  // first k-step of this workgroup's slice
+    const int  ksteps = SPLITK ? min(ks_per, k / GEMM_KSTEP - ks0) : k / GEMM_KSTEP;
 
     // B stream pointers (column groups past the end re-read the last one; their results are dropped)
     const int    KT = INT8 ? k / TILE_K_I8 : k / TILE_K_F16;
@@ -98,28 +122,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
     constexpr int CHUNKS = BM * GEMM_KSTEP / 8;             // 16-byte chunks per stage
     constexpr int CPT    = (CHUNKS + NTHR - 1) / NTHR;            // chunks per thread
     u32x4         areg[CPT];
-    auto load_a = [&](int ks) {
+    auto load_a_into = [&](u32x4 (&areg)[CPT], int ks) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int ch = threadIdx.x + i * NTHR;
-            if (ch < CHUNKS) {
+            if (CHUNKS % NTHR == 0 || ch < CHUNKS) {  // (a branch here costs hipcc its count of the loads in flight)
                 int row = m0 + ch / 8;
                 row     = row < m ? row : m - 1;
-                areg[i] = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)ks * GEMM_KSTEP + (ch % 8) * 8);
+                areg[i] = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)(ks0 + ks) * GEMM_KSTEP + (ch % 8) * 8);
             }
         }
     };
-    auto store_a = [&](int buf) {
+    auto load_a = [&](int ks) { load_a_into(areg, ks); };
+    auto store_a_from = [&](const u32x4 (&areg)[CPT], int buf) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int ch = threadIdx.x + i * NTHR;
-            if (ch < CHUNKS) {
+            if (CHUNKS % NTHR == 0 || ch < CHUNKS) {  // (a branch here costs hipcc its count of the loads in flight)
                 const int kc = ch % 8;                                             // k chunk of this piece
                 const int pc = INT8 ? (((kc & 1) << 2) | (kc >> 1)) : kc;          // its position in the row
                 *reinterpret_cast<u32x4*>(&As[buf][(ch / 8) * GEMM_LDA + pc * 8]) = areg[i];
             }
         }
     };
+    auto store_a = [&](int buf) { store_a_from(areg, buf); };
 
     f32x4 acc[RG][NG];
 #pragma unroll
@@ -136,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
     typedef u32x4 BTile[NG][2];  // int8: [0] only ; fp16: two 32-k tiles per 64-k step
     BTile         B0, B1;
     auto load_b = [&](BTile& br, int ks) {
-        ks = ks < ksteps ? ks : ksteps - 1;
+        ks = ks0 + (ks < ksteps ? ks : ksteps - 1);
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if constexpr (INT8) {
@@ -148,9 +174,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
             }
         }
     };
-    // at entry As[ks & 1] holds stage ks (its barrier has been passed) and areg stage ks + 1
-    auto step = [&](const BTile& br, int ks) {
-        f16x8 bf[NG][2];
+    auto dequant_b = [&](const BTile& br, f16x8 (&bf)[NG][2]) {
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if constexpr (INT8) {
@@ -167,38 +191,197 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
                 bf[j][1] = __builtin_bit_cast(f16x8, br[j][1]);
             }
         }
+    };
+    auto compute = [&](const BTile& br, int ks) {
         // A fragment k offsets must follow the B fragment's k order (see file header)
         const int  koff0 = g * 8;
         const int  koff1 = 32 + g * 8;
         const f16* as    = As[ks & 1];
+#ifndef GEMM_PREFETCH_A
+#define GEMM_PREFETCH_A 1
+#endif
+        if constexpr (GEMM_PREFETCH_A == 2 || (GEMM_PREFETCH_A == 1 && D > 0)) {
+            // all A fragments of the step requested up front (their LDS latency passes under the dequantisation), then the MFMAs
+            // back to back with the two k halves of an accumulator RG * NG instructions apart (a dependent MFMA stalls its wave)
+#ifndef GEMM_PF_ROWS
+#define GEMM_PF_ROWS 2
+#endif
+            constexpr int PR = RG < GEMM_PF_ROWS ? RG : GEMM_PF_ROWS;  // row groups whose fragments are in flight together
+            f16x8         af[PR][2];
 #pragma unroll
-        for (int r = 0; r < RG; r++) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff0]);
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff1]);
+            for (int r = 0; r < PR; r++) {
+                af[r][0] = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff0]);
+                af[r][1] = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff1]);
+            }
+            f16x8 bf[NG][2];
+            dequant_b(br, bf);
 #pragma unroll
-            for (int j = 0; j < NG; j++) {
-                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[j][0], acc[r][j], 0, 0, 0);
-                acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j][1], acc[r][j], 0, 0, 0);
+            for (int r0 = 0; r0 < RG; r0 += PR) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+#pragma unroll
+                    for (int r = 0; r < PR; r++) {
+#pragma unroll
+                        for (int j = 0; j < NG; j++) {
+                            acc[r0 + r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[r][h], bf[j][h], acc[r0 + r][j], 0, 0, 0);
+                        }
+                    }
+                }
+                if (r0 + PR < RG) {
+#pragma unroll
+                    for (int r = 0; r < PR; r++) {
+                        af[r][0] = *reinterpret_cast<const f16x8*>(&as[((r0 + PR + r) * 16 + c) * GEMM_LDA + koff0]);
+                        af[r][1] = *reinterpret_cast<const f16x8*>(&as[((r0 + PR + r) * 16 + c) * GEMM_LDA + koff1]);
+                    }
+                }
             }
         }
-        store_a((ks + 1) & 1);  // the other buffer: its readers (stage ks - 1) finished before the previous barrier
-        load_a(ks + 2 < ksteps ? ks + 2 : ksteps - 1);
-        __syncthreads();
-    };
-
-    load_a(0);
-    load_b(B0, 0);
-    load_b(B1, 1);
-    store_a(0);
-    load_a(1 < ksteps ? 1 : 0);
-    __syncthreads();
-    for (int ks = 0; ks < ksteps; ks += 2) {
-        step(B0, ks);
-        load_b(B0, ks + 2);
-        if (ks + 1 < ksteps) {
-            step(B1, ks + 1);
+        else {
+            f16x8 bf[NG][2];
+            dequant_b(br, bf);
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff0]);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(&as[(r * 16 + c) * GEMM_LDA + koff1]);
+#pragma unroll
+                for (int j = 0; j < NG; j++) {
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[j][0], acc[r][j], 0, 0, 0);
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[j][1], acc[r][j], 0, 0, 0);
+                }
+            }
         }
-        load_b(B1, ks + 3);
+    };
+    if constexpr (D > 0) {
+        // deep form (short prompt phases: one or two workgroups per CU, each k-step a dependent round trip otherwise): weight
+        // tiles AND the A tile's register stage D k-steps ahead; stage s lives in ring slot s % D (static: the loop is unrolled D
+        // times), the LDS double buffer as in the plain form
+        static_assert(D % 2 == 0, "the LDS buffer of a stage is its ring slot's parity");
+        BTile Bq[D];
+        u32x4 aq[D][CPT];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            load_a_into(aq[d], d < ksteps ? d : ksteps - 1);
+            load_b(Bq[d], d);
+        }
+        store_a_from(aq[0], 0);
+        load_a_into(aq[0], D < ksteps ? D : ksteps - 1);
+        __syncthreads();
+        for (int ks = 0; ks < ksteps; ks += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {  // ksteps % D == 0 (the launcher sees to it): no step is conditional -- a branch
+                                           // around a step makes hipcc wait for ALL outstanding loads at the loop head
+                compute(Bq[d], d);
+                store_a_from(aq[(d + 1) % D], (d + 1) & 1);  // stage ks + d + 1
+                load_a_into(aq[(d + 1) % D], ks + d + 1 + D < ksteps ? ks + d + 1 + D : ksteps - 1);
+                __syncthreads();
+                load_b(Bq[d], ks + d + D);
+                // (hipcc's scheduler otherwise sinks the requests towards their uses, D steps later: the ring drains)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    else {
+        // at entry As[ks & 1] holds stage ks (its barrier has been passed) and areg stage ks + 1
+        auto step = [&](const BTile& br, int ks) {
+            compute(br, ks);
+            store_a((ks + 1) & 1);  // the other buffer: its readers (stage ks - 1) finished before the previous barrier
+            load_a(ks + 2 < ksteps ? ks + 2 : ksteps - 1);
+            __syncthreads();
+        };
+        load_a(0);
+        load_b(B0, 0);
+        load_b(B1, 1);
+        store_a(0);
+        load_a(1 < ksteps ? 1 : 0);
+        __syncthreads();
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            step(B0, ks);
+            load_b(B0, ks + 2);
+            if (ks + 1 < ksteps) {
+                step(B1, ks + 1);
+            }
+            load_b(B1, ks + 3);
+        }
+    }
+    if constexpr (SPLITK) {
+        if (KS > 1) {
+            constexpr int FR   = RG * NG * 64;  // f32x4 per wave
+            const int     tile = bx * gy + by;
+            // partial tiles travel as write-through (sc1) 8-byte stores and are read back with sc1 loads: no whole-L2 write-back /
+            // invalidate per workgroup (an agent-scope fence costs that: 30 ms for the 13B prompt phase at 128 tokens against 16)
+            typedef unsigned long long u64;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            u64* P = reinterpret_cast<u64*>(ws + ((size_t)(tile * KS + kz) * WAVES + wid) * FR) + lane;
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+#pragma unroll
+                for (int j = 0; j < NG; j++) {
+                    const f32x4 a = acc[r][j];
+                    __hip_atomic_store(P + ((r * NG + j) * 2 + 0) * 64, __builtin_bit_cast(u64, f32x2{a[0], a[1]}), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(P + ((r * NG + j) * 2 + 1) * 64, __builtin_bit_cast(u64, f32x2{a[2], a[3]}), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __shared__ int last;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have been acknowledged
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last             = t == (unsigned)(KS - 1);
+                if (last) {
+                    __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+                }
+            }
+            __syncthreads();
+            if (!last) {
+                return;
+            }
+            // slice by slice, all of a slice's fragments requested together (one round trip per slice, not per fragment)
+            const u64* Q = reinterpret_cast<const u64*>(ws + ((size_t)(tile * KS) * WAVES + wid) * FR) + lane;
+#pragma unroll
+            for (int r = 0; r < RG; r++) {
+#pragma unroll
+                for (int j = 0; j < NG; j++) {
+                    acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#ifndef GEMM_ZB
+#define GEMM_ZB 1
+#endif
+            constexpr int ZB = RG <= 4 ? GEMM_ZB : 2;  // slices requested together (32 / 64 VGPRs each)
+            for (int z0 = 0; z0 < KS; z0 += ZB) {
+                u64 v[ZB][RG][NG][2];
+#pragma unroll
+                for (int i = 0; i < ZB; i++) {
+                    if (z0 + i < KS) {
+#pragma unroll
+                        for (int r = 0; r < RG; r++) {
+#pragma unroll
+                            for (int j = 0; j < NG; j++) {
+                                const u64* q  = Q + (size_t)(z0 + i) * WAVES * FR * 2 + (r * NG + j) * 2 * 64;
+                                v[i][r][j][0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                v[i][r][j][1] = __hip_atomic_load(q + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < ZB; i++) {
+                    if (z0 + i < KS) {
+#pragma unroll
+                        for (int r = 0; r < RG; r++) {
+#pragma unroll
+                            for (int j = 0; j < NG; j++) {
+                                const f32x2 lo = __builtin_bit_cast(f32x2, v[i][r][j][0]);
+                                const f32x2 hi = __builtin_bit_cast(f32x2, v[i][r][j][1]);
+                                acc[r][j] += f32x4{lo[0], lo[1], hi[0], hi[1]};
+                            }
+                        }
+                    }
+                }
+            }
+        }
     }
     // C/D layout of mfma 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -239,8 +422,17 @@ __global__ __launch_bounds__(64 * WAVES) void k_gemm_tiled(const f16* __restrict
     }
 }
 
+size_t gemm_tiled_ticket_bytes()
+{
+    return GEMM_SPLITK_TILES * sizeof(unsigned);
+}
+size_t gemm_tiled_workspace_bytes()
+{
+    return GEMM_SPLITK_WS + GEMM_SPLITK_TILES * sizeof(unsigned);
+}
+
 void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
-                       int k, bool int8, hipStream_t s)
+                       int k, bool int8, hipStream_t s, float* workspace)
 {
     if (m == 0) {
         return;
@@ -248,6 +440,45 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0, "GEMM needs k % 64 == 0 (as the reference: fpA_intB_gemm_template.h:159-163)");
     FTCF_CHECK_ARG(n % 16 == 0, "GEMM needs n % 16 == 0");
     const int NT = n / 16;
+    static const int splitk_target = getenv("FTCF_GEMM_SPLITK") ? atoi(getenv("FTCF_GEMM_SPLITK")) : 256;
+    static const int splitk_max_m = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : GEMM_SPLITK_MAX_M;
+    if (workspace && m <= splitk_max_m && splitk_target > 0) {
+        // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)
+        static const int deep = getenv("FTCF_GEMM_DEEP") ? atoi(getenv("FTCF_GEMM_DEEP")) : 4;
+        constexpr int NG = 2, BM = 64, DQ = 4;
+        const int gx = (NT + 8 * NG - 1) / (8 * NG), gy = (m + BM - 1) / BM, gx8 = 8 * ((gx + 7) / 8);
+        const int ksteps = k / GEMM_KSTEP;
+        int       KS     = std::max(1, std::min({8, splitk_target / (gx8 * gy), ksteps / 8}));
+        KS               = std::max<long>(1, std::min<long>(KS, (long)(GEMM_SPLITK_WS / (size_t)(BM * 256 * 4)) / ((long)gx * gy)));
+        if (gx * gy <= (int)GEMM_SPLITK_TILES) {
+            // the deep form runs whole rounds of its ring: slices of a multiple of DQ k-steps (else the plain form)
+            const bool dd  = deep > 0 && ksteps % DQ == 0;
+            const int  rnd = dd ? DQ : 1;
+            const int  per = ((ksteps + KS - 1) / KS + rnd - 1) / rnd * rnd;
+            KS             = (ksteps + per - 1) / per;  // no empty slice
+            f32x4*    ws   = reinterpret_cast<f32x4*>(workspace);
+            unsigned* tk   = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + GEMM_SPLITK_WS);
+            dim3      grid(gx8 * gy * KS);
+#define FTCF_SK(I8, Dv)                                                                                                          \
+    hipLaunchKernelGGL((k_gemm_tiled<I8, 4, NG, 8, false, true, true, Dv>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, \
+                       gx, gy, KS, per, ws, tk)
+            if (int8 && dd) {
+                FTCF_SK(true, DQ);
+            }
+            else if (int8) {
+                FTCF_SK(true, 0);
+            }
+            else if (dd) {
+                FTCF_SK(false, DQ);
+            }
+            else {
+                FTCF_SK(false, 0);
+            }
+#undef FTCF_SK
+            FTCF_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if (m <= 32) {
         dim3 grid((NT + 3) / 4, (m + 31) / 32);
         if (int8) {

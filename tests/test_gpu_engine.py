@@ -96,14 +96,28 @@ MID = dict(head_num=8, size_per_head=128, inter_size=4096, num_layer=2, vocab_si
 @pytest.mark.parametrize("B", [1, 2, 3, 6])
 def test_mid_model_fused_and_general_decode_paths(gh, B, int8_mode):
     """H=1024/Dh=128: with the defaults B<=2 runs the persistent layer kernel and B=3, 6 the general path (burst GEMMs);
-    in the `launches` variant B<=3 runs the per-stage GEMV launches.  All must follow the oracle."""
+    in the `launches` variant B<=3 runs the per-stage GEMV launches.  All must follow the oracle.  (The prompt phases of
+    B = 3, 6 are 111 / 222 rows: the split-K form of the tiled GEMM.)"""
+    _mid_model_follows_the_oracle(gh, B, int8_mode)
+
+
+@pytest.mark.parametrize("int8_mode", [0, 1])
+@pytest.mark.parametrize("max_rows", [16, 64])
+def test_mid_model_decode_steps_above_16_rows(gh, monkeypatch, max_rows, int8_mode):
+    """20 rows per decode step: the split-K tiled GEMM (default) or, with FTCF_SMALLM_MAX_ROWS=64, the burst GEMM in
+    chunks of 16 rows on the two branch streams."""
+    monkeypatch.setenv("FTCF_SMALLM_MAX_ROWS", str(max_rows))
+    _mid_model_follows_the_oracle(gh, 20, int8_mode, out=6)
+
+
+def _mid_model_follows_the_oracle(gh, B, int8_mode, out=12):
     cfg = MID
     w = random_model(cfg, seed=B + 10 * int8_mode, std=0.04)
     layers, glob = weight_list_to_layers(cfg, w)
     if int8_mode:
         layers = quantize_layers(layers)
     rng = np.random.RandomState(B)
-    S, out = 37, 12
+    S = 37
     lens = rng.randint(20, S + 1, size=B).astype(np.int32)
     lens[0] = S
     ids = np.full((B, S), cfg["end_id"], dtype=np.int32)

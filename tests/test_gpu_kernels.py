@@ -79,6 +79,29 @@ def test_fpA_intB_gemm_matches_reference_formula(n, k):
         torch.testing.assert_close(out.cpu().float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3, msg=lambda t: f"m={m}: {t}")
 
 
+@pytest.mark.parametrize("k", [1088, 2304])
+def test_fpA_intB_gemm_split_k_forms(k):
+    """17..256 rows cut the K extent of their tiles into slices: k = 1088 (17 k-steps: not a whole number of rounds of the
+    four-deep ring -> the plain loop) and 2304 (36 k-steps: the deep loop, ragged last slice); repeated launches re-arm the
+    tickets; rtol / atol as the reference's grid test (th_gemm_dequantize.py:65-115)."""
+    n = 1280
+    qd, sd, q_rm, s_o = _grid_weights(n, k)
+    for m in (17, 64, 65, 200, 256):
+        g = torch.Generator().manual_seed(m * 7 + k)
+        act = torch.randn(m, k, generator=g).half()
+        bias = torch.randn(n, generator=g).half()
+        ref = orc.gemm(act.float().numpy(), q=q_rm, scale=s_o, bias=bias.float().numpy(), act=1, fp16=True)
+        A, bd = act.cuda(), bias.cuda()
+        outs = []
+        for _ in range(3):
+            out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+            capi.check(capi.lib().ftcf_fpA_intB_gemm(capi.vp(A), capi.vp(qd), capi.vp(sd), capi.vp(bd), 1, capi.vp(out), m, n, k, sp()))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])  # slices are added in slice order
+        torch.testing.assert_close(outs[0].float(), torch.from_numpy(ref), rtol=1e-3, atol=2e-3, msg=lambda t: f"m={m}: {t}")
+
+
 @pytest.mark.parametrize("m", [4, 128])
 def test_identity_activation_dequant_is_bit_exact(m):
     # th_gemm_dequantize.py:22-40
