@@ -62,11 +62,11 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 // a ticket; the one that takes the tile's last ticket adds the KS partial tiles IN SLICE ORDER (deterministic) and applies the
 // epilogue.  Agent-scope fences on both sides of the ticket (release: L2 write-back, acquire: L2 invalidate -- the XCDs' L2s are
 // not coherent with each other) make the partials visible wherever the last workgroup runs; it re-arms the ticket.
-template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false, bool SPLITK = false, int D = 0>
-#ifndef GEMM_DEEP_WGS
-#define GEMM_DEEP_WGS 1
-#endif
-__global__ __launch_bounds__(64 * WAVES, D > 0 && INT8 ? GEMM_DEEP_WGS * WAVES / 4 : 1) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
+// PF: all (of two row groups') A fragments of a k-step are read from LDS before the dequantisation; OCC2: register budget of two
+// workgroups per CU (128 VGPRs at 8 waves)
+template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false, bool SPLITK = false, int D = 0, bool PF = false,
+         bool OCC2 = false>
+__global__ __launch_bounds__(64 * WAVES, OCC2 ? WAVES / 2 : 1) void k_gemm_tiled(const f16* __restrict__ A, const void* __restrict__ W,
                                                     const f16* __restrict__ scale, const f16* __restrict__ bias,
                                                     int act, f16* __restrict__ C, int m, int n, int k, int gx = 0,
                                                     int gy = 0, int KS = 1, int ks_per = 0, f32x4* __restrict__ ws = nullptr,
@@ -197,10 +197,7 @@ __global__ __launch_bounds__(64 * WAVES, D > 0 && INT8 ? GEMM_DEEP_WGS * WAVES /
         const int  koff0 = g * 8;
         const int  koff1 = 32 + g * 8;
         const f16* as    = As[ks & 1];
-#ifndef GEMM_PREFETCH_A
-#define GEMM_PREFETCH_A 1
-#endif
-        if constexpr (GEMM_PREFETCH_A == 2 || (GEMM_PREFETCH_A == 1 && D > 0)) {
+        if constexpr (PF) {
             // all A fragments of the step requested up front (their LDS latency passes under the dequantisation), then the MFMAs
             // back to back with the two k halves of an accumulator RG * NG instructions apart (a dependent MFMA stalls its wave)
 #ifndef GEMM_PF_ROWS
@@ -460,7 +457,7 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
             unsigned* tk   = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + GEMM_SPLITK_WS);
             dim3      grid(gx8 * gy * KS);
 #define FTCF_SK(I8, Dv)                                                                                                          \
-    hipLaunchKernelGGL((k_gemm_tiled<I8, 4, NG, 8, false, true, true, Dv>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, \
+    hipLaunchKernelGGL((k_gemm_tiled<I8, 4, NG, 8, false, true, true, Dv, (Dv > 0)>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, \
                        gx, gy, KS, per, ws, tk)
             if (int8 && dd) {
                 FTCF_SK(true, DQ);
@@ -502,20 +499,41 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         const bool    small = (long)gx * ((m + 127) / 128) < 160;
         const int     gy = small ? (m + 63) / 64 : (m + 127) / 128;
         dim3          grid(8 * ((gx + 7) / 8) * gy);
-        if (small) {
-            if (int8) {
-                hipLaunchKernelGGL((k_gemm_tiled<true, 4, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
-            }
-            else {
-                hipLaunchKernelGGL((k_gemm_tiled<false, 4, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
-            }
+        // The ring form, two k-steps deep (it needs an even number of k-steps; else the plain loop).  At most one workgroup per CU
+        // (n = 5120 at m <= 1024: 160 tiles): with the A fragments prefetched, 163 VGPRs.  More tiles than that: without the
+        // prefetch and held to 128 VGPRs, so that two workgroups share a CU as in the plain form (124 VGPRs).  13B int8 layer,
+        // us, plain loop / ring at one workgroup per CU / ring at two: m = 1024: QKV 163 / 180 / 163, out-proj 91 / 80 / 93,
+        // FFN1 218 / 235 / 216, FFN2 293 / 270 / 295; m = 2048: 348 / 375 / 340, 138 / 147 / 135, 392 / 418 / 380, 506 / 532 / 487.
+        static const int big_deep = getenv("FTCF_GEMM_BIG_DEEP") ? atoi(getenv("FTCF_GEMM_BIG_DEEP")) : 2;
+        const int        bd       = (k / GEMM_KSTEP) % 2 == 0 ? big_deep : 0;
+        const bool       lone     = (long)gx * gy <= 256;
+#define FTCF_BIG(I8, RGv, Dv, PFv, O2v)                                                                                          \
+    hipLaunchKernelGGL((k_gemm_tiled<I8, RGv, NG, 8, false, true, false, Dv, PFv, O2v>), grid, dim3(512), 0, s, A, W, scale, bias, act, \
+                       C, m, n, k, gx, gy)
+#define FTCF_BIG_D(I8, RGv)                                                                                                      \
+    if (bd == 2 && lone) {                                                                                                       \
+        FTCF_BIG(I8, RGv, 2, true, false);                                                                                       \
+    }                                                                                                                            \
+    else if (bd == 2) {                                                                                                          \
+        FTCF_BIG(I8, RGv, 2, !I8, I8);                                                                                           \
+    }                                                                                                                            \
+    else {                                                                                                                       \
+        FTCF_BIG(I8, RGv, 0, false, false);                                                                                      \
+    }
+        if (small && int8) {
+            FTCF_BIG_D(true, 4)
+        }
+        else if (small) {
+            FTCF_BIG_D(false, 4)
         }
         else if (int8) {
-            hipLaunchKernelGGL((k_gemm_tiled<true, 8, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
+            FTCF_BIG_D(true, 8)
         }
         else {
-            hipLaunchKernelGGL((k_gemm_tiled<false, 8, NG, 8, false, true>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, gx, gy);
+            FTCF_BIG_D(false, 8)
         }
+#undef FTCF_BIG_D
+#undef FTCF_BIG
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }
