@@ -458,10 +458,12 @@ __device__ __forceinline__ bool mmha_partial(const MmhaParams& p, char* smem, u6
     return true;
 }
 
-// One launch: every split workgroup publishes its partial as granules; the split-0 workgroup of each (row, head) then
+// One launch: every split workgroup publishes its partial as granules; the LAST split's workgroup of each (row, head) then
 // polls the nsplit partials (all loads of one pass in flight together), merges them in split order (deterministic)
-// and writes ctx.  Only split 0 ever waits, producers never do: no deadlock under any dispatch order as long as the
-// producers get scheduled, and every spin is bounded.
+// and writes ctx.  Only the merger ever waits, producers never do, and every launcher dispatches a (row, head)'s last split
+// after its other splits: a merger never holds a slot that a producer it waits for still needs (with split 0 as the merger and
+// more workgroups than slots -- 16 rows x 40 heads x 2 splits -- the first wave of workgroups spun until their limit:
+// 10..80 ms per step).  Every spin is bounded.
 template<int DH, bool BEAMS = false>
 __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int& s_last, const int h, const int b, const int sp)
 {
@@ -470,10 +472,10 @@ __device__ __forceinline__ void mmha_block(const MmhaParams& p, char* smem, int&
     const unsigned tag  = (unsigned)(step * 1024 + p.layer) + 1u;  // salt < 1024: layer + row group * num_layer
     u64*           gall = p.gran + ((size_t)b * p.nh + h) * p.nsplit * (DH + 2);
     const bool     live = mmha_partial<DH, BEAMS>(p, smem, gall + (size_t)sp * (DH + 2), tag, h, b, sp);
-    if (!live || sp != 0) {
+    if (!live || sp != p.nsplit - 1) {
         return;
     }
-    // ---- merger (split 0) ----
+    // ---- merger (the last split) ----
     __syncthreads();
     float* sval = reinterpret_cast<float*>(smem);  // [nsplit][DH+2], then [nsplit] weights + [1] denominator
     const int ne = DH + 2;

@@ -42,7 +42,8 @@ size_t mmha_smem_bytes(int dh, int s_max, int nsplit)
 
 int mmha_pick_nsplit(int B, int nh, int s_max)
 {
-    int want = (640 + B * nh - 1) / (B * nh);  // aim for >= ~640 workgroups
+    static const int wgs = getenv("FTCF_MMHA_WGS") ? atoi(getenv("FTCF_MMHA_WGS")) : 640;
+    int want = (wgs + B * nh - 1) / (B * nh);  // aim for >= ~640 workgroups
     int maxs = (s_max + 63) / 64;              // at least 64 keys per split
     int n    = std::max(1, std::min(std::min(want, maxs), 16));  // <= MMHA_MAX_SPLIT: one polling pass per merge
     return n;

@@ -4,13 +4,14 @@ import torch
 from fastertransformer4codefuse_amd import capi
 L = capi.lib()
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-B, nh, dh, rot, s_max, tl = 1, 40, 128, 32, 1536, 1100
+B, nh, dh, rot = int(os.environ.get('B', 1)), 40, 128, 32
+s_max, tl = int(os.environ.get('SMAX', 1536)), int(os.environ.get('TL', 1100))
 hl = nh * dh
 nlayers = 8   # rotate over several caches so that the 256 MB infinity cache cannot hold them
 Ks = [torch.randn(B, nh, s_max, dh, device='cuda').half() for _ in range(nlayers)]
 Vs = [torch.randn(B, nh, s_max, dh, device='cuda').half() for _ in range(nlayers)]
 qkv = torch.randn(B, 3 * hl, device='cuda').half(); bias = torch.randn(3 * hl, device='cuda').half()
-seq = torch.tensor([tl], dtype=torch.int32, device='cuda'); pad = torch.zeros(B, dtype=torch.int32, device='cuda')
+seq = torch.full((B,), tl, dtype=torch.int32, device='cuda'); pad = torch.zeros(B, dtype=torch.int32, device='cuda')
 msk = torch.zeros(B, s_max, dtype=torch.uint8, device='cuda'); fin = torch.zeros(B, dtype=torch.uint8, device='cuda')
 ctx = torch.zeros(B, hl, device='cuda', dtype=torch.float16)
 wsb = L.ftcf_masked_multihead_attention_workspace(B, nh, dh, s_max) * 4
@@ -24,4 +25,4 @@ n = 200
 e0.record()
 for i in range(n): call(i)
 e1.record(); torch.cuda.synchronize()
-print(f"dbg={os.environ.get('FTCF_MMHA_DBG','0')} nsplit={os.environ.get('FTCF_MMHA_NSPLIT','auto')}: {e0.elapsed_time(e1)*1e3/n:.2f} us per call (incl. memset of the slab)")
+print(f"B={B} s_max={s_max} tl={tl} wgs={os.environ.get('FTCF_MMHA_WGS','640')}: {e0.elapsed_time(e1)*1e3/n:.2f} us per call (incl. memset of the slab)")
