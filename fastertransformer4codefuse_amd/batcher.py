@@ -23,10 +23,11 @@ class ContinuousBatcher:
         self._h = C.c_void_p()
         capi.check(capi.lib().ftcf_batcher_create(op._h, int(max_batch), int(page_tokens), int(num_pages), int(max_seq_len),
                                                   C.byref(self._h)))
-        n = 2 * self.max_batch
+        n = 2 * self.max_batch  # (a chunked admission can produce more events per iteration: the rest comes with the next call)
         self._ids = (C.c_long * n)()
         self._tok = (C.c_int * n)()
         self._fin = (C.c_int * n)()
+        self._cb = None
 
     def __del__(self):
         try:
@@ -56,6 +57,16 @@ class ContinuousBatcher:
             C.c_float(temperature), C.c_float(repetition_penalty), C.c_ulonglong(int(seed)),
             sw.ctypes.data_as(C.POINTER(C.c_int)) if sw is not None else None, int(sw_len), C.byref(rid)))
         return int(rid.value)
+
+    def set_token_callback(self, fn):
+        """fn(request_id, token, finished) is called from inside step() for every token the moment it is on the host (between
+        the chunks of a long admission as well); None unsets.  The events are still returned by step()."""
+        if fn is None:
+            self._cb = None
+            capi.check(capi.lib().ftcf_batcher_set_token_callback(self._h, C.cast(None, capi.TOKEN_CALLBACK), None))
+            return
+        self._cb = capi.TOKEN_CALLBACK(lambda _user, rid, tok, fin: fn(int(rid), int(tok), bool(fin)))
+        capi.check(capi.lib().ftcf_batcher_set_token_callback(self._h, self._cb, None))
 
     def step(self):
         """One scheduler iteration; returns [(request_id, token, finished), ...] in production order."""

@@ -19,6 +19,7 @@ class FtcfError(RuntimeError):
 TOKEN_CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p)
 # ftcf_host_allgather_fn (include/ftcf.h): int (*)(void* user, const void* send, void* recv, size_t bytes_per_rank)
 HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+TOKEN_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int, C.c_int)
 
 
 class GptNeoXConfig(C.Structure):
@@ -72,7 +73,7 @@ EXPORTED = [
     "ftcf_comm_allgather", "ftcf_gptneox_create", "ftcf_gptneox_forward", "ftcf_gptneox_begin", "ftcf_gptneox_step", "ftcf_gptneox_finish",
     "ftcf_gptneox_get_stats",
     "ftcf_gptneox_set_profiling", "ftcf_gptneox_destroy",
-    "ftcf_batcher_create", "ftcf_batcher_submit", "ftcf_batcher_submit_ex", "ftcf_batcher_step", "ftcf_batcher_status", "ftcf_batcher_cancel", "ftcf_batcher_destroy"]
+    "ftcf_batcher_create", "ftcf_batcher_submit", "ftcf_batcher_submit_ex", "ftcf_batcher_step", "ftcf_batcher_set_token_callback", "ftcf_batcher_status", "ftcf_batcher_cancel", "ftcf_batcher_destroy"]
 
 _lib = None
 

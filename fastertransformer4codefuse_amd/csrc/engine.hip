@@ -1218,7 +1218,7 @@ struct ftcf_gptneox {
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
             smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
-            const bool tiled_rows = (prefill_m > 16 && prefill_m <= 256) || (B > 16 && B <= 256);
+            const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= 256);  // (a chunked prompt phase runs <= 256 rows at a time)
             tiled_ws              = (!fp32 && tiled_rows) ? c.take<float>(gemm_tiled_workspace_bytes() / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
@@ -1433,6 +1433,42 @@ struct ftcf_gptneox {
     // engine stream; each micro-batch's all-reduce goes to the side stream behind an event, and the NEXT layer's work on that
     // micro-batch waits for it: the reduction of one half runs under the GEMMs of the other.  Same arithmetic per row as
     // context_decoder (the all-reduce sums the same values): results are bit-identical to the un-overlapped path.
+    // Chunked prompt phase of ONE sequence (the continuous-batching front end, section 4e of DESIGN.md): the prompt's tokens pass
+    // through all layers `prefill_chunk` at a time -- every GEMM / LayerNorm / residual is row wise, a chunk's attention reads
+    // the earlier chunks' K/V from the cache -- and `prefill_hook` runs between two chunks (the batcher enqueues one decode step
+    // of its running slots there: an admission delays them by one chunk, not by the whole prompt).  The row-wise arithmetic is
+    // that of context_decoder; the split-K form of the GEMMs depends on the row count, so results agree to fp16 rounding of
+    // the GEMM outputs, not bit for bit.
+    int                   prefill_chunk = 0;
+    std::function<void()> prefill_hook;
+    bool context_decoder_chunked(int S, const int* input_lengths, int s_max)
+    {
+        if (!prefill_hook || prefill_chunk <= 0 || S <= prefill_chunk || fp32 || cfg.tensor_para_size != 1 || !cfg.use_gptj_residual
+            || !residual_dual_ln_supported(H)) {
+            return false;
+        }
+        Range r("ftcf.GptNeoXContextDecoder.chunked");
+        bind_layers();
+        const size_t cache_l = (size_t)nhl * s_max * dh;
+        for (int s0 = 0; s0 < S; s0 += prefill_chunk) {
+            const int s1 = std::min(S, s0 + prefill_chunk), m = s1 - s0;
+            f16*      X  = px + (size_t)s0 * H;
+            for (int l = 0; l < L; l++) {
+                const LayerWeights& w = layers[l];
+                launch_residual_dual_ln(X, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm + (size_t)s0 * H,
+                                        pnrm2 + (size_t)s0 * H, m, H, 1e-5f, stream);
+                context_attention_layer.forward(pnrm, pqkv, pctx, patt, w, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, 1,
+                                                S, s_max, 1, stream, s0, s1);
+                ffn_layer.forward(pnrm2 + (size_t)s0 * H, pmid + (size_t)s0 * il, pffn + (size_t)s0 * H, w, m, stream);
+                launch_add_bias_attn_ffn_residual(X, pffn + (size_t)s0 * H, patt + (size_t)s0 * H, X, w.ffn2.bias, m, H, 1, 1, true, stream);
+            }
+            if (s1 < S) {
+                prefill_hook();
+            }
+        }
+        return true;
+    }
+
     hipEvent_t ov_done[2] = {nullptr, nullptr}, ov_red[2] = {nullptr, nullptr};
     bool context_decoder_overlapped(int B, int S, const int* input_lengths, int s_max)
     {
@@ -1504,6 +1540,9 @@ struct ftcf_gptneox {
 
     void context_decoder(int B, int S, const int* input_lengths, int s_max, int tile)
     {
+        if (tile == 1 && B == 1 && context_decoder_chunked(S, input_lengths, s_max)) {
+            return;
+        }
         if (tile == 1 && context_decoder_overlapped(B, S, input_lengths, s_max)) {
             return;
         }
@@ -2853,6 +2892,9 @@ struct ftcf_batcher {
     void*        samp_ws = nullptr;
     float*       smallm_ws = nullptr;
     float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..256 rows)
+    // chunked admission: with slots running, a prompt longer than this is prefilled alone, `prefill_chunk` tokens at a time, one
+    // decode step of the running slots between two chunks (FTCF_BATCHER_PREFILL_CHUNK; 0 = whole prompts)
+    int prefill_chunk = 512;
     size_t       smallm_partial = 0;
     unsigned     smallm_seq = 0;
     long         gemm_steps = 0;
@@ -2889,6 +2931,9 @@ struct ftcf_batcher {
                        "the batcher serves fp16 / int8 engines with parallel residual, tensor_para_size 1 and size_per_head 64 / 128");
         FTCF_CHECK_ARG(mb >= 1 && mb <= 64 && page_tokens >= 8 && pages >= 1 && max_seq_len >= 2, "bad batcher geometry");
         FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
+        if (const char* c = getenv("FTCF_BATCHER_PREFILL_CHUNK")) {
+            prefill_chunk = std::max(0, atoi(c));
+        }
         max_batch = mb;
         P         = page_tokens;
         num_pages = pages;
@@ -2994,6 +3039,17 @@ struct ftcf_batcher {
         long id;
         int  token, finished;
     };
+    std::vector<Event>* hook_ev = nullptr;  // where the decode steps inside a chunked admission put their events
+    std::deque<Event>   outbox;             // events of an iteration that did not fit the caller's arrays
+    ftcf_token_callback_fn on_token = nullptr;  // called for every event the moment it exists (inside step())
+    void*                  on_token_user = nullptr;
+    void emit(std::vector<Event>& ev, const Event& x)
+    {
+        ev.push_back(x);
+        if (on_token) {
+            on_token(on_token_user, x.id, x.token, x.finished);
+        }
+    }
 
     // stop_criteria_kernels.cu:24-83: does the history END with one of the request's stop sequences?
     static bool hits_stop_word(const Slot& s)
@@ -3131,7 +3187,7 @@ struct ftcf_batcher {
             s.generated = 1;
             s.max_new = r.max_new;
             const int done = (first == e->cfg.end_id || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
-            ev.push_back(Event{r.id, first, done});
+            emit(ev, Event{r.id, first, done});
             if (done) {
                 const uint8_t one8 = 1;
                 FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
@@ -3299,7 +3355,7 @@ struct ftcf_batcher {
             s.generated += 1;
             s.hist.push_back(tok[si]);
             const int done = (fin[si] || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
-            ev.push_back(Event{s.id, tok[si], done});
+            emit(ev, Event{s.id, tok[si], done});
             if (done) {
                 if (!fin[si]) {
                     const uint8_t one8 = 1;
@@ -3350,6 +3406,61 @@ struct ftcf_batcher {
             sis.push_back(si);
             rs.push_back(std::move(waiting.front()));
             waiting.pop_front();
+        }
+        bool any_long = false;
+        for (const Request& r : rs) {
+            any_long |= prefill_chunk > 0 && (int)r.prompt.size() > prefill_chunk;
+        }
+        if (!sis.empty() && any && any_long) {
+            // slots are running and a long prompt arrives: one request at a time, its prompt phase in chunks with a decode step of
+            // the running slots after every chunk (events of those steps are final whatever happens to the admission)
+            while (!sis.empty()) {
+                const std::vector<int>     one_si{sis.front()};
+                const std::vector<Request> one_r{rs.front()};
+                std::vector<Event>         own, between;
+                bool                       running = false;
+                for (const Slot& s : slots) {
+                    running |= s.active;
+                }
+                try {
+                    if (running) {
+                        hook_ev          = &between;
+                        e->prefill_chunk = prefill_chunk;
+                        e->prefill_hook  = [this] {
+                            bool live = false;
+                            for (const Slot& s : slots) {
+                                live |= s.active;
+                            }
+                            if (live) {
+                                decode(*hook_ev);
+                            }
+                        };
+                    }
+                    admit(one_si, one_r, own);
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
+                }
+                catch (...) {
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
+                    (void)hipDeviceSynchronize();
+                    (void)hipGetLastError();
+                    ev.insert(ev.end(), between.begin(), between.end());
+                    for (const int si : sis) {  // this request and the ones not yet admitted go back to the queue's head
+                        release(slots[si]);
+                        const uint8_t one8 = 1;
+                        (void)hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice);
+                    }
+                    for (size_t i = rs.size(); i-- > 0;) {
+                        waiting.push_front(std::move(rs[i]));
+                    }
+                    throw;
+                }
+                ev.insert(ev.end(), between.begin(), between.end());
+                ev.insert(ev.end(), own.begin(), own.end());
+                sis.erase(sis.begin());
+                rs.erase(rs.begin());
+            }
         }
         if (!sis.empty()) {
             const size_t ev0 = ev.size();
@@ -3422,14 +3533,33 @@ extern "C" int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* token
     return guarded([&] {
         FTCF_CHECK_ARG(b && request_ids && tokens && finished && n_events, "NULL argument");
         FTCF_CHECK_ARG(capacity >= 2 * b->max_batch, "event arrays must hold 2 * max_batch entries");
-        std::vector<ftcf_batcher::Event> ev;
-        b->step(ev);
-        *n_events = (int)ev.size();
-        for (size_t i = 0; i < ev.size(); i++) {
-            request_ids[i] = ev[i].id;
-            tokens[i]      = ev[i].token;
-            finished[i]    = ev[i].finished;
+        if (b->outbox.empty()) {  // (else: the rest of the previous iteration's events first)
+            std::vector<ftcf_batcher::Event> ev;
+            try {
+                b->step(ev);
+            }
+            catch (...) {
+                b->outbox.insert(b->outbox.end(), ev.begin(), ev.end());  // tokens of decode steps that did run are not lost
+                throw;
+            }
+            b->outbox.insert(b->outbox.end(), ev.begin(), ev.end());
         }
+        int n = 0;
+        for (; n < capacity && !b->outbox.empty(); n++) {
+            request_ids[n] = b->outbox.front().id;
+            tokens[n]      = b->outbox.front().token;
+            finished[n]    = b->outbox.front().finished;
+            b->outbox.pop_front();
+        }
+        *n_events = n;
+    });
+}
+extern "C" int ftcf_batcher_set_token_callback(ftcf_batcher_t b, ftcf_token_callback_fn fn, void* user)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        b->on_token      = fn;
+        b->on_token_user = user;
     });
 }
 extern "C" int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages)
@@ -3444,7 +3574,7 @@ extern "C" int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running,
             *waiting = (int)b->waiting.size();
         }
         if (running) {
-            *running = run;
+            *running = run + (b->outbox.empty() ? 0 : 1);  // (events still to be fetched keep the batcher "busy")
         }
         if (free_pages) {
             *free_pages = (int)b->free_pages.size();

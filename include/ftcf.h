@@ -245,8 +245,17 @@ int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_l
                            float temperature, float repetition_penalty, unsigned long long seed, const int* stop_words,
                            int stop_len, long* request_id);
 /* One scheduler iteration: one decode step for the running sequences, then admissions (prefill + first token).  Returns one
- * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch. */
+ * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch.
+ * With sequences running, a prompt longer than FTCF_BATCHER_PREFILL_CHUNK tokens (default 512; 0 = never) is admitted alone and
+ * prefilled in chunks of that many tokens, with one decode step of the running sequences after every chunk but the last: the
+ * iteration then produces several tokens per running sequence.  Events that do not fit `capacity` are returned by the next
+ * calls, before a new iteration runs (`running` of ftcf_batcher_status counts 1 for them). */
 int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events);
+/* Streaming (the reference's token callback, GptNeoX.cc:362-375, 1023 `token_generated_cb_`, per request here): `fn` is called
+ * from inside ftcf_batcher_step, on the calling thread, for every event the moment its token is on the host -- i.e. between
+ * the chunks of a long admission as well -- and the same events are returned by the step call afterwards.  NULL unsets. */
+typedef void (*ftcf_token_callback_fn)(void* user, long request_id, int token, int finished);
+int ftcf_batcher_set_token_callback(ftcf_batcher_t b, ftcf_token_callback_fn fn, void* user);
 int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages);
 /* drop a waiting or running request (its pages return to the pool at once); *found = 0 when the id is unknown or already done */
 int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found);

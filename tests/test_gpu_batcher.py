@@ -271,3 +271,56 @@ def test_a_seeded_sampling_request_is_the_same_alone_and_in_a_busy_batcher(gh):
     rid2 = cb.submit(prompt, 10, **kw)
     busy = cb.run_all()[rid2]
     assert busy == alone, (busy, alone)
+
+
+@pytest.mark.parametrize("chunk", [8, 4])
+def test_a_long_prompt_is_admitted_in_chunks_between_decode_steps(gh, monkeypatch, chunk):
+    """With a slot running, a prompt longer than the chunk is prefilled alone, chunk by chunk, and the running slots decode one
+    token after every chunk but the last (the admission no longer stalls them for the whole prompt): in the step() call that
+    admits a 19-token prompt in chunks of 8, the running request receives 1 + 2 tokens.  Every stream still equals what the CPU
+    oracle generates for the request alone (the chunked prompt phase is the same arithmetic row by row).  The token callback
+    sees every event as it is produced; with chunks of 4 the iteration produces 9 events for event arrays of 6: the rest comes
+    with the next call, before a new iteration runs."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    from oracle import oracle as orc
+    from tests.helpers import weight_list_to_layers
+    monkeypatch.setenv("FTCF_BATCHER_PREFILL_CHUNK", str(chunk))
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    layers, glob = weight_list_to_layers(cfg, w)
+    model = orc.Model(dict(cfg, fp16=1), layers, glob)
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(17)
+    r19 = rng.randint(3, V, size=19).tolist()
+    r7 = rng.randint(3, V, size=7).tolist()
+    pb = z["prompt_b"].tolist()
+    reqs = [(pb, 12), (r19, 9), (r7, 6)]
+    ref = [_oracle_alone(model, p, n, end_id, top_k=1) for p, n in reqs]
+    cb = ContinuousBatcher(op, max_batch=3, page_tokens=8, num_pages=24, max_seq_len=64)
+    ids, got, per_step, streamed, returned = {}, {}, [], [], []
+    cb.set_token_callback(lambda rid, tok, fin: streamed.append((rid, tok, fin)))
+    arrivals = {0: [0], 2: [1, 2]}
+    it = 0
+    while arrivals or cb.busy():
+        for k in arrivals.pop(it, []):
+            ids[cb.submit(reqs[k][0], reqs[k][1], top_k=1)] = k
+        evs = cb.step()
+        returned += evs
+        per_step.append([ids[rid] for rid, _, _ in evs])
+        for rid, tok, fin in evs:
+            got.setdefault(ids[rid], []).append(tok)
+        it += 1
+        assert it < 1000
+    for k in range(len(reqs)):
+        assert got[k] == ref[k], (k, got[k], ref[k])
+    assert streamed == returned
+    if chunk == 8:
+        # call 2: one decode step, then the 19-token prompt in chunks of 8, 8, 3 with a decode step after the first two; the
+        # 7-token prompt in one piece
+        assert per_step[2] == [0, 0, 0, 1, 2], per_step[:4]
+    else:
+        # chunks of 4, 4, 4, 4, 3 (four decode steps in between), then the 7-token prompt as 4 + 3 with one decode step of the
+        # now TWO running requests in between: 9 events for arrays of 6
+        assert per_step[2] == [0, 0, 0, 0, 0, 1] and per_step[3] == [0, 1, 2], per_step[:5]
+    cb.set_token_callback(None)
+    assert cb.status()["free_pages"] == 24
