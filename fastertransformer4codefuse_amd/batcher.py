@@ -63,9 +63,9 @@ class ContinuousBatcher:
         the chunks of a long admission as well); None unsets.  The events are still returned by step()."""
         if fn is None:
             self._cb = None
-            capi.check(capi.lib().ftcf_batcher_set_token_callback(self._h, C.cast(None, capi.TOKEN_CALLBACK), None))
+            capi.check(capi.lib().ftcf_batcher_set_token_callback(self._h, C.cast(None, capi.BATCHER_TOKEN_CALLBACK), None))
             return
-        self._cb = capi.TOKEN_CALLBACK(lambda _user, rid, tok, fin: fn(int(rid), int(tok), bool(fin)))
+        self._cb = capi.BATCHER_TOKEN_CALLBACK(lambda _user, rid, tok, fin: fn(int(rid), int(tok), bool(fin)))
         capi.check(capi.lib().ftcf_batcher_set_token_callback(self._h, self._cb, None))
 
     def step(self):

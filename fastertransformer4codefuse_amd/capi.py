@@ -19,7 +19,7 @@ class FtcfError(RuntimeError):
 TOKEN_CALLBACK = C.CFUNCTYPE(None, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p)
 # ftcf_host_allgather_fn (include/ftcf.h): int (*)(void* user, const void* send, void* recv, size_t bytes_per_rank)
 HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
-TOKEN_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int, C.c_int)
+BATCHER_TOKEN_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_int, C.c_int)
 
 
 class GptNeoXConfig(C.Structure):

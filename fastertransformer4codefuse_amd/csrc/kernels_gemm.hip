@@ -437,7 +437,8 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     FTCF_CHECK_ARG(k % GEMM_KSTEP == 0, "GEMM needs k % 64 == 0 (as the reference: fpA_intB_gemm_template.h:159-163)");
     FTCF_CHECK_ARG(n % 16 == 0, "GEMM needs n % 16 == 0");
     const int NT = n / 16;
-    static const int splitk_target = getenv("FTCF_GEMM_SPLITK") ? atoi(getenv("FTCF_GEMM_SPLITK")) : 256;
+    const char*      sk_env        = getenv("FTCF_GEMM_SPLITK");  // (read per call: the tests switch it inside one process)
+    const int        splitk_target = sk_env ? atoi(sk_env) : 256;
     static const int splitk_max_m = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : GEMM_SPLITK_MAX_M;
     if (workspace && m <= splitk_max_m && splitk_target > 0) {
         // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)

@@ -113,7 +113,12 @@ def test_two_processes_on_one_gpu_exchange_through_ipc_windows(gh, tmp_path, mod
         # one or two rows: the persistent kernel's tensor-parallel instantiation, the all-reduce inside the launch through
         # the IPC-mapped windows (decode_path 1); more rows: the general path with host-staged collectives (2)
         want = 1 if B <= 2 else 2
-        assert int(res[0][name + ".decode_path"][0]) == want and int(res[1][name + ".decode_path"][0]) == want, name
+        got = (int(res[0][name + ".decode_path"][0]), int(res[1][name + ".decode_path"][0]))
+        if B <= 2 and got == (0, 0) and int(res[0]["attempts"][0]) == 6:
+            # six fresh engine pairs in a row fell back to the collective path TOGETHER (the designed reaction to a peer
+            # kernel that is not scheduled next to this one: nothing guarantees two processes co-run on one GPU)
+            pytest.xfail("the two processes' kernels were not co-scheduled in six attempts: in-kernel path not exercised")
+        assert got == (want, want), name
         o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode), lay, glob).generate(ids, lens, n_out, return_logits=True)
         _check(o["output_ids"], o["logits"], res[0][name + ".output_ids"], res[0][name + ".logits"], lens, f"{model} {name} vs oracle", frac)
         r1 = gh.run_op(op1, ids, lens, n_out, cfg["vocab_size"], **kw)

@@ -32,9 +32,9 @@ def main():
     # Two processes on one GPU run concurrently in practice but nothing guarantees it: when the peer's kernel is not
     # scheduled next to this one, the bounded hand-off gives up, every rank learns of it, the request is replayed on the
     # collective path and the engine stays there (the designed fall-back).  The test is about the in-kernel path, so a
-    # run in which a one- or two-row request left it is repeated with fresh engines, up to three times.
+    # run in which a one- or two-row request left it is repeated with fresh engines, up to six times.
     reqs = requests(cfg, model)
-    for attempt in range(3):
+    for attempt in range(6):
         op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD)
         res = {}
         left = 0
