@@ -712,7 +712,10 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, 
 // is that a slot streams nothing while its workgroup computes, leaves and is replaced: ~60 % of the in-flight capacity.)
 // tag = f(decode step, launch) is unique per launch within a request; the engine zeroes the granules when a request begins.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SMB_T     = 20;       // tiles per wave and slice
+#ifndef SMB_T_TILES
+#define SMB_T_TILES 20
+#endif
+constexpr int SMB_T     = SMB_T_TILES;  // tiles per wave and slice
 constexpr int SMB_WAVES = 4;        // waves (16-column groups) per workgroup: they share the x slice
 constexpr int SMB_SPINS = 1 << 22;  // bounded: a protocol bug must not hang the GPU
 typedef unsigned long long                          smb_u64;
