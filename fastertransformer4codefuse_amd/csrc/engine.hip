@@ -820,7 +820,7 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
 
 // the stand-alone GEMM entry points carry no workspace argument (the reference's runner takes one from its caller:
 // fpA_intB_gemm.h gemm(..., workspace_ptr, workspace_bytes)): one split-K workspace per (device, stream) that has called with
-// 17..256 rows, kept for the life of the process
+// 17..320 rows, kept for the life of the process
 static float* abi_gemm_workspace(int m, hipStream_t s)
 {
     if (m <= 16) {
@@ -1031,7 +1031,7 @@ struct ftcf_gptneox {
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
-    float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..256 rows (short prompt phases)
+    float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..320 rows (short prompt phases)
     size_t    smallm_partial = 0;
     unsigned  smallm_seq = 0;       // launch counter: part of the granule tag of its in-launch reduction
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
@@ -1218,7 +1218,7 @@ struct ftcf_gptneox {
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
             smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
-            const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= 256);  // (a chunked prompt phase runs <= 256 rows at a time)
+            const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= 320);
             tiled_ws              = (!fp32 && tiled_rows) ? c.take<float>(gemm_tiled_workspace_bytes() / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);
@@ -2891,7 +2891,7 @@ struct ftcf_batcher {
     DecodeState *d_state = nullptr, *d_gstate = nullptr;
     void*        samp_ws = nullptr;
     float*       smallm_ws = nullptr;
-    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..256 rows)
+    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..320 rows)
     // chunked admission: with slots running, a prompt longer than this is prefilled alone, `prefill_chunk` tokens at a time, one
     // decode step of the running slots between two chunks (FTCF_BATCHER_PREFILL_CHUNK; 0 = whole prompts)
     int prefill_chunk = 512;
@@ -2985,7 +2985,7 @@ struct ftcf_batcher {
                              + gemm_smallm_workspace_bytes(bc, H, hl, i8) + gemm_smallm_workspace_bytes(bc, H, il, i8);
             smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
         }
-        if (max_batch > 16 && max_batch <= 256) {
+        if (max_batch > 16 && max_batch <= 320) {
             tiled_ws = dmalloc<float>(gemm_tiled_workspace_bytes() / 4);
         }
         std::vector<uint8_t> fin(max_batch, 1);

@@ -19,7 +19,7 @@ constexpr int GEMM_KSTEP = 64;
 // split-K form of the tiled GEMM (short prompt phases): partial tiles [tile][slice] of 64 x 256 fp32 + one ticket per tile
 constexpr size_t GEMM_SPLITK_WS    = (size_t)48 << 20;
 constexpr size_t GEMM_SPLITK_TILES = 4096;
-constexpr int    GEMM_SPLITK_MAX_M = 256;
+constexpr int    GEMM_SPLITK_MAX_M = 320;  // (13B int8 prompt phase, ms: 257 tokens 14.7 on the 128-row form, 12.4 here; 384: 15.5 / 16.0)
 
 // one 16-byte weight fragment against the 16 rows of x in LDS (xr: this lane's row lane&15, k group lane>>4)
 template<bool INT8>
@@ -56,7 +56,7 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 // tile in LDS, so WAVES = 8 halves the number of workgroups re-reading A from L2 (prefill is L2-traffic bound: at m = 1024
 // a 128 x 128 tile moves 1.2 GB of A and 0.6 GB of weights through the L2 for the QKV GEMM).
 //
-// SPLITK (short prompt phases, 17..256 rows: HBM bound work on too few tiles to fill 256 CUs -- n = 5120 at 64 < m <= 128 is
+// SPLITK (short prompt phases, 17..320 rows: HBM bound work on too few tiles to fill 256 CUs -- n = 5120 at 64 < m <= 128 is
 // 40 workgroups): the K extent of a block tile is cut into KS slices, one workgroup each (all on the tile's XCD).  Every
 // workgroup stores its fp32 accumulators in MFMA fragment order (16 B per lane, one coalesced wave store per fragment) and takes
 // a ticket; the one that takes the tile's last ticket adds the KS partial tiles IN SLICE ORDER (deterministic) and applies the
