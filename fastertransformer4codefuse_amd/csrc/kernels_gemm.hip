@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC2 ? WAVES / 2 : 1) void k_gemm_tiled
 #ifndef GEMM_PF_ROWS
 #define GEMM_PF_ROWS 2
 #endif
-            constexpr int PR = RG < GEMM_PF_ROWS ? RG : GEMM_PF_ROWS;  // row groups whose fragments are in flight together
+            constexpr int PR = RG % GEMM_PF_ROWS == 0 ? GEMM_PF_ROWS : 1;  // row groups whose fragments are in flight together
             f16x8         af[PR][2];
 #pragma unroll
             for (int r = 0; r < PR; r++) {
@@ -443,7 +443,14 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     if (workspace && m <= splitk_max_m && splitk_target > 0) {
         // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)
         static const int deep = getenv("FTCF_GEMM_DEEP") ? atoi(getenv("FTCF_GEMM_DEEP")) : 4;
-        constexpr int NG = 2, BM = 64, DQ = 4;
+        // 64-row tiles; one row block (m <= 64): the lowest tile that covers it, 32 / 48 / 64 rows -- a 64-row tile on 17..32 rows
+        // spends half its MFMAs and LDS reads on clamped duplicate rows (13B int8 prompt phase: 17 tokens 5.2 -> 4.4 ms, 33: 5.3 ->
+        // 5.0).  With several row blocks lower tiles measured no better (a k-step's fixed costs -- barrier, A staging,
+        // dequantisation -- outweigh its MFMAs at these heights).
+        static const int rgsel = getenv("FTCF_GEMM_RG32") ? atoi(getenv("FTCF_GEMM_RG32")) : 1;
+        constexpr int NG = 2, DQ = 4;
+        const int     RGs = (rgsel && m <= 64) ? std::max(2, (m + 15) / 16) : 4;
+        const int BM = RGs * 16;
         const int gx = (NT + 8 * NG - 1) / (8 * NG), gy = (m + BM - 1) / BM, gx8 = 8 * ((gx + 7) / 8);
         const int ksteps = k / GEMM_KSTEP;
         int       KS     = std::max(1, std::min({8, splitk_target / (gx8 * gy), ksteps / 8}));
@@ -457,21 +464,32 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
             f32x4*    ws   = reinterpret_cast<f32x4*>(workspace);
             unsigned* tk   = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(workspace) + GEMM_SPLITK_WS);
             dim3      grid(gx8 * gy * KS);
-#define FTCF_SK(I8, Dv)                                                                                                          \
-    hipLaunchKernelGGL((k_gemm_tiled<I8, 4, NG, 8, false, true, true, Dv, (Dv > 0)>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, n, k, \
-                       gx, gy, KS, per, ws, tk)
+#define FTCF_SK(I8, Dv, RGv)                                                                                                     \
+    hipLaunchKernelGGL((k_gemm_tiled<I8, RGv, NG, 8, false, true, true, Dv, (Dv > 0)>), grid, dim3(512), 0, s, A, W, scale, bias, act, C, m, \
+                       n, k, gx, gy, KS, per, ws, tk)
+#define FTCF_SK_RG(I8, Dv)                                                                                                       \
+    if (RGs == 2) {                                                                                                              \
+        FTCF_SK(I8, Dv, 2);                                                                                                      \
+    }                                                                                                                            \
+    else if (RGs == 3) {                                                                                                         \
+        FTCF_SK(I8, Dv, 3);                                                                                                      \
+    }                                                                                                                            \
+    else {                                                                                                                       \
+        FTCF_SK(I8, Dv, 4);                                                                                                      \
+    }
             if (int8 && dd) {
-                FTCF_SK(true, DQ);
+                FTCF_SK_RG(true, DQ)
             }
             else if (int8) {
-                FTCF_SK(true, 0);
+                FTCF_SK_RG(true, 0)
             }
             else if (dd) {
-                FTCF_SK(false, DQ);
+                FTCF_SK_RG(false, DQ)
             }
             else {
-                FTCF_SK(false, 0);
+                FTCF_SK_RG(false, 0)
             }
+#undef FTCF_SK_RG
 #undef FTCF_SK
             FTCF_HIP_CHECK(hipGetLastError());
             return;

@@ -86,7 +86,7 @@ def test_fpA_intB_gemm_split_k_forms(k):
     tickets; rtol / atol as the reference's grid test (th_gemm_dequantize.py:65-115)."""
     n = 1280
     qd, sd, q_rm, s_o = _grid_weights(n, k)
-    for m in (17, 64, 65, 200, 256):
+    for m in (17, 33, 48, 64, 65, 200, 256, 300):  # tile heights 32 / 48 / 64, one to five row blocks
         g = torch.Generator().manual_seed(m * 7 + k)
         act = torch.randn(m, k, generator=g).half()
         bias = torch.randn(n, generator=g).half()
