@@ -1003,7 +1003,11 @@ struct ftcf_gptneox {
     // events; under capture the branch becomes a parallel branch of the token's hipGraph)
     hipStream_t               side = nullptr;
     hipEvent_t                ev_fork = nullptr, ev_join = nullptr;
-    int                       decode_branches = 1;  // FTCF_DECODE_BRANCHES=0: one stream, GEMMs paired per launch
+    // batched decode GEMMs: 1 = the attention branch and the FFN branch on two streams, 0 = one stream, the independent GEMMs
+    // paired per launch.  Default: two streams at tensor_para_size 1 (the launches are bandwidth bound and fill each other's ramps:
+    // 13B int8 bs = 16, 4.31 vs 4.66 ms per step), pairs on a tensor-parallel shard (launch-latency bound: TP 8 shard 1.79 vs 2.36
+    // ms, TP 4 2.16 vs 2.62, TP 2 3.13 vs 3.28; `bench.py --fake-tp`).  FTCF_DECODE_BRANCHES overrides.
+    int                       decode_branches = 1;
     hipEvent_t                ev_user = nullptr;
     hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
     bool                      tp_graph = false;
@@ -2722,6 +2726,7 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_PERSIST_CS3")) {
             e->persist_cs3 = atoi(m);
         }
+        e->decode_branches = cfg->tensor_para_size == 1 ? 1 : 0;
         if (const char* m = getenv("FTCF_DECODE_BRANCHES")) {
             e->decode_branches = atoi(m);
         }
