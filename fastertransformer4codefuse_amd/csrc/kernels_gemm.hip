@@ -9,7 +9,13 @@
 // wave-load and one lane's 16 bytes ARE that lane's B fragment(s) (int8: two fragments after the in-register
 // dequant, k order (lane>>4)*16 + c*8 + j; fp16: one fragment, k order (lane>>4)*8 + j).  Each wave owns 16 output
 // columns and keeps its dequantised B fragments in registers across all row groups of the block tile; activations
-// are staged through LDS and shared by the 4 waves.  Roofline: MFMA for m >= 512, HBM below.
+// are staged through LDS and shared by the waves of the workgroup.  Roofline: MFMA for m >= 512, HBM below.
+//
+// Forms of k_gemm_tiled, by row count (launch_gemm_tiled): 17..320 rows with a workspace -- 32 / 48 / 64-row tiles cut along K
+// into ~256 workgroups, a ring of four k-steps of weight tiles and A-tile registers, the slices reduced inside the launch
+// (SPLITK, D = 4); more rows -- 64- or 128-row tiles, ring of two k-steps (D = 2) when the k-steps divide, with the A
+// fragments prefetched (PF) where one workgroup per CU runs anyway and held to 128 VGPRs (OCC2) otherwise; the plain loop
+// (D = 0) for odd k-step counts and without a workspace.  5..16 rows: k_gemm_smallm_burst below.
 #include "ftcf_common.h"
 #include "kernels.h"
 
