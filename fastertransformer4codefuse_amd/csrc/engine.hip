@@ -3437,6 +3437,7 @@ struct ftcf_batcher {
                                 live |= s.active;
                             }
                             if (live) {
+                                refresh_host_flags();
                                 decode(*hook_ev);
                             }
                         };
@@ -3489,6 +3490,12 @@ struct ftcf_batcher {
                 throw;
             }
         }
+        refresh_host_flags();
+    }
+    // host view of the running slots' sampling parameters (kernel selection and LDS sizing of the sampling kernels): after every
+    // admission, and before a decode step that runs inside an admission (a request admitted a moment ago is already running)
+    void refresh_host_flags()
+    {
         host_max_top_k = 1;
         host_any_top_p = 0;
         host_any_temperature = false;

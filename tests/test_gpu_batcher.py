@@ -324,3 +324,29 @@ def test_a_long_prompt_is_admitted_in_chunks_between_decode_steps(gh, monkeypatc
         assert per_step[2] == [0, 0, 0, 0, 0, 1] and per_step[3] == [0, 1, 2], per_step[:5]
     cb.set_token_callback(None)
     assert cb.status()["free_pages"] == 24
+
+
+def test_decode_steps_inside_an_admission_use_the_running_slots_sampling_parameters(gh, monkeypatch):
+    """A request admitted a moment ago decodes inside the NEXT request's chunked admission: the host-side view of the running
+    slots' sampling parameters (largest top_k, any top-p row, temperature) must include it by then.  A seeded top-k / top-p
+    request that is admitted in chunks right before another long prompt produces the same tokens as alone."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    monkeypatch.setenv("FTCF_BATCHER_PREFILL_CHUNK", "4")
+    cfg, w, z = load_tiny()
+    V = cfg["vocab_size"]
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(23)
+    long_a = rng.randint(3, V, size=17).tolist()
+    long_b = rng.randint(3, V, size=15).tolist()
+    kw = dict(top_k=8, top_p=0.95, temperature=1.1, seed=5)
+    cb = ContinuousBatcher(op, max_batch=3, page_tokens=8, num_pages=24, max_seq_len=64)
+    rid = cb.submit(long_a, 10, **kw)
+    alone = cb.run_all()[rid]
+    g0 = cb.submit(z["prompt_b"].tolist(), 14, top_k=1)  # a greedy request is running (largest top_k so far: 1)
+    cb.step()
+    cb.step()
+    rid2 = cb.submit(long_a, 10, **kw)                      # admitted in chunks; then decodes inside long_b's admission
+    g1 = cb.submit(long_b, 6, top_k=1)
+    out = cb.run_all()
+    assert out[rid2] == alone, (out[rid2], alone)
+    assert len(out[g1]) <= 6 and g0 in out
