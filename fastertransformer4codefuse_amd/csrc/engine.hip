@@ -823,8 +823,8 @@ static void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f
 // 17..320 rows, kept for the life of the process
 static float* abi_gemm_workspace(int m, hipStream_t s)
 {
-    if (m <= 16) {
-        return nullptr;
+    if (m <= 16 || m > gemm_tiled_splitk_max_m()) {
+        return nullptr;  // (only the split-K form of 17..320 rows uses it)
     }
     static std::mutex                                    mu;
     static std::map<std::pair<int, hipStream_t>, float*> ws;
@@ -834,7 +834,10 @@ static float* abi_gemm_workspace(int m, hipStream_t s)
     float*&                     p = ws[{dev, s}];
     if (!p) {
         FTCF_HIP_CHECK(hipMalloc(&p, gemm_tiled_workspace_bytes()));
-        FTCF_HIP_CHECK(hipMemset(p, 0, gemm_tiled_workspace_bytes()));
+        // only the tickets need zeros (the partial tiles are written before they are read), and on the CALLER's stream: a
+        // null-stream memset is not ordered with a launch on a non-blocking stream
+        FTCF_HIP_CHECK(hipMemsetAsync(reinterpret_cast<char*>(p) + gemm_tiled_workspace_bytes() - gemm_tiled_ticket_bytes(), 0,
+                                      gemm_tiled_ticket_bytes(), s));
     }
     return p;
 }
@@ -1187,6 +1190,19 @@ struct ftcf_gptneox {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, tpn == 1);
+                // second form of the kernel (persist4_device.hip.h: the attention branch on the control waves under the FFN
+                // streams): one row, <= 256 keys per KV split, up to FTCF_PERSIST_A4_MAX_TP ranks (finer shards are hand-off
+                // bound, not stream bound, and keep the eight-wave attention of the first form)
+                static const int a4_max_tp = getenv("FTCF_PERSIST_A4_MAX_TP") ? atoi(getenv("FTCF_PERSIST_A4_MAX_TP")) : 2;
+                static const int a4_cs3 = getenv("FTCF_PERSIST4_CS3") ? atoi(getenv("FTCF_PERSIST4_CS3")) : 12;
+                if (pplan.ok && B == 1 && tpn <= a4_max_tp) {
+                    const PersistPlan p4 = persist_plan4(
+                        persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, a4_cs3, false), B, H, hl, il, nhl,
+                        dh, s_max, int8);
+                    if (p4.ok && p4.a4) {
+                        pplan = p4;
+                    }
+                }
                 const bool resident = !pplan.ok ? false
                                       : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
                                                  : persist_resident(pplan, int8, B, dh, num_cu, tpn);
@@ -2181,7 +2197,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
         ps_tab_ready = false;
         static const int tab_env = getenv("FTCF_PERSIST_TABLES") ? atoi(getenv("FTCF_PERSIST_TABLES")) : 1;
-        if (tab_env && ps_tab && cfg.tensor_para_size == 1) {
+        if (tab_env && ps_tab && !(cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->local)) {
             // the run / tile tables of this plan: one launch over no layers builds and stores them, every token's launch
             // loads them (17 us of table building per launch otherwise)
             PersistParams pp = persist_params(B, s_max);

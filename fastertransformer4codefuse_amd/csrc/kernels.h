@@ -71,6 +71,7 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
 // slices reduced inside the launch.  One workspace serves one stream.
 size_t gemm_tiled_workspace_bytes();
 size_t gemm_tiled_ticket_bytes();  // the workspace's tail
+int    gemm_tiled_splitk_max_m();  // rows up to which launch_gemm_tiled uses the workspace (FTCF_GEMM_SPLITK_MAX_M)
 void   launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
                          int k, bool int8, hipStream_t s, float* workspace = nullptr);
 // batched decode GEMM for m <= 16 rows (HBM bound forms); with a `workspace` (>= gemm_smallm_workspace_bytes of this
@@ -206,6 +207,12 @@ struct PersistPlan {
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
     int    p3l;       // the control waves' P3 share is prefetched into LDS during the attention (one row, short form, TP = 1)
     int    a3;        // the attention runs on the control waves alone, K rows by LDS-DMA (one row, short form, TP = 1)
+    // second form of the kernel (persist4_device.hip.h, k_decode_persistent4: the attention branch on the control waves under
+    // the FFN streams; one row, short attention form):
+    int    a4;
+    int    r1max, r3max;  // runs per workgroup (P1 / P3): the partial-sum buffers' heights
+    int    mid_span;      // halves of mid a workgroup stages (the K range of its FFN2 pieces), the maximum over workgroups
+    int    ctx_off;       // LDS half offset of ctx inside the x region
     size_t smem;
 };
 struct PersistParams {
@@ -261,6 +268,10 @@ bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int 
 void        launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipStream_t s);
 // tensor-parallel instantiations (kernels_persist_tp.hip); nullptr when the shape has none
 const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
+// second form (kernels_persist4.hip): turns an eligible plan of persist_plan() into one for k_decode_persistent4 (a4 = 1, its
+// own P1 tables and LDS carve), or returns it unchanged; the kernel for a shape (nullptr: none)
+PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8);
+const void* persist4_kernel(bool int8, int dh, bool tp, bool group);
 
 // ---- fp32 instantiation (FTGptNeoX<float>, GptNeoXOp.cc:56-70) : kernels_fp32.hip ----
 struct Mmha32Params {

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
                                                                 const int* __restrict__ input_lengths,
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
-                                                                f16* __restrict__ ctx, float qk_scale, int crm, int s_lo)
+                                                                f16* __restrict__ ctx, float qk_scale, int crm, int s_lo,
+                                                                int s_hi)
 {
     static_assert(DH % 16 == 0 && (KT == 32 || KT == 64), "head size: a multiple of 16");
     constexpr int ND  = (DH + 31) / 32;  // d steps of Q K^T
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
         m_run[j] = -INFINITY;
         l_run[j] = 0.f;
     }
-    const int q_last   = min(q0 + 63, len - 1);
+    const int q_last   = min(min(q0 + 63, len - 1), s_hi - 1);  // last query row of the block whose K/V is in the cache
     const int w_last   = q0 + wid * 16 + 15;  // last query row of this wave
     f16*      sPw      = sP[wid];
     for (int k0 = 0; k0 <= q_last; k0 += KT) {
@@ -436,14 +437,16 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
         for (int i = threadIdx.x; i < KT * DH / 8; i += 256) {  // K tile, row major
             const int r = i / (DH / 8), ch = i % (DH / 8);
             int       kk = k0 + r;
-            kk           = kk < S ? kk : S - 1;
+            // (keys above the block's last query row are masked for every row of the block: they re-read that row instead of
+            // cache lines a chunked prompt phase has not written yet -- a masked P = 0 times a stale NaN / Inf is NaN)
+            kk           = kk < q_last ? kk : q_last;
             *reinterpret_cast<u32x4*>(&sK[r * LDK + ch * 8]) = *reinterpret_cast<const u32x4*>(kc + (size_t)kk * DH + ch * 8);
         }
         for (int i = threadIdx.x; i < (KT / 2) * (DH / 8); i += 256) {  // V tile, transposed: a thread moves 2 keys x 8 dims
             const int rp = i % (KT / 2), ch = i / (KT / 2);            // (lanes of a wave spread over the banks)
             int       k1 = k0 + 2 * rp, k2 = k0 + 2 * rp + 1;
-            k1           = k1 < S ? k1 : S - 1;
-            k2           = k2 < S ? k2 : S - 1;
+            k1           = k1 < q_last ? k1 : q_last;
+            k2           = k2 < q_last ? k2 : q_last;
             const f16x8 v1 = *reinterpret_cast<const f16x8*>(vc + (size_t)k1 * DH + ch * 8);
             const f16x8 v2 = *reinterpret_cast<const f16x8*>(vc + (size_t)k2 * DH + ch * 8);
 #pragma unroll
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int qi = q0 + wid * 16 + g * 4 + j;
-        if (qi < len && qi < S) {
+        if (qi < len && qi < s_hi) {
             const float inv = 1.f / (l_run[j] + 1e-6f);  // unfused_attention_kernels.cu:322
 #pragma unroll
             for (int n = 0; n < NO; n++) {
@@ -568,7 +571,7 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
 #define X(D)                                                                                                           \
     if (dh == D) {                                                                                                     \
         hipLaunchKernelGGL((k_context_attention_mfma<D, (D > 128 ? 32 : 64)>), grid, dim3(256), 0, s, qkv, input_lengths,\
-                           k_cache, v_cache, S, nh, s_max, ctx, qk_scale, cache_row_mult, s_lo);                       \
+                           k_cache, v_cache, S, nh, s_max, ctx, qk_scale, cache_row_mult, s_lo, s_hi);                 \
     }
         FTCF_HEAD_SIZES(X)
 #undef X

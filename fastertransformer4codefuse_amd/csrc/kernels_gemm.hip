@@ -66,8 +66,9 @@ constexpr int GEMM_LDA   = GEMM_KSTEP + 16;
 // 40 workgroups): the K extent of a block tile is cut into KS slices, one workgroup each (all on the tile's XCD).  Every
 // workgroup stores its fp32 accumulators in MFMA fragment order (16 B per lane, one coalesced wave store per fragment) and takes
 // a ticket; the one that takes the tile's last ticket adds the KS partial tiles IN SLICE ORDER (deterministic) and applies the
-// epilogue.  Agent-scope fences on both sides of the ticket (release: L2 write-back, acquire: L2 invalidate -- the XCDs' L2s are
-// not coherent with each other) make the partials visible wherever the last workgroup runs; it re-arms the ticket.
+// epilogue.  The partials are write-through (sc1) stores whose acknowledgement every wave awaits (s_waitcnt vmcnt(0)) before the
+// workgroup takes its ticket, and the last workgroup reads them back with sc1 loads (the XCDs' L2s are not coherent with each
+// other): no agent-scope fence, i.e. no whole-L2 write-back / invalidate per workgroup; it re-arms the ticket.
 // PF: all (of two row groups') A fragments of a k-step are read from LDS before the dequantisation; OCC2: register budget of two
 // workgroups per CU (128 VGPRs at 8 waves)
 template<bool INT8, int RG, int NG, int WAVES, bool NT_W = true, bool XCD = false, bool SPLITK = false, int D = 0, bool PF = false,
@@ -327,7 +328,10 @@ __global__ __launch_bounds__(64 * WAVES, OCC2 ? WAVES / 2 : 1) void k_gemm_tiled
                 }
             }
             __shared__ int last;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have been acknowledged
+            // Every wave waits for the acknowledgement of ITS OWN write-through stores (vmcnt counts stores on gfx950) before the
+            // barrier: a workgroup-scope release alone compiles to no wait at all, and wave 0's ticket could then reach the L2
+            // ahead of the other waves' partials.  No L2 write-back is needed: the stores are sc1 (written through) already.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
                 const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -434,6 +438,12 @@ size_t gemm_tiled_workspace_bytes()
     return GEMM_SPLITK_WS + GEMM_SPLITK_TILES * sizeof(unsigned);
 }
 
+int gemm_tiled_splitk_max_m()
+{
+    static const int v = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : GEMM_SPLITK_MAX_M;
+    return v;
+}
+
 void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
                        int k, bool int8, hipStream_t s, float* workspace)
 {
@@ -445,7 +455,7 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     const int NT = n / 16;
     const char*      sk_env        = getenv("FTCF_GEMM_SPLITK");  // (read per call: the tests switch it inside one process)
     const int        splitk_target = sk_env ? atoi(sk_env) : 256;
-    static const int splitk_max_m = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : GEMM_SPLITK_MAX_M;
+    const int splitk_max_m = gemm_tiled_splitk_max_m();
     if (workspace && m <= splitk_max_m && splitk_target > 0) {
         // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)
         static const int deep = getenv("FTCF_GEMM_DEEP") ? atoi(getenv("FTCF_GEMM_DEEP")) : 4;

@@ -260,10 +260,16 @@ static bool ps_kernel_resident(const void* k, const PersistPlan& pl, int num_cu,
 }
 bool persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world)
 {
+    if (pl.a4) {
+        return ps_kernel_resident(persist4_kernel(int8, dh, true, true), pl, num_cu, (long)pl.NB * world);
+    }
     return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, true), pl, num_cu, (long)pl.NB * world);
 }
 bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp)
 {
+    if (pl.a4) {
+        return ps_kernel_resident(persist4_kernel(int8, dh, tp > 1, false), pl, num_cu, pl.NB);
+    }
     if (tp > 1) {
         return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
     }
@@ -276,7 +282,9 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false) : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0, p.plan.p3l != 0);
+    const void* k = p.plan.a4 ? persist4_kernel(int8, p.dh, p.tp > 1, false)
+                    : p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false)
+                               : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0, p.plan.p3l != 0);
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
     FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;
@@ -288,7 +296,7 @@ void launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipS
 {
     FTCF_CHECK_ARG(g.world >= 2 && g.world <= PERSIST_MAX_TP && g.nb >= 1, "bad local group");
     const PersistParams& p = g.p[0];
-    const void*          k = persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
+    const void*          k = p.plan.a4 ? persist4_kernel(int8, p.dh, true, true) : persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
     FTCF_CHECK_ARG(k != nullptr && p.plan.ok && p.plan.NB == g.nb, "persistent decode: no group kernel for this shape");
     PersistGroupParams gg     = g;
     void*              args[] = {&gg};

@@ -107,6 +107,8 @@ typedef const PersistLayer PsLayerC;
 // batch-table entry (one per PS_U tiles of ONE run, consecutive k): bit 0 valid, 1 flush after the batch, 2..6 run,
 // 8..24 LDS half offset of the first tile's x, 25 x stride select, 26 wait for the late x vector, 27..30 valid tiles
 constexpr unsigned PS_BT_FAST = 1u, PS_BT_FLUSH = 2u, PS_BT_XSEL = 1u << 25, PS_BT_WAIT = 1u << 26;
+// bit 31 (persist4_device.hip.h): after this batch's flush the wave bumps an LDS counter -- its last batch of the QKV runs
+constexpr unsigned PS_BT_SIGNAL = 1u << 31;
 
 struct RunRec {  // static per launch (LDS)
     int tile0;  // first tile of the run inside its weight array
@@ -223,9 +225,10 @@ struct PsStage {
     int             xs0, xs1;
 };
 
-template<bool INT8, int M>
+template<bool INT8, int M, bool SIG = false>
 struct PsStream {
     static constexpr int TK = TileK<INT8>::value;
+    int* sig = nullptr;  // SIG: LDS counter bumped after a PS_BT_SIGNAL batch
     u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
     f32x4      acc;
     PsStage    g;
@@ -304,6 +307,13 @@ struct PsStream {
         }
         if (bd & PS_BT_FLUSH) {
             flush(j);
+        }
+        if constexpr (SIG) {
+            if (bd & PS_BT_SIGNAL) {  // (DS operations of a wave execute in order: the flush above is visible first)
+                if (lane == 0) {
+                    atomicAdd(sig, 1);
+                }
+            }
         }
     }
     // the first rotation: issued before the hand-off this stage waits for.  The streamer waves issue only half of it
@@ -387,7 +397,7 @@ struct PsStream {
 // and are never consumed), so a batch never spans two runs.  One lane per batch.
 template<int TK>
 __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nruns, const int tb, const int te,
-                                                unsigned* lt, unsigned* bt, const int entries)
+                                                unsigned* lt, unsigned* bt, const int entries, const int jbase = 0)
 {
     const int lane = threadIdx.x & 63;
     // the wave's first tile (padding address): uniform
@@ -417,7 +427,7 @@ __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nrun
                 cnt   = (b - t < PS_U) ? b - t : PS_U;
                 first = r.tile0 + off;
                 sel   = r.sel;
-                bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)j << 2)
+                bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)(j + jbase) << 2)
                      | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
                      | ((unsigned)cnt << 27);
             }
@@ -587,19 +597,19 @@ struct PsAttn {
         int t_last = t_beg + chunk - 1;
         t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
         t_last     = item ? t_last : t_beg;
+        // (a block's K request and V row together, four blocks at a time: requested in two passes, the 32 clamped row indices
+        // -- two registers each -- stay live from the first pass to the second, beside the 128 registers of V rows: the role
+        // spilled)
 #pragma unroll
         for (int i = 0; i < NBLK; i++) {
             const int j = (i / BPC) * PS_NW + c * BPC + i % BPC;
             int       t = t_beg + j * KPI + grp;
             t           = t < t_last ? t : t_last;
             ps_lds_dma16(kc + (size_t)t * DH + sub * 8, (unsigned)ps_rfl((int)(kbuf_lds + (unsigned)j * 1024u)));
-        }
-#pragma unroll
-        for (int i = 0; i < NBLK; i++) {
-            const int j = (i / BPC) * PS_NW + c * BPC + i % BPC;
-            int       t = t_beg + j * KPI + grp;
-            t           = t < t_last ? t : t_last;
             vrow(st, i) = *PS_G(u32x4, vc + (size_t)t * DH + sub * 8);
+            if (i % 4 == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         mask_bits = 0u;
         if (p.masked_tokens && sub == 0) {
@@ -693,20 +703,20 @@ struct PsAttn {
 #pragma unroll 1
         for (int u = 0; u < UK; u++) {  // (rolled: nothing of it can be hoisted above the V rows' long lives)
             const char* kb = kbuf + (size_t)(u * PS_NW + c * BPC) * 1024 + lane * 16;
-            f16x8       kv[BPC];
+            // (two key blocks in flight, pinned: with all four -- 16 registers of K beside the 128 of V rows -- the role spilled)
 #pragma unroll
             for (int q = 0; q < BPC; q++) {
-                kv[q] = *reinterpret_cast<const f16x8*>(kb + q * 1024);
-            }
-#pragma unroll
-            for (int q = 0; q < BPC; q++) {
-                const int t = t_beg + (u * PS_NW + c * BPC + q) * KPI + grp;
-                float     a = 0.f;
-                a           = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[q][0], kv[q][1]}, a);
-                a           = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[q][2], kv[q][3]}, a);
-                a           = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[q][4], kv[q][5]}, a);
-                a           = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[q][6], kv[q][7]}, a);
-                a           = group_sum_dpp<LPK>(a) * inv_sqrt_dh;
+                if (q % 2 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const f16x8 kq = *reinterpret_cast<const f16x8*>(kb + q * 1024);
+                const int   t = t_beg + (u * PS_NW + c * BPC + q) * KPI + grp;
+                float       a = 0.f;
+                a             = dot2(f16x2{qv[0], qv[1]}, f16x2{kq[0], kq[1]}, a);
+                a             = dot2(f16x2{qv[2], qv[3]}, f16x2{kq[2], kq[3]}, a);
+                a             = dot2(f16x2{qv[4], qv[5]}, f16x2{kq[4], kq[5]}, a);
+                a             = dot2(f16x2{qv[6], qv[7]}, f16x2{kq[6], kq[7]}, a);
+                a             = group_sum_dpp<LPK>(a) * inv_sqrt_dh;
                 const bool m = ((mask_bits >> (u * BPC + q)) & 1u) != 0u;
                 a            = m ? -INFINITY : a;
                 if (t < t_cached_end && sub == 0) {
@@ -756,6 +766,8 @@ struct PsAttn {
                     acc[e] = (sc[q] == -INFINITY) ? acc[e] : fmaf(pt, (float)vv[e], acc[e]);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // (one group of four key blocks at a time: interleaved, the groups' scores,
+                                                // weights and converted rows pile up beside the 128 registers of V rows)
         }
         if (owns_cur && c == 0) {
             const float pt = __expf(cur_p - m_c);
@@ -1072,17 +1084,17 @@ struct PsAttn {
 
 // split-0 workgroup of a (row, head): WAVE 0 alone sweeps the nsplit partials, merges them in split order and publishes
 // ctx as granules (one wave: no workgroup barrier, the other waves are already streaming the next stage)
-template<int DH>
+#ifndef PS_MERGE_NPER
+#define PS_MERGE_NPER 8
+#endif
+template<int DH, int NPER = PS_MERGE_NPER>
 __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem, u64* gall, const unsigned tag, int h,
                                               int b, const int tx)
 {
     const int ne = DH + 2, ns = p.plan.nsplit;
     const int ng = ns * ne;
     float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
-#ifndef PS_MERGE_NPER
-#define PS_MERGE_NPER 8
-#endif
-    ps_sweep<PS_MERGE_NPER>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
+    ps_sweep<NPER>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
     if (p.ts && tx == 0) {  // (debug stamp 15: partials swept)
         p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + 0) * 16 + 15] = wall_clock64();
     }
@@ -1149,20 +1161,37 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
             __hip_atomic_store((gu64*)(p.xw[r2] + plane + (size_t)p.tp_rank * slab + gi), ((u64)tag << 32) | (u64)pair, PS_RLX,
                                __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        // (all ranks' slots are requested together and re-read until every tag matches: one round trip when the partials are
+        // in, not tp dependent ones -- round 3 polled them one after the other: ~4 us of a TP = 8 layer)
         float lo = 0.f, hi = 0.f;
-        for (int r2 = 0; r2 < p.tp; r2++) {
-            const gu64* src = (const gu64*)(p.xw[p.tp_rank] + plane + (size_t)r2 * slab + gi);
-            u64         v;
-            int         sp2 = 0;
-            for (;;) {
-                v = __hip_atomic_load(src, PS_RLX, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned)(v >> 32) == tag || ps_give_up(sp2, p.err, 9)) {
-                    break;
+        u64   pv[PERSIST_MAX_TP];
+        int   sp2 = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int r2 = 0; r2 < PERSIST_MAX_TP; r2++) {
+                if (r2 < p.tp) {
+                    pv[r2] = __hip_atomic_load((const gu64*)(p.xw[p.tp_rank] + plane + (size_t)r2 * slab + gi), PS_RLX,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
-            lo += (float)bits_f16((unsigned)v);
-            hi += (float)bits_f16((unsigned)v >> 16);
+#pragma unroll
+            for (int r2 = 0; r2 < PERSIST_MAX_TP; r2++) {
+                if (r2 < p.tp) {
+                    ok &= ((unsigned)(pv[r2] >> 32) == tag);
+                }
+            }
+            if (ok || ps_give_up(sp2, p.err, 9)) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < PERSIST_MAX_TP; r2++) {  // rank order: the same sum on every rank
+            if (r2 < p.tp) {
+                lo += (float)bits_f16((unsigned)pv[r2]);
+                hi += (float)bits_f16((unsigned)pv[r2] >> 16);
+            }
         }
         const unsigned fin = (unsigned)f16_bits((f16)lo) | ((unsigned)f16_bits((f16)hi) << 16);
         if (last) {
