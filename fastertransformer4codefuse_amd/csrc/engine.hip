@@ -24,6 +24,7 @@
 #include "host_quant.h"
 #include "kernels.h"
 #include "layers.hip.h"
+#include "logger.h"
 
 using namespace ftcf;
 
@@ -41,10 +42,12 @@ static int guarded(F&& f)
     }
     catch (const ftcf::Error& e) {
         g_last_error = e.what();
+        FT_LOG_DEBUG(0, "call failed (%d): %s", e.code, e.what());  // (the binding raises it: not an ERROR line of its own)
         return e.code;
     }
     catch (const std::exception& e) {
         g_last_error = e.what();
+        FT_LOG_DEBUG(0, "call failed: %s", e.what());
         return FTCF_ERR_INVALID_ARG;
     }
 }
@@ -595,7 +598,7 @@ static void comm_ensure_window(ftcf_comm* c, size_t bytes, hipStream_t s)
         c->win.assign(c->world, nullptr);
         c->win_ok = false;
         if (c->rank == 0) {
-            fprintf(stderr, "[ftcf] tensor-parallel exchange windows unavailable: RCCL all-reduce per layer instead\n");
+            FT_LOG_WARNING(0, "tensor-parallel exchange windows unavailable: RCCL all-reduce per layer instead");
         }
         return;
     }
@@ -1682,6 +1685,13 @@ struct ftcf_gptneox {
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
         const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual && (dh == 64 || dh == 128);
         stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
+        if (ses.steps == 0) {  // once per request
+            FT_LOG_DEBUG(cfg.device, "decoder of this request: %s (rows %d, context %d%s)",
+                         pplan.ok ? (pplan.a4 ? "persistent layers, second form (attention branch on the control waves)"
+                                              : "persistent layers")
+                                  : (staged ? "per-stage launches" : "general path (batched GEMMs)"),
+                         B, s_max, pplan.ok ? (pplan.uk == 16 ? ", 512 keys per KV split" : ", 256 keys per KV split") : "");
+        }
         if (pplan.ok) {
             // all stages of every layer inside persistent launches (kernels_persist.hip); one launch per token when
             // there is no collective between the layers
@@ -2041,8 +2051,8 @@ struct ftcf_gptneox {
             // word across the ranks) and the engine stays off the persistent path.
             persist_failed = false;
             persist        = 0;
-            fprintf(stderr, "[ftcf] persistent decode kernel gave up on a hand-off: replaying the request on the "
-                            "per-stage path (this engine stays there)\n");
+            FT_LOG_WARNING(cfg.device, "persistent decode kernel gave up on a hand-off: replaying the request on the per-stage "
+                                       "path (this engine stays there)");
             begin(a);
             step(a.output_len);
             finish();
@@ -2079,6 +2089,8 @@ static std::vector<T> broadcast_arg(const T* p, int n, int B, T dflt, const char
 void ftcf_gptneox::begin(const ftcf_forward_args& a)
 {
     Range r("ftcf.begin");
+    FT_LOG_TRACE(cfg.device, "begin: batch %d x beam %d, max_input_len %d, output_len %d", a.batch_size, a.beam_width, a.max_input_len,
+                 a.output_len);
     const int B = a.batch_size * (a.beam_width > 0 ? a.beam_width : 1);  // rows
     const int S = a.max_input_len, out_len = a.output_len;
     FTCF_CHECK_ARG(a.batch_size >= 1 && S >= 1 && out_len >= 1, "batch_size, max_input_len and output_len must be >= 1");
@@ -2585,6 +2597,11 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         FTCF_CHECK_ARG(w->n_weights == 12 * L + 4, "weights must hold 12*L+4 tensors");
         FTCF_CHECK_ARG(L >= 1 && L <= 256, "num_layer must be in 1..256");
         FTCF_HIP_CHECK(hipSetDevice(cfg->device));
+        FT_LOG_INFO(cfg->device, "GptNeoX engine on device %d: %d layers, %d heads x %d, inter %d, vocab %d, rotary %d, %s%s, "
+                                 "tensor_para %d/%d, %s residual",
+                    cfg->device, L, cfg->head_num, cfg->size_per_head, cfg->inter_size, cfg->vocab_size, cfg->rotary_embedding_dim,
+                    cfg->dtype == FTCF_FP32 ? "fp32" : "fp16", cfg->int8_mode ? " + int8 weights" : "", cfg->tensor_para_rank, tp,
+                    cfg->use_gptj_residual ? "parallel" : "sequential");
         auto e   = std::make_unique<ftcf_gptneox>();
         e->cfg   = *cfg;
         e->L     = L;
@@ -3024,7 +3041,8 @@ struct ftcf_batcher {
     {
         FTCF_CHECK_ARG(repetition_penalty > 0.f, "repetition_penalty must be positive");
         FTCF_CHECK_ARG(stop_len >= 0 && stop_len <= STOP_LW && (stop_len == 0 || stop_words), "bad stop word list");
-        FTCF_CHECK_ARG((size_t)max_len * 8 <= 60 * 1024 || repetition_penalty == 1.f,
+        // (the decode step stages total_len = max_len + 2 history entries: the same bound as launch_dynamic_decode's)
+        FTCF_CHECK_ARG(((size_t)max_len + 2) * 8 <= 60 * 1024 || repetition_penalty == 1.f,
                        "max_seq_len too large for the repetition-penalty staging buffer");
         FTCF_CHECK_ARG(ids && n >= 1 && max_new >= 1, "empty prompt or max_new_tokens < 1");
         FTCF_CHECK_ARG(n + max_new <= max_len && n <= max_prompt, "prompt + max_new_tokens exceed the batcher's max_seq_len");
@@ -3069,6 +3087,17 @@ struct ftcf_batcher {
         ev.push_back(x);
         if (on_token) {
             on_token(on_token_user, x.id, x.token, x.finished);
+        }
+    }
+
+    // the first tokens of an admission reach the callback only when the admission is known to have succeeded: a failed one is
+    // rolled back and retried, and a streaming consumer must not see its first tokens twice
+    void fire(const std::vector<Event>& ev, const size_t from)
+    {
+        if (on_token) {
+            for (size_t i = from; i < ev.size(); i++) {
+                on_token(on_token_user, ev[i].id, ev[i].token, ev[i].finished);
+            }
         }
     }
 
@@ -3208,7 +3237,7 @@ struct ftcf_batcher {
             s.generated = 1;
             s.max_new = r.max_new;
             const int done = (first == e->cfg.end_id || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
-            emit(ev, Event{r.id, first, done});
+            ev.push_back(Event{r.id, first, done});  // (the token callback fires when the admission has succeeded: step())
             if (done) {
                 const uint8_t one8 = 1;
                 FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
@@ -3480,6 +3509,7 @@ struct ftcf_batcher {
                 }
                 ev.insert(ev.end(), between.begin(), between.end());
                 ev.insert(ev.end(), own.begin(), own.end());
+                fire(own, 0);
                 sis.erase(sis.begin());
                 rs.erase(rs.begin());
             }
@@ -3505,6 +3535,7 @@ struct ftcf_batcher {
                 ev.resize(ev0);
                 throw;
             }
+            fire(ev, ev0);
         }
         refresh_host_flags();
     }

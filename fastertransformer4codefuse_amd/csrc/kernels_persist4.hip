@@ -13,6 +13,9 @@ static size_t ps4_smem_bytes(int H, int xs_halves, int r1, int r3, int dh, int s
 
 PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8)
 {
+    // share of a control wave in the first stream (FFN1 tiles it streams before it turns to the attention), in 1/16 of a
+    // streamer wave's: the control waves are idle until q/k/v are complete (~40 % of the stream)
+    static const int cs1_env = getenv("FTCF_PERSIST4_CS1") ? atoi(getenv("FTCF_PERSIST4_CS1")) : 8;
     static const int on = getenv("FTCF_PERSIST_A4") ? atoi(getenv("FTCF_PERSIST_A4")) : 1;
     PersistPlan      pl = base;
     if (!on || !pl.ok || B != 1 || pl.uk != PS_UK || pl.a3 || pl.p3l) {
@@ -28,15 +31,16 @@ PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il,
         }
         pl.nsplit = std::min(pl.nsplit, std::max(ns, 2));
     }
+    pl.cs1 = std::max(0, std::min(16, cs1_env));
     int e1 = 0, r1 = 0, r3 = 0, span = 0;
     for (int b = 0; b < NB; b++) {
         const int qb = (b + pl.qrot) % NB;
         const int nq = (int)((long)NT0 * (qb + 1) / NB) - (int)((long)NT0 * qb / NB);
         const int nf = (int)((long)NF * (b + 1) / NB) - (int)((long)NF * b / NB);
         r1           = std::max(r1, nq + nf);
-        for (int i = 0; i < PS4_NS; i++) {
+        for (int w = 0; w < PS_NW; w++) {
             int eq;
-            e1 = std::max(e1, ps4_p1_entries(nq, nf, KT, i, eq));
+            e1 = std::max(e1, ps4_p1_entries(nq, nf, KT, pl.cs1, w, eq));
         }
         const int rB0 = (int)((long)NG * pl.PB * b / NB), rB1 = (int)((long)NG * pl.PB * (b + 1) / NB);
         const int rA0 = (int)((long)NG * pl.PA * b / NB), rA1 = (int)((long)NG * pl.PA * (b + 1) / NB);

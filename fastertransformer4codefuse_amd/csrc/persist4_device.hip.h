@@ -29,17 +29,25 @@ constexpr int PS4_NS = PS_NW - PS_NC;  // streamer waves
 #ifndef PS4_COND_TAIL
 #define PS4_COND_TAIL 1  // the streamer waves skip the next layer's set-up (and its 32 KiB of prefetch per wave) after the last layer
 #endif
-#ifndef PS4_KV_EARLY
-#define PS4_KV_EARLY 0   // 1: the control waves request the next layer's K/V rows before they gather x' (else after the LayerNorm)
-#endif
 
-// The P1 share of streamer wave i (0..PS4_NS-1) of a workgroup with Tq QKV tiles and Tf FFN1 tiles: a slice of the QKV
-// runs FIRST, then a slice of the FFN1 runs sized so that the waves' totals balance; slices start on batch boundaries.
-__host__ __device__ inline void ps4_p1_ranges(const int Tq, const int Tf, const int i, int& qb, int& qe, int& fb, int& fe)
+// The P1 shares of a workgroup with Tq QKV tiles and Tf FFN1 tiles.  Streamer wave i (0..PS4_NS-1): a slice of the QKV runs
+// FIRST, then a slice of the FFN1 runs sized so that the waves' totals balance.  The control waves are idle from the
+// LayerNorm until q/k/v are complete: they stream cs/16 of a streamer wave's share from the END of the FFN1 runs first (their
+// register batches hold the V rows only afterwards).  Slices start on batch boundaries.
+__host__ __device__ inline int ps4_ctrl_tiles(const int Tq, const int Tf, const int cs)
 {
+    const long W = (long)PS4_NS * 16 + (long)PS_NC * cs;
+    long       t = (long)(Tq + Tf) * cs / W / PS_U * PS_U;
+    const long cap = (long)Tf / PS_NC / PS_U * PS_U;
+    return (int)(t < cap ? t : cap);
+}
+__host__ __device__ inline void ps4_p1_ranges(const int Tq, const int Tf_all, const int cs, const int i, int& qb, int& qe, int& fb,
+                                              int& fe)
+{
+    const int Tf = Tf_all - PS_NC * ps4_ctrl_tiles(Tq, Tf_all, cs);  // the streamer waves' part of FFN1
     auto al = [](long v) { return (int)(v / PS_U * PS_U); };
     auto qend = [&](int k) { return k >= PS4_NS ? Tq : al((long)Tq * k / PS4_NS); };
-    auto fend = [&](int k) {  // FFN1 tiles owned by waves 0..k-1
+    auto fend = [&](int k) {  // FFN1 tiles owned by streamer waves 0..k-1
         if (k >= PS4_NS) {
             return Tf;
         }
@@ -58,13 +66,26 @@ __host__ __device__ inline void ps4_p1_ranges(const int Tq, const int Tf, const 
         fe = fb;
     }
 }
-// table entries of that share (every run piece padded to whole batches), KT tiles per run
-__host__ __device__ inline int ps4_p1_entries(const int nq, const int nf, const int KT, const int i, int& eq)
+// control wave c (0..PS_NC-1): [fb, fe) of the FFN1 runs
+__host__ __device__ inline void ps4_p1_ctrl_range(const int Tq, const int Tf_all, const int cs, const int c, int& fb, int& fe)
 {
-    int qb, qe, fb, fe;
-    ps4_p1_ranges(nq * KT, nf * KT, i, qb, qe, fb, fe);
+    const int tc = ps4_ctrl_tiles(Tq, Tf_all, cs);
+    fb           = Tf_all - (PS_NC - c) * tc;
+    fe           = fb + tc;
+}
+// table entries of a wave's share (every run piece padded to whole batches), KT tiles per run; w: wave of the workgroup
+__host__ __device__ inline int ps4_p1_entries(const int nq, const int nf, const int KT, const int cs, const int w, int& eq)
+{
     auto nt = [&](int) { return KT; };
-    eq      = ps_wave_entries(nq, nt, qb, qe);
+    if (w < PS_NC) {
+        int fb, fe;
+        ps4_p1_ctrl_range(nq * KT, nf * KT, cs, w, fb, fe);
+        eq = 0;
+        return ps_wave_entries(nf, nt, fb, fe);
+    }
+    int qb, qe, fb, fe;
+    ps4_p1_ranges(nq * KT, nf * KT, cs, w - PS_NC, qb, qe, fb, fe);
+    eq = ps_wave_entries(nq, nt, qb, qe);
     return eq + ps_wave_entries(nf, nt, fb, fe);
 }
 
@@ -167,7 +188,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
     else {
         for (int i = threadIdx.x; i < 64; i += PS_NT) {
             s.misc[i] = 0;  // [0] merge groups, [32] ctx arrivals, [33] control pair, [34] streamer barrier, [35] control
-        }                   // barrier inside the attention, [36] QKV flushes, [37] streamer waves without QKV tiles
+        }                   // barrier inside the attention, [36] QKV flushes, [37] streamer waves without QKV tiles, [38] control waves' FFN1 share flushed
         __syncthreads();
         if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
             const int  j   = threadIdx.x;
@@ -247,18 +268,23 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
             T3          = ps_rfl(T3);
             const int w = ps_rfl(wid);
             int       nrot1 = 1;
-            if (w >= PS_NC) {  // P1: streamer waves only -- their QKV slice, then their FFN1 slice
-                int a, b, c, d;
-                ps4_p1_ranges(nq * KT, nf * KT, w - PS_NC, a, b, c, d);
+            {   // P1: a streamer wave's QKV slice, then its FFN1 slice; a control wave's FFN1 slice
+                int a = 0, b = 0, c, d;
+                if (w >= PS_NC) {
+                    ps4_p1_ranges(nq * KT, nf * KT, p.plan.cs1, w - PS_NC, a, b, c, d);
+                }
+                else {
+                    ps4_p1_ctrl_range(nq * KT, nf * KT, p.plan.cs1, w, c, d);
+                }
                 int       eq;
-                const int ent = ps4_p1_entries(nq, nf, KT, w - PS_NC, eq);
+                const int ent = ps4_p1_entries(nq, nf, KT, p.plan.cs1, w, eq);
                 nrot1         = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
                 nrot1         = nrot1 < 1 ? 1 : nrot1;
                 unsigned* lt  = s.lt1 + (size_t)w * E1;
                 unsigned* bt  = s.bt1 + (size_t)w * (E1 / PS_U);
                 ps_build_tables<TK>(s.rt1, nq, a, b, lt, bt, eq, 0);
                 ps_build_tables<TK>(s.rt1 + nq, nf, c, d, lt + eq, bt + eq / PS_U, nrot1 * PS_U * PS_NBUF - eq, nq);
-                if ((threadIdx.x & 63) == 0) {
+                if (w >= PS_NC && (threadIdx.x & 63) == 0) {
                     if (eq > 0) {
                         bt[eq / PS_U - 1] |= PS_BT_SIGNAL;  // (the builder's lanes wrote it: same wave, DS order)
                     }
@@ -419,18 +445,16 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
                     s.rsc[tid] = r_sc1;
                 }
             }
-            if constexpr (!CTRL) {
-                for (int i = tid & 63; i < nruns1 * 16; i += 64) {  // (a wave zeroes the slots it flushes itself)
-                    s.part[((size_t)(i / 16) * PS_NW + (tid >> 6)) * 16 + i % 16] = 0.f;
-                }
+            for (int i = tid & 63; i < nruns1 * 16; i += 64) {  // (a wave zeroes the slots it flushes itself)
+                s.part[((size_t)(i / 16) * PS_NW + (tid >> 6)) * 16 + i % 16] = 0.f;
             }
             load_p1_consts(l);
+            sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
+            sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
+            st.bind(sg1, s.rsc, s.xs, s.part, tid);
+            st.sig = &s.misc[36];
             if constexpr (!CTRL) {
-                sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
-                sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
-                st.bind(sg1, s.rsc, s.xs, s.part, tid);
-                st.sig = &s.misc[36];
-                st.prime();
+                st.prime();  // (the control waves request theirs after the LayerNorm: the gather's polls would return behind it)
             }
         };
         auto setup_p3 = [&](const int l) {
@@ -464,9 +488,6 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
             stamp(l, 0);
             // =========================== S0: layer input -> xraw (control waves) =================================
             if constexpr (CTRL) {
-                if constexpr (PS4_KV_EARLY) {
-                    at.issue_ctrl(p, lw, a_h, a_b, a_sp, tid, st, kbuf_lds, has_item);
-                }
                 if (l == p.l_begin) {
                     for (int i = tid * 8; i < H; i += PS_NC * 64 * 8) {
                         *reinterpret_cast<f16x8*>(s.xraw + i) = *reinterpret_cast<const f16x8*>(p.x_in + i);
@@ -540,13 +561,24 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
                 st.template run<false>();
                 stamp(l, 3);
                 strm_barrier();  // every streamer wave has flushed its FFN1 runs (and is done with LN2(x) in LDS)
+                {   // (the control waves finished their share of FFN1 long ago: they bump this counter behind it)
+                    const int want = (li + 1) * PS_NC;
+                    for (int spins = 0; ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[38]) < want;) {
+                        if (++spins > (PS_SPIN << 6)) {
+                            __hip_atomic_store(p.err, 14, PS_RLX, PS_AGT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
                 {   // mid = gelu(y + b) of this workgroup's FFN1 columns -> granules
                     const int idx = tid - PS_NC * 64;
                     if (idx < nf * 16) {
                         const int j = nq + idx / 16, c = idx & 15;
                         float     v = 0.f;
 #pragma unroll
-                        for (int w = PS_NC; w < PS_NW; w++) {
+                        for (int w = 0; w < PS_NW; w++) {
                             v += s.part[((size_t)j * PS_NW + w) * 16 + c];
                         }
                         f16 o;
@@ -586,10 +618,15 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
                 stamp(l, 10);
             }
             else {
-                // =========================== control waves: the attention branch ==================================
-                if constexpr (!PS4_KV_EARLY) {
-                    at.issue_ctrl(p, lw, a_h, a_b, a_sp, tid, st, kbuf_lds, has_item);
+                // =========================== control waves: a share of FFN1, then the attention branch ============
+                st.prime_lo();
+                st.template run<true>();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) {
+                    atomicAdd(&s.misc[38], 1);  // this wave's FFN1 partial sums are flushed
                 }
+                stamp(l, 8);
+                at.issue_ctrl(p, lw, a_h, a_b, a_sp, tid, st, kbuf_lds, has_item);
                 // q/k/v of this workgroup's QKV columns: complete when every streamer wave has flushed its QKV slice
                 {
                     const int want = (li + 1) * (PS4_NS - n_noq);

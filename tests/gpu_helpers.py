@@ -12,7 +12,7 @@ def dev(a, dtype=torch.float16):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
 
 
-def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True, dtype=torch.float16):
+def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True, dtype=torch.float16, op_class=None):
     """cfg: dict like tests.helpers ; w: reference-order list of float32 numpy arrays -- the full TP=1 layout, or with
     tp > 1 the shard of `rank` (tests.helpers.shard_weights)."""
     L = cfg["num_layer"]
@@ -38,7 +38,8 @@ def make_op(cfg, w, int8_mode=0, tp=1, rank=0, comm=None, use_gptj_residual=True
                 dev(w[12 * L + 3].reshape(V, H), dtype)]
     if not int8_mode:
         int8_w, scales = [], []
-    op = GptNeoXOp(comm, rank, cfg["head_num"], cfg["size_per_head"], I, L, V, cfg["rotary_dim"], cfg.get("start_id", 0),
+    # (op_class: the compiled libth_gptneox.GptNeoXOp instead of the ctypes one -- tests/test_gpu_th_modules.py)
+    op = (op_class or GptNeoXOp)(comm, rank, cfg["head_num"], cfg["size_per_head"], I, L, V, cfg["rotary_dim"], cfg.get("start_id", 0),
                    cfg["end_id"], tp, 1, int8_mode, 1024, use_gptj_residual, weights, int8_w, scales)
     return op
 

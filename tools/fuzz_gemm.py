@@ -17,17 +17,16 @@ from fastertransformer4codefuse_amd.gptneox_op import symmetric_quantize_last_ax
 from oracle import oracle as orc  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=300)
-    ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+def run(seconds=300.0, seed=0, max_cases=None):
+    """random cases until `seconds` have passed or `max_cases` have run (tests/test_gpu_headline_shapes.py runs a fixed-seed
+    slice inside the -m gpu suite); returns (cases, worst error as a fraction of the tolerance)"""
+    a = argparse.Namespace(seconds=seconds, seed=seed)
     capi.require_gpu()
     L = capi.lib()
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     rng = np.random.RandomState(a.seed)
     t0, cases, worst = time.time(), 0, 0.0
-    while time.time() - t0 < a.seconds:
+    while time.time() - t0 < a.seconds and (max_cases is None or cases < max_cases):
         n = 16 * int(rng.randint(1, 129))
         k = 64 * int(rng.choice([1, 2, 3, 4, 5, 8, 9, 10, 16, 17, 20, 33, 36, 40, 64, 80]))
         int8 = bool(rng.randint(0, 2))
@@ -70,6 +69,16 @@ def main():
             worst = max(worst, float(err.max()))
             assert err.max() <= 1.0, ("mismatch", m, n, k, int8, act_kind, use_bias, float(err.max()))
             cases += 1
+    return cases, worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    t0 = time.time()
+    cases, worst = run(a.seconds, a.seed)
     print(f"fuzz_gemm: {cases} cases in {time.time() - t0:.0f} s, worst error {worst:.3f} of the tolerance (rtol 2e-3, atol 2e-3)")
 
 
