@@ -5,6 +5,16 @@
 // through include/ftcf.h and writes the token ids to `out`, one row per request.
 //
 //   gptneox_example <config.ini> [--start_ids <file.csv>] [--out <file>]
+//                   [--rendezvous <dir>] [--exchange rccl|host] [--rank r --world n] [--device d]
+//
+// TENSOR PARALLEL (examples/cpp/gptneox/gptneox_example.cc:399-411 runs under mpirun, one rank per GPU): start
+// `tensor_para_size` copies of this program, e.g. `torchrun --nproc-per-node N ... gptneox_example cfg.ini --rendezvous /tmp/r`
+// or `mpirun -n N` -- rank and world size come from RANK / WORLD_SIZE (torchrun), OMPI_COMM_WORLD_RANK / _SIZE (mpirun) or the
+// flags; the device from LOCAL_RANK, else rank % devices.  The ranks meet in a DIRECTORY (no MPI, no torch in this program):
+// every exchange between them is an all-gather of small files there -- the RCCL unique id (nccl_utils.cc ftNcclInitialize's
+// MPI_Bcast), or, with `--exchange host` / FTCF_TP_EXCHANGE=host, everything a host-exchange communicator needs
+// (include/ftcf.h ftcf_comm_init_host_exchange: lets the ranks share one device -- how tests/test_gpu_cli.py runs TP = 2 on a
+// one-GPU box).  Rank r loads the converter's `.r.bin` shards; rank 0 writes `out`.
 //
 // ini (same keys as examples/cpp/gptneox/gptneox_config.ini):
 //   [ft_instance_hyperparameter]  model_name, model_dir, tensor_para_size (1 here: one process, one GPU), int8_mode
@@ -13,9 +23,12 @@
 //   [<model_name>]                head_num, size_per_head, inter_size, vocab_size, decoder_layers, rotary_embedding,
 //                                 start_id, end_id, use_gptj_residual, weight_data_type (fp32 | fp16)
 //   (the model section may instead live in <model_dir>/config.ini as [gptneox] with num_layer, the converter's output)
-// Single process: tensor_para_size must be 1 (the multi-rank launcher of the reference is mpirun; ours is torchrun +
-// the Python harness).
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <thread>
 
 #include <cstdint>
 #include <cstdio>
@@ -42,6 +55,74 @@ std::string trim(const std::string& s)
     }
     const size_t b = s.find_last_not_of(" \t\r\n");
     return s.substr(a, b - a + 1);
+}
+
+// ---- the ranks' meeting place: an all-gather of small files in a shared directory ---------------------------------
+struct Rendezvous {
+    std::string dir;
+    int         rank = 0, world = 1;
+    long        seq = 0;
+    double      timeout_s = 600.0;
+
+    std::string name(long k, int r) const { return dir + "/ag." + std::to_string(k) + "." + std::to_string(r); }
+    // recv[r * bytes ..] = rank r's send; 0 on success (the signature of ftcf_host_allgather_fn)
+    static int allgather(void* user, const void* send, void* recv, size_t bytes)
+    {
+        auto* self = static_cast<Rendezvous*>(user);
+        try {
+            const long k = self->seq++;
+            if (k >= 2) {  // (everybody has read call k - 2: a rank enters call k only after reading all of k - 1)
+                (void)unlink(self->name(k - 2, self->rank).c_str());
+            }
+            const std::string mine = self->name(k, self->rank), tmp = mine + ".tmp";
+            {
+                std::ofstream f(tmp, std::ios::binary);
+                f.write(static_cast<const char*>(send), (std::streamsize)bytes);
+                if (!f.good()) {
+                    throw std::runtime_error("cannot write " + tmp);
+                }
+            }
+            if (rename(tmp.c_str(), mine.c_str()) != 0) {
+                throw std::runtime_error("cannot publish " + mine);
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < self->world; r++) {
+                const std::string fn = self->name(k, r);
+                for (;;) {
+                    struct stat st;
+                    if (stat(fn.c_str(), &st) == 0 && (size_t)st.st_size == bytes) {
+                        std::ifstream f(fn, std::ios::binary);
+                        f.read(static_cast<char*>(recv) + (size_t)r * bytes, (std::streamsize)bytes);
+                        if (f.good()) {
+                            break;
+                        }
+                    }
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > self->timeout_s) {
+                        throw std::runtime_error("rank " + std::to_string(r) + " did not arrive at " + fn);
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+            }
+            return 0;
+        }
+        catch (const std::exception& e) {
+            fprintf(stderr, "[ERROR] rendezvous: %s\n", e.what());
+            return 1;
+        }
+    }
+};
+
+int env_int(const char* a, const char* b, int dflt)
+{
+    if (const char* v = getenv(a)) {
+        return atoi(v);
+    }
+    if (b) {
+        if (const char* v = getenv(b)) {
+            return atoi(v);
+        }
+    }
+    return dflt;
 }
 
 Ini read_ini(const std::string& path)
@@ -195,16 +276,36 @@ int main(int argc, char** argv)
 {
     try {
         if (argc < 2) {
-            fprintf(stderr, "usage: %s <config.ini> [--start_ids <file.csv>] [--out <file>]\n", argv[0]);
+            fprintf(stderr, "usage: %s <config.ini> [--start_ids <file.csv>] [--out <file>] [--rendezvous <dir>] [--exchange rccl|host] "
+                            "[--rank r --world n] [--device d]\n", argv[0]);
             return 2;
         }
         std::string ini_path = argv[1], ids_path = "start_ids.csv", out_path = "out";
+        std::string rdv_dir = getenv("FTCF_RENDEZVOUS") ? getenv("FTCF_RENDEZVOUS") : "";
+        std::string exchange = (getenv("FTCF_TP_EXCHANGE") && !strcmp(getenv("FTCF_TP_EXCHANGE"), "host")) ? "host" : "rccl";
+        int rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", 0), world = env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1);
+        int device_flag = -1;
         for (int i = 2; i + 1 < argc; i += 2) {
             if (!strcmp(argv[i], "--start_ids")) {
                 ids_path = argv[i + 1];
             }
             else if (!strcmp(argv[i], "--out")) {
                 out_path = argv[i + 1];
+            }
+            else if (!strcmp(argv[i], "--rendezvous")) {
+                rdv_dir = argv[i + 1];
+            }
+            else if (!strcmp(argv[i], "--exchange")) {
+                exchange = argv[i + 1];
+            }
+            else if (!strcmp(argv[i], "--rank")) {
+                rank = atoi(argv[i + 1]);
+            }
+            else if (!strcmp(argv[i], "--world")) {
+                world = atoi(argv[i + 1]);
+            }
+            else if (!strcmp(argv[i], "--device")) {
+                device_flag = atoi(argv[i + 1]);
             }
         }
         const Ini         ini   = read_ini(ini_path);
@@ -213,8 +314,15 @@ int main(int argc, char** argv)
         const std::string mdir  = get(ini, inst, "model_dir");
         const int         tp    = std::stoi(get(ini, inst, "tensor_para_size", "1"));
         const int         int8  = std::stoi(get(ini, inst, "int8_mode", "0"));
-        if (tp != 1 || std::stoi(get(ini, inst, "pipeline_para_size", "1")) != 1) {
-            throw std::runtime_error("this single-process example runs tensor_para_size = pipeline_para_size = 1");
+        if (std::stoi(get(ini, inst, "pipeline_para_size", "1")) != 1) {
+            throw std::runtime_error("pipeline_para_size must be 1");
+        }
+        if (tp != world || rank < 0 || rank >= world) {
+            throw std::runtime_error("tensor_para_size = " + std::to_string(tp) + " needs that many ranks (this is rank "
+                                     + std::to_string(rank) + " of " + std::to_string(world) + ": torchrun / mpirun / --rank --world)");
+        }
+        if (tp > 1 && rdv_dir.empty()) {
+            throw std::runtime_error("tensor_para_size > 1 needs --rendezvous <dir> (or FTCF_RENDEZVOUS): where the ranks meet");
         }
         // model hyper-parameters: [<model_name>] of the main ini, else [gptneox] of <model_dir>/config.ini
         Ini         mini = ini;
@@ -281,7 +389,12 @@ int main(int argc, char** argv)
             }
         }
 
-        hip_check(hipSetDevice(0), "hipSetDevice");
+        int ndev = 0;
+        hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+        const int device = device_flag >= 0 ? device_flag : env_int("LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", rank) % (ndev > 0 ? ndev : 1);
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        const int  hl = H / tp, il = I / tp;  // this rank's shard (huggingface_convert.py:35-81: QKV / FFN1 columns, out-proj / FFN2 rows)
+        const std::string rk = "." + std::to_string(rank);
         // ---- weights in the order of GptNeoXOp.h:121-174 ----
         DeviceBlobs              dev;
         std::vector<const void*> w((size_t)12 * L + 4, nullptr), q, sc;
@@ -290,10 +403,10 @@ int main(int argc, char** argv)
                                         "mlp.dense_h_to_4h.weight.0", "mlp.dense_h_to_4h.bias.0", "mlp.dense_4h_to_h.weight.0",
                                         "mlp.dense_4h_to_h.bias", "post_attention_layernorm.bias",
                                         "post_attention_layernorm.weight"};
-        const size_t count[12] = {(size_t)H, (size_t)H, (size_t)H * 3 * H, (size_t)3 * H, (size_t)H * H, (size_t)H,
-                                  (size_t)H * I, (size_t)I, (size_t)I * H, (size_t)H, (size_t)H, (size_t)H};
-        const size_t kdim[12]  = {0, 0, (size_t)H, 0, (size_t)H, 0, (size_t)H, 0, (size_t)I, 0, 0, 0};
-        const size_t ndim[12]  = {0, 0, (size_t)3 * H, 0, (size_t)H, 0, (size_t)I, 0, (size_t)H, 0, 0, 0};
+        const size_t count[12] = {(size_t)H, (size_t)H, (size_t)H * 3 * hl, (size_t)3 * hl, (size_t)hl * H, (size_t)H,
+                                  (size_t)H * il, (size_t)il, (size_t)il * H, (size_t)H, (size_t)H, (size_t)H};
+        const size_t kdim[12]  = {0, 0, (size_t)H, 0, (size_t)hl, 0, (size_t)H, 0, (size_t)il, 0, 0, 0};
+        const size_t ndim[12]  = {0, 0, (size_t)3 * hl, 0, (size_t)H, 0, (size_t)il, 0, (size_t)H, 0, 0, 0};
         if (int8) {
             q.assign((size_t)4 * L, nullptr);
             sc.assign((size_t)4 * L, nullptr);
@@ -305,8 +418,11 @@ int main(int argc, char** argv)
                     continue;  // empty slot (GptNeoXOp.h:137)
                 }
                 std::string fn = names[g];
+                if (fn.size() > 2 && fn.compare(fn.size() - 2, 2, ".0") == 0) {
+                    fn = fn.substr(0, fn.size() - 2) + rk;  // the converter's per-rank files
+                }
                 if (g == 9 && gptj) {
-                    fn = "mlp.attention.bias.sum";  // attn-out bias + ffn2 bias, written by the converter
+                    fn = "mlp.attention.bias.sum";  // attn-out bias + ffn2 bias (already divided by TP), written by the converter
                 }
                 const bool kernel = kdim[g] != 0;
                 if (kernel && int8) {
@@ -338,15 +454,37 @@ int main(int argc, char** argv)
         cfg.rotary_embedding_dim = rot;
         cfg.start_id = start_id;
         cfg.end_id = end_id;
-        cfg.tensor_para_size = 1;
-        cfg.tensor_para_rank = 0;
+        // ---- tensor-parallel communicator (nccl_utils.cc ftNcclInitialize over MPI in the reference) ----
+        Rendezvous  rdv;
+        ftcf_comm_t comm = nullptr;
+        if (tp > 1) {
+            rdv.dir   = rdv_dir;
+            rdv.rank  = rank;
+            rdv.world = world;
+            (void)mkdir(rdv_dir.c_str(), 0777);
+            if (exchange == "host") {
+                ftcf_check(ftcf_comm_init_host_exchange(world, rank, device, &Rendezvous::allgather, &rdv, &comm), "ftcf_comm_init_host_exchange");
+            }
+            else {
+                std::vector<uint8_t> id(FTCF_UNIQUE_ID_BYTES, 0), all((size_t)FTCF_UNIQUE_ID_BYTES * world);
+                if (rank == 0) {
+                    ftcf_check(ftcf_comm_get_unique_id(id.data()), "ftcf_comm_get_unique_id");
+                }
+                if (Rendezvous::allgather(&rdv, id.data(), all.data(), id.size()) != 0) {
+                    throw std::runtime_error("rendezvous failed");
+                }
+                ftcf_check(ftcf_comm_init(all.data(), world, rank, device, &comm), "ftcf_comm_init");  // rank 0's id
+            }
+        }
+        cfg.tensor_para_size = tp;
+        cfg.tensor_para_rank = rank;
         cfg.pipeline_para_size = 1;
         cfg.int8_mode = int8;
         cfg.dtype = FTCF_FP16;
         cfg.use_gptj_residual = gptj ? 1 : 0;
-        cfg.device = 0;
+        cfg.device = device;
         cfg.stream = stream;
-        cfg.comm = nullptr;
+        cfg.comm = comm;
         cfg.use_hip_graph = 1;
         ftcf_gptneox_weights ww{};
         ww.weights = w.data();
@@ -397,17 +535,22 @@ int main(int argc, char** argv)
 
         std::vector<int> out((size_t)B * beam * total);
         hip_check(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost), "hipMemcpy");
-        std::ofstream of(out_path);
-        for (size_t i = 0; i < out.size(); i++) {  // gptneox_example.cc:415-440: one row per (request, beam)
-            of << out[i] << " ";
-            if ((i + 1) % (size_t)total == 0) {
-                of << std::endl;
+        if (rank == 0) {  // gptneox_example.cc:411-440: rank 0 writes, one row per (request, beam)
+            std::ofstream of(out_path);
+            for (size_t i = 0; i < out.size(); i++) {
+                of << out[i] << " ";
+                if ((i + 1) % (size_t)total == 0) {
+                    of << std::endl;
+                }
             }
         }
         printf("[INFO] request_batch_size %d beam_width %d head_num %d size_per_head %d total_output_len %d decoder_layers %d "
                "vocab_size %d FT-CPP-decoding-beamsearch-time %.2f ms\n",
                B, beam, nh, dh, total, L, V, ms);
         ftcf_check(ftcf_gptneox_destroy(eng), "destroy");
+        if (comm) {
+            ftcf_check(ftcf_comm_destroy(comm), "comm destroy");
+        }
         return 0;
     }
     catch (const std::exception& e) {

@@ -1082,6 +1082,9 @@ struct ftcf_gptneox {
         if (ses.graph_exec) {
             (void)hipGraphExecDestroy(ses.graph_exec);
         }
+        if (ses.graph_exec_n) {
+            (void)hipGraphExecDestroy(ses.graph_exec_n);
+        }
         if (tp_scratch) {
             (void)hipFree(tp_scratch);
         }
@@ -1193,9 +1196,11 @@ struct ftcf_gptneox {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
                 pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, tpn == 1);
-                // second form of the kernel (persist4_device.hip.h: the attention branch on the control waves under the FFN
-                // streams): one row, <= 256 keys per KV split, up to FTCF_PERSIST_A4_MAX_TP ranks (finer shards are hand-off
-                // bound, not stream bound, and keep the eight-wave attention of the first form)
+#ifdef PS_EXPERIMENTS
+                // (experiment builds only, `make EXPERIMENTS=1`; FTCF_PERSIST_A4=1 selects it)  Second form of the kernel
+                // (persist4_device.hip.h: the attention branch on the control waves under the FFN streams): built, parity green,
+                // measured 1-2.5 % SLOWER than the first form at TP = 1 (profiles/r04_notes.md) -- six streaming waves carry a
+                // lower rate than eight, and what the removed hand-off window gains is lost there
                 static const int a4_max_tp = getenv("FTCF_PERSIST_A4_MAX_TP") ? atoi(getenv("FTCF_PERSIST_A4_MAX_TP")) : 2;
                 static const int a4_cs3 = getenv("FTCF_PERSIST4_CS3") ? atoi(getenv("FTCF_PERSIST4_CS3")) : 12;
                 if (pplan.ok && B == 1 && tpn <= a4_max_tp) {
@@ -1206,6 +1211,7 @@ struct ftcf_gptneox {
                         pplan = p4;
                     }
                 }
+#endif
                 const bool resident = !pplan.ok ? false
                                       : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
                                                  : persist_resident(pplan, int8, B, dh, num_cu, tpn);
@@ -1656,6 +1662,7 @@ struct ftcf_gptneox {
         }
         pp.plan = pplan;
         pp.d_step = &state->step;
+        pp.d_stop = &state->all_finished;
         pp.seq_len = seq_len;
         pp.pad_count = pad_count;
         pp.masked_tokens = masked;
@@ -1685,7 +1692,8 @@ struct ftcf_gptneox {
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
         const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual && (dh == 64 || dh == 128);
         stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
-        if (ses.steps == 0) {  // once per request
+        if (!ses.path_logged) {  // once per request
+            ses.path_logged = true;
             FT_LOG_DEBUG(cfg.device, "decoder of this request: %s (rows %d, context %d%s)",
                          pplan.ok ? (pplan.a4 ? "persistent layers, second form (attention branch on the control waves)"
                                               : "persistent layers")
@@ -2002,6 +2010,8 @@ struct ftcf_gptneox {
         bool              all_finished = false;
         hipEvent_t        e0 = nullptr, e1 = nullptr;
         hipGraphExec_t    graph_exec = nullptr;
+        bool              path_logged = false;  // the decoder of this request has been named in the log (FT_LOG_LEVEL=DEBUG)
+        hipGraphExec_t    graph_exec_n = nullptr;  // graph_tokens consecutive tokens in one graph (persistent path, no callback)
     } ses;
     bool use_graph = true;
     // drops whatever an unfinished request left behind: the captured graph holds the OLD arena pointers, shapes and sampling
@@ -2015,6 +2025,10 @@ struct ftcf_gptneox {
         if (ses.graph_exec) {
             (void)hipGraphExecDestroy(ses.graph_exec);
             ses.graph_exec = nullptr;
+        }
+        if (ses.graph_exec_n) {
+            (void)hipGraphExecDestroy(ses.graph_exec_n);
+            ses.graph_exec_n = nullptr;
         }
         if (ses.e0) {
             event_pool.push_back(ses.e0);
@@ -2215,6 +2229,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
             PersistParams pp = persist_params(B, s_max);
             pp.l_begin = pp.l_end = 0;
             pp.tab_mode = 1;
+            pp.d_stop   = nullptr;  // (the flag still holds the previous request's outcome here)
             launch_decode_persistent(pp, int8, stream);
             ps_tab_ready = true;
         }
@@ -2340,6 +2355,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     ses.s_max = s_max;
     ses.next_step = S;
     ses.steps = 0;
+    ses.path_logged = false;
     ses.all_finished = false;
     ses.e0 = e0;
     ses.e1 = e1;
@@ -2359,7 +2375,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
     }
     else if (with_decoder) {
             launch_step_prologue(x, wte, step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
-                                 stream);
+                                 stream, &state->all_finished);
             decoder(B, s_max);
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
@@ -2373,7 +2389,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
                 launch32_lm_head(F(nrm), F(lm_head) + (Wrows - lm_head), out, B, rows, H, ld, stream);
             }
             else if (fuse_ln) {
-                launch_lm_head(x, Wrows, out, B, rows, H, ld, stream, final_g, final_b, 1e-5f);
+                launch_lm_head(x, Wrows, out, B, rows, H, ld, stream, final_g, final_b, 1e-5f, &state->all_finished);
             }
             else {
                 lm_head_dispatch(nrm, Wrows, out, B, rows, H, ld, stream);
@@ -2424,22 +2440,36 @@ int ftcf_gptneox::step(int max_steps)
     std::vector<int> h_tokens(B), h_idx(B), h_seq(B);
     hipEvent_t ea = get_event(), eb = get_event();
     FTCF_HIP_CHECK(hipEventRecord(ea, stream));
+    // (read per call, not once per process: the tests switch it between engines)
+    const int graph_tokens_cfg = getenv("FTCF_GRAPH_TOKENS") ? atoi(getenv("FTCF_GRAPH_TOKENS")) : 8;
     int  done    = 0;
     bool lagging = false;  // the host has not yet seen the flags of the token launched last
+    int  lag_slot = 0;     // launches of the pipelined loop so far (two events alternate)
     while (done < max_steps && ses.next_step < total && !ses.all_finished) {
         const int  step         = ses.next_step;
         const bool with_decoder = !(S > 1 && step == S);
         // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
         // has been validated on a multi-GPU node (this round's boxes have one GPU)
         const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local && !cfg.comm->hx)) && !a.debug_logits;
+        // Several tokens per graph launch (FTCF_GRAPH_TOKENS, default 8): a graph launch costs ~14 us of GPU idle time between
+        // two tokens (profiles/r03_notes.md section 6), and every kernel of a persistent-path token returns at once when the
+        // device-side "every row has finished" flag is set, so the tokens of a graph behind the request's last one cost a few
+        // microseconds each, not a decoder pass.  Persistent decode path, no streaming callback, one GPU.
+        const int  graph_tokens = std::max(1, std::min(64, graph_tokens_cfg));
+        const bool multi        = graph_ok && graph_tokens > 1 && pplan.ok && ses.K == 1 && !a.callback && tp == 1
+                                  && max_steps - done >= graph_tokens && total - step >= graph_tokens;
+        int launched = 1;
         if (graph_ok) {
-            if (!ses.graph_exec) {
-                // capture ONE regular decode step (all pointers are fixed for the session, the step counter lives
-                // on the device) and replay it: no per-kernel host launch cost, cross-stream fork/join become edges
+            hipGraphExec_t& ge = multi ? ses.graph_exec_n : ses.graph_exec;
+            if (!ge) {
+                // capture the regular decode step(s) (all pointers are fixed for the session, the step counter lives
+                // on the device) and replay: no per-kernel host launch cost, cross-stream fork/join become edges
                 hipGraph_t g = nullptr;
                 FTCF_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 try {
-                    enqueue_step(true);
+                    for (int t = 0; t < (multi ? graph_tokens : 1); t++) {
+                        enqueue_step(true);
+                    }
                 }
                 catch (...) {
                     (void)hipStreamEndCapture(stream, &g);
@@ -2449,10 +2479,11 @@ int ftcf_gptneox::step(int max_steps)
                     throw;
                 }
                 FTCF_HIP_CHECK(hipStreamEndCapture(stream, &g));
-                FTCF_HIP_CHECK(hipGraphInstantiate(&ses.graph_exec, g, nullptr, nullptr, 0));
+                FTCF_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
                 FTCF_HIP_CHECK(hipGraphDestroy(g));
             }
-            FTCF_HIP_CHECK(hipGraphLaunch(ses.graph_exec, stream));
+            FTCF_HIP_CHECK(hipGraphLaunch(ge, stream));
+            launched = multi ? graph_tokens : 1;
         }
         else {
             enqueue_step(with_decoder);
@@ -2460,24 +2491,25 @@ int ftcf_gptneox::step(int max_steps)
         if (a.debug_logits) {
             // (logits are modified in place by the decode kernels; the tap is taken inside enqueue_step when eager)
         }
-        ses.steps++;
-        ses.next_step++;
-        done++;
+        ses.steps += launched;
+        ses.next_step += launched;
+        done += launched;
         // The reference synchronises once per token here (stop_criteria_kernels.cu:149-156).  Without a streaming
         // callback nothing on the host needs token t before token t+1 is enqueued, so the replayed graph of the next
-        // token is launched first and the host only waits for the PREVIOUS token's event: the GPU never idles for the
-        // host round trip (~25 us per token).  `finished` is sticky on the device, so the one speculative step that may
-        // run after every row has finished only rewrites end_id / leaves the lengths alone.
+        // token(s) is launched first and the host only waits for the PREVIOUS launch's event: the GPU never idles for the
+        // host round trip (~25 us per token).  `finished` is sticky on the device and the launches behind the last token
+        // return at once; the host's counters are set back to the device's when it learns of the end (below).
         if (graph_ok && !a.callback && tp == 1) {  // (tp > 1: every rank must leave the loop at the SAME token -> synchronous)
-            hipEvent_t& ev = tok_ev[done & 1];
+            hipEvent_t& ev = tok_ev[lag_slot & 1];
             if (!ev) {
                 FTCF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             }
             FTCF_HIP_CHECK(hipEventRecord(ev, stream));
             if (lagging) {
-                comm_event_sync(cfg.comm, tok_ev[(done - 1) & 1]);
+                comm_event_sync(cfg.comm, tok_ev[(lag_slot - 1) & 1]);
                 ses.all_finished = h_flags[0] != 0;
             }
+            lag_slot++;
             lagging = true;
             continue;
         }
@@ -2501,6 +2533,17 @@ int ftcf_gptneox::step(int max_steps)
     comm_event_sync(cfg.comm, eb, "the prefill");
     if (lagging) {
         ses.all_finished = h_flags[0] != 0;
+    }
+    if (ses.all_finished && ses.K == 1) {
+        // launches behind the token that finished the last row did nothing on the device (every kernel of a token returns at
+        // once on the flag, k_decode_finish included: the device's step counter stopped): the host's counters follow the
+        // device's, so that `steps_done` is the reference's loop count (GptNeoX.cc:776-1048 leaves its loop at that token)
+        const int over = ses.next_step - (h_flags[1] + 1);
+        if (over > 0) {
+            ses.next_step -= over;
+            ses.steps -= over;
+            done -= over;
+        }
     }
     float ms = 0.f;
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ea, eb));
@@ -2547,6 +2590,10 @@ void ftcf_gptneox::finish()
     if (ses.graph_exec) {
         (void)hipGraphExecDestroy(ses.graph_exec);
         ses.graph_exec = nullptr;
+    }
+    if (ses.graph_exec_n) {
+        (void)hipGraphExecDestroy(ses.graph_exec_n);
+        ses.graph_exec_n = nullptr;
     }
     drain_events();
     if (pplan.ok && ps_ts) {

@@ -63,7 +63,7 @@ void plan_splitk(SplitKParams& p, bool int8, int M, int max_waves);
 void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStream_t s);
 // optional fused LayerNorm of x (gamma != NULL)
 void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s,
-                    const f16* gamma = nullptr, const f16* beta = nullptr, float eps = 1e-5f);
+                    const f16* gamma = nullptr, const f16* beta = nullptr, float eps = 1e-5f, const int* d_stop = nullptr);
 
 // ---- MFMA GEMM (prefill / batched decode) : kernels_gemm.hip ----
 // C[m,n] = A[m,k] x W(tiled)  (+bias, gelu) ; int8: fused fp32 epilogue ; fp16: half epilogue
@@ -158,7 +158,8 @@ bool   mmha_head_size_supported(int dh);  // the reference's list (DecoderSelfAt
 void   launch_rotary_table(float* table, const int* d_step, const int* pad_count, int B, int rot, hipStream_t s);
 // launch_step_embedding + launch_rotary_table in one launch
 void   launch_step_prologue(f16* out, const f16* table, const int* output_ids, const int* d_step, float* rot_table,
-                            const int* pad_count, int B, int H, int rot, hipStream_t s);
+                            const int* pad_count, int B, int H, int rot, hipStream_t s, const int* d_stop = nullptr);
+// (d_stop, here and below: device flag "every row has finished" -- the kernel returns at once when it is set)
 void   launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
                                 f16* v_cache, int B, int S, int nh, int dh, int rot, int s_max, f16* ctx,
                                 hipStream_t s, int cache_row_mult = 1, int s_lo = 0,
@@ -204,6 +205,7 @@ struct PersistPlan {
     int    xs_halves; // LDS x region
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
+    int    wt1[8], wt3[8];  // ... and the shares of all eight waves (wt[0] = wt[1] = cs; FTCF_PERSIST_WT1 / WT3, ps_wave_range_w)
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
     int    p3l;       // the control waves' P3 share is prefetched into LDS during the attention (one row, short form, TP = 1)
     int    a3;        // the attention runs on the control waves alone, K rows by LDS-DMA (one row, short form, TP = 1)
@@ -227,6 +229,7 @@ struct PersistParams {
     int                 H, Hl, Il, nh, dh, rot, s_max, B, tp;
     PersistPlan         plan;
     const int*          d_step;
+    const int*          d_stop;  // optional device flag "every row has finished": the launch returns at once when it is set
     const int*          seq_len;
     const int*          pad_count;
     const uint8_t*      masked_tokens;

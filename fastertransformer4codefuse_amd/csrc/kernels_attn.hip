@@ -67,8 +67,11 @@ __global__ void k_rotary_table(float* table, const int* d_step, const int* pad_c
 __global__ __launch_bounds__(256) void k_step_prologue(f16* out, const f16* __restrict__ table,
                                                        const int* __restrict__ output_ids, const int* d_step,
                                                        float* rot_table, const int* __restrict__ pad_count, int B, int H,
-                                                       int rot)
+                                                       int rot, const int* d_stop)
 {
+    if (d_stop && *d_stop) {
+        return;  // every row has finished: a token of a multi-token graph behind the request's last one
+    }
     const int b    = blockIdx.x;
     const int step = *d_step;
     if ((int)threadIdx.x < rot / 2) {
@@ -87,11 +90,11 @@ __global__ __launch_bounds__(256) void k_step_prologue(f16* out, const f16* __re
 }
 
 void launch_step_prologue(f16* out, const f16* table, const int* output_ids, const int* d_step, float* rot_table,
-                          const int* pad_count, int B, int H, int rot, hipStream_t s)
+                          const int* pad_count, int B, int H, int rot, hipStream_t s, const int* d_stop)
 {
     FTCF_CHECK_ARG(rot / 2 <= 256 && H % 8 == 0, "rotary_embedding_dim must be <= 512 and the hidden size a multiple of 8");
     hipLaunchKernelGGL(k_step_prologue, dim3(B), dim3(256), 0, s, out, table, output_ids, d_step, rot_table, pad_count, B, H,
-                       rot);
+                       rot, d_stop);
     FTCF_HIP_CHECK(hipGetLastError());
 }
 

@@ -175,9 +175,13 @@ __global__ __launch_bounds__(GEMV_SPLITK_MAX_WAVES * 64) void k_gemv_splitk(cons
 template<int M>
 __global__ __launch_bounds__(256) void k_lm_head(const f16* __restrict__ x, const f16* __restrict__ W,
                                                  float* __restrict__ logits, int n_rows, int K, int ldc,
-                                                 const f16* __restrict__ gamma, const f16* __restrict__ beta, float eps)
+                                                 const f16* __restrict__ gamma, const f16* __restrict__ beta, float eps,
+                                                 const int* d_stop)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (d_stop && *d_stop) {
+        return;  // every row has finished: a token of a multi-token graph behind the request's last one
+    }
     f16*   xs  = reinterpret_cast<f16*>(smem);  // [M][K]
     float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2);
     if (gamma) {
@@ -410,7 +414,7 @@ void launch_gemv_splitk(const SplitKParams& p, bool int8, int M, int epi, hipStr
 }
 
 void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows, int K, int ldc, hipStream_t s,
-                    const f16* gamma, const f16* beta, float eps)
+                    const f16* gamma, const f16* beta, float eps, const int* d_stop)
 {
     FTCF_CHECK_ARG(K % 8 == 0, "K must be a multiple of 8");
     const size_t smem = (size_t)M * (K + XPAD) * 2 + 64;
@@ -419,7 +423,7 @@ void launch_lm_head(const f16* x, const f16* W, float* logits, int M, int n_rows
         grid = 2048;
     }
 #define FTCF_LM(MM)                                                                                                    \
-    hipLaunchKernelGGL((k_lm_head<MM>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc, gamma, beta, eps)
+    hipLaunchKernelGGL((k_lm_head<MM>), dim3(grid), dim3(256), smem, s, x, W, logits, n_rows, K, ldc, gamma, beta, eps, d_stop)
     switch (M) {
         case 1: FTCF_LM(1); break;
         case 2: FTCF_LM(2); break;

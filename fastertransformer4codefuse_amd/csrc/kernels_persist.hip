@@ -46,6 +46,20 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     }
     int nsplit = NB / (B * nh);
     nsplit     = nsplit > MMHA_MAX_SPLIT ? MMHA_MAX_SPLIT : nsplit;
+    // The attention of a split costs the same for 16 keys and for 256 (one trip of fixed size), its partial costs the merge
+    // 130 granules to sweep and a term to add: with fewer heads than workgroups (tensor-parallel shards: 5 heads per rank at
+    // TP = 8) take the FEWEST splits whose chunk fits one short trip, at least two (so that small test models still merge).
+    // 13B at TP = 1: 6 either way.  TP = 8 shard: 16 -> 6 splits, "partials swept -> merged" 5.6 -> 2 us per layer.
+    {
+        static const int few = getenv("FTCF_PERSIST_FEW_SPLITS") ? atoi(getenv("FTCF_PERSIST_FEW_SPLITS")) : 1;
+        int ns = 1;
+        while (ns < nsplit && ((((s_max + ns - 1) / ns) + 15) & ~15) > PS_NW * (64 / (dh / 8)) * PS_UK) {
+            ns++;
+        }
+        if (few && ((((s_max + ns - 1) / ns) + 15) & ~15) <= PS_NW * (64 / (dh / 8)) * PS_UK) {
+            nsplit = std::min(nsplit, std::max(ns, 2));
+        }
+    }
     const int chunk = ((((s_max + nsplit - 1) / nsplit) + 15) & ~15);
     if (chunk > PS_NW * (64 / (dh / 8)) * PS_UK_LONG) {
         return pl;  // the K/V rows of a split must fit the registers of one trip
@@ -105,9 +119,27 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (best > 1e29) {
         return pl;
     }
+    // per-wave shares of the two streams (1/16 of a nominal share): the control waves' from cs1 / cs3, the streamer waves' from
+    // FTCF_PERSIST_WT1 / WT3 = six comma-separated integers for waves 2..7 (default 16 each)
+    int  wt1[8], wt3[8];
+    auto fill_wt = [](int* wt, const int cs, const char* env) {
+        for (int i = 0; i < PS_NW; i++) {
+            wt[i] = i < PS_NC ? cs : 16;
+        }
+        if (const char* e = getenv(env)) {
+            int v[PS_NW - PS_NC];
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+                for (int i = PS_NC; i < PS_NW; i++) {
+                    wt[i] = std::max(1, std::min(64, v[i - PS_NC]));
+                }
+            }
+        }
+    };
     // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations (e3c: control waves, P3)
     int  e1 = 0, e3 = 0, e3c = 0;
     auto count_entries = [&](const int c1, const int c3) {
+        fill_wt(wt1, c1, "FTCF_PERSIST_WT1");
+        fill_wt(wt3, c3, "FTCF_PERSIST_WT3");
         e1 = e3 = e3c = 0;
         for (int b = 0; b < NB; b++) {
             const int nr1 = (int)((long)NT0h * (b + 1) / NB) - (int)((long)NT0h * b / NB)
@@ -130,9 +162,9 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
             }
             for (int w = 0; w < PS_NW; w++) {
                 int tb, te;
-                ps_wave_range(nr1 * KT, w, c1, tb, te);
+                ps_wave_range_w(nr1 * KT, w, wt1, tb, te);
                 e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
-                ps_wave_range(T3, w, c3, tb, te);
+                ps_wave_range_w(T3, w, wt3, tb, te);
                 const int en = ps_wave_entries(nB + nA, nt3, tb, te);
                 e3           = std::max(e3, en);
                 if (w < PS_NC) {
@@ -169,6 +201,10 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     pl.nsplit     = nsplit;
     pl.cs1        = cs1;
     pl.cs3        = cs3;
+    for (int i = 0; i < PS_NW; i++) {
+        pl.wt1[i] = wt1[i];
+        pl.wt3[i] = wt3[i];
+    }
     pl.xs_halves  = M * std::max(2 * (H + XPAD), Il + Hl + 2 * XPAD);
     if (pl.xs_halves > 0x1ffff) {
         return pl;
@@ -260,16 +296,20 @@ static bool ps_kernel_resident(const void* k, const PersistPlan& pl, int num_cu,
 }
 bool persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world)
 {
+#ifdef PS_EXPERIMENTS
     if (pl.a4) {
         return ps_kernel_resident(persist4_kernel(int8, dh, true, true), pl, num_cu, (long)pl.NB * world);
     }
+#endif
     return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, true), pl, num_cu, (long)pl.NB * world);
 }
 bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp)
 {
+#ifdef PS_EXPERIMENTS
     if (pl.a4) {
         return ps_kernel_resident(persist4_kernel(int8, dh, tp > 1, false), pl, num_cu, pl.NB);
     }
+#endif
     if (tp > 1) {
         return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
     }
@@ -282,9 +322,13 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = p.plan.a4 ? persist4_kernel(int8, p.dh, p.tp > 1, false)
-                    : p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false)
-                               : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0, p.plan.p3l != 0);
+    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false)
+                             : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.a3 != 0, p.plan.p3l != 0);
+#ifdef PS_EXPERIMENTS
+    if (p.plan.a4) {
+        k = persist4_kernel(int8, p.dh, p.tp > 1, false);
+    }
+#endif
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
     FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;
@@ -296,7 +340,12 @@ void launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipS
 {
     FTCF_CHECK_ARG(g.world >= 2 && g.world <= PERSIST_MAX_TP && g.nb >= 1, "bad local group");
     const PersistParams& p = g.p[0];
-    const void*          k = p.plan.a4 ? persist4_kernel(int8, p.dh, true, true) : persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
+    const void*          k = persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
+#ifdef PS_EXPERIMENTS
+    if (p.plan.a4) {
+        k = persist4_kernel(int8, p.dh, true, true);
+    }
+#endif
     FTCF_CHECK_ARG(k != nullptr && p.plan.ok && p.plan.NB == g.nb, "persistent decode: no group kernel for this shape");
     PersistGroupParams gg     = g;
     void*              args[] = {&gg};

@@ -16,7 +16,7 @@ PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il,
     // share of a control wave in the first stream (FFN1 tiles it streams before it turns to the attention), in 1/16 of a
     // streamer wave's: the control waves are idle until q/k/v are complete (~40 % of the stream)
     static const int cs1_env = getenv("FTCF_PERSIST4_CS1") ? atoi(getenv("FTCF_PERSIST4_CS1")) : 8;
-    static const int on = getenv("FTCF_PERSIST_A4") ? atoi(getenv("FTCF_PERSIST_A4")) : 1;
+    static const int on = getenv("FTCF_PERSIST_A4") ? atoi(getenv("FTCF_PERSIST_A4")) : 0;  // (opt-in: slower than the first form)
     PersistPlan      pl = base;
     if (!on || !pl.ok || B != 1 || pl.uk != PS_UK || pl.a3 || pl.p3l) {
         return base;

@@ -81,6 +81,9 @@ __device__ __forceinline__ VI block_best(VI x, float* redv, int* redi)
 // ---- step 1: penalties, masks, softmax (one block per row) -----------------------------------------------------
 __global__ __launch_bounds__(1024) void k_decode_prep(const SamplingParams p)
 {
+    if (p.state->all_finished) {
+        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[64];
     const int        b    = blockIdx.x;
@@ -287,6 +290,9 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* red, int& tot)
 
 __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, float* cand_v, int* cand_i, int slice)
 {
+    if (p.state->all_finished) {
+        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
+    }
     __shared__ float redv[4];
     __shared__ int   redi[4];
     __shared__ int   hist[256];
@@ -575,6 +581,9 @@ __device__ __forceinline__ void bitonic_sort_global(float* v, int* id, const int
 
 __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* cand_v, int* cand_i)
 {
+    if (p.state->all_finished) {
+        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float redv[4];
     __shared__ int   redi[4];
@@ -906,6 +915,9 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
 // ---- step 4: stop words, length criterion, bookkeeping (single block) -----------------------------------------
 __global__ void k_decode_finish(const SamplingParams p)
 {
+    if (p.state->all_finished) {
+        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
+    }
     __shared__ int s_all;
     const int      step = p.state->step;
     if (threadIdx.x == 0) {

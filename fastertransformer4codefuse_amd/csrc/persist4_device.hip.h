@@ -160,6 +160,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
         q += (size_t)PS_NW * (E3 / PS_U) * 4;
         s.kbuf = smem + (((size_t)(q - smem) + 1023) & ~(size_t)1023);
     }
+    if (p.d_stop && *p.d_stop) {
+        return;  // every row has finished (a token of a multi-token graph behind the request's last one): uniform over the grid
+    }
     const int      step     = *p.d_step;
     const unsigned tag_base = (unsigned)step * 256u + 1u;
     if (p.ts && (threadIdx.x & 63) == 0) {  // kernel entry (slot 15 of the first layer)
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
                 }
             }
             int tb, te;
-            ps_wave_range(T3, w, p.plan.cs3, tb, te);
+            ps_wave_range_w(T3, w, p.plan.wt3, tb, te);
             const int ent3 = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
             int       nrot3 = (ent3 + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
             nrot3           = nrot3 < 1 ? 1 : nrot3;
@@ -664,12 +667,17 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent4(
                                            ctrl_barrier);
                 }
                 stamp(l, 5);
-                if (has_item && a_sp == 0 && wid == 0) {
+                if (has_item && a_sp == 0) {  // (both control waves; `live` is uniform over the pair)
                     if (live) {
-                        // (16 granules per lane and pass: the partials of up to seven splits in ONE round trip)
-                        ps_attn_merge<DH, 16>(p, s.att, gall, tag, a_h, a_b, tid);
+                        if constexpr (PS_MERGE_V2 != 0) {
+                            ps_attn_merge_sweep(p, s.att, gall, tag, DH, tid);
+                            ctrl_barrier();
+                        }
+                        if (wid == 0) {
+                            ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
+                        }
                     }
-                    else {
+                    else if (wid == 0) {
                         ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
                     }
                     stamp(l, 13);

@@ -194,6 +194,27 @@ __host__ __device__ inline void ps_wave_range(const int T, const int w, const in
     tb              = (int)((long)T * c0 / total) / PS_U * PS_U;
     te              = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
 }
+// The same with one weight per wave (wt[w], in 1/16 of a nominal share; flat order: waves PS_NC.. first, control waves last).
+// Round 4: the waves of a workgroup do NOT stream at one rate -- the stamps show the first streamer waves ending a stage 2-6 us
+// before the last ones on equal shares (issue arbitration favours the older wave), and the stage ends with the slowest wave.
+__host__ __device__ inline void ps_wave_range_w(const int T, const int w, const int* wt, int& tb, int& te)
+{
+    int total = 0, c0 = 0;
+    for (int i = 0; i < PS_NW; i++) {
+        total += wt[i];
+    }
+    for (int k = 0; k < PS_NW; k++) {  // k-th wave of the flat order
+        const int i = (k + PS_NC) % PS_NW;
+        if (i == w) {
+            break;
+        }
+        c0 += wt[i];
+    }
+    const int c1 = c0 + wt[w];
+    total        = total > 0 ? total : 1;
+    tb           = (int)((long)T * c0 / total) / PS_U * PS_U;
+    te           = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
+}
 // table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
 template<typename NT>
 __host__ __device__ inline int ps_wave_entries(const int nruns, NT&& run_nt, const int tb, const int te)
@@ -1094,6 +1115,93 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
     const int ne = DH + 2, ns = p.plan.nsplit;
     const int ng = ns * ne;
     float*    sval = reinterpret_cast<float*>(smem);  // [ns][ne] then [ns] weights + denominator
+#ifndef PS_MERGE_V2
+#define PS_MERGE_V2 1  // (round 4: ctx arrives ~2.5 us earlier, the launch is 1.5 % shorter; 0 = round 3's single-wave merge)
+#endif
+    if constexpr (PS_MERGE_V2 != 0) {
+        // The partials were swept into LDS by BOTH control waves (ps_attn_merge_sweep: 128 lanes x 8 granules = six splits of a
+        // 128-wide head in ONE round trip; the first form's single wave needed two) and the merge runs out of registers: every
+        // lane reads the splits' maxima and sums from LDS (broadcast reads), derives the weights itself and combines its own
+        // columns -- no cross-lane step, no LDS round trip for the weights (the first form: 1.7 us between "partials swept" and
+        // "merged", on the path every out-proj piece waits for)
+        // (every LDS value this lane needs is requested up front -- loops over `ns` with dependent LDS reads cost a round trip each)
+        constexpr int MS = 8;
+        if (ns <= MS) {
+            // (three batches of LDS reads -- statistics, first column, second column -- so that 16 values are live, not 32: the
+            // control role has no registers to spare)
+            float wgt[MS], t0[MS];
+#pragma unroll
+            for (int s2 = 0; s2 < MS; s2++) {
+                const int q = s2 < ns ? s2 : 0;
+                wgt[s2]     = sval[q * ne + DH];
+                t0[s2]      = sval[q * ne + DH + 1];
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int s2 = 0; s2 < MS; s2++) {
+                m = s2 < ns ? fmaxf(m, wgt[s2]) : m;
+            }
+            float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < MS; s2++) {  // split order
+                wgt[s2] = (s2 >= ns || wgt[s2] == -INFINITY) ? 0.f : __expf(wgt[s2] - m);
+                L += __fmul_rn(wgt[s2], t0[s2]);  // (the product rounded on its own, as the first form's shuffled sum has it)
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < MS; s2++) {
+                t0[s2] = sval[(s2 < ns ? s2 : 0) * ne + tx];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < MS; s2++) {
+                o0 += wgt[s2] * t0[s2];
+            }
+            if constexpr (DH > 64) {
+#pragma unroll
+                for (int s2 = 0; s2 < MS; s2++) {
+                    t0[s2] = sval[(s2 < ns ? s2 : 0) * ne + 64 + (tx < DH - 64 ? tx : 0)];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < MS; s2++) {
+                    o1 += wgt[s2] * t0[s2];
+                }
+            }
+            const float inv = 1.f / (L + 1.e-6f);  // :1632
+            static_assert(DH == 64 || DH == 128, "one or two columns per lane");
+#pragma unroll
+            for (int k = 0; k < DH / 64; k++) {
+                const int      d  = tx + k * 64;
+                const unsigned b0 = f16_bits((f16)((k == 0 ? o0 : o1) * inv));
+                const unsigned b1 = next_lane_u32(b0);
+                if ((d & 1) == 0) {
+                    st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
+                }
+            }
+            return;
+        }
+        float m = -INFINITY;
+        for (int s2 = 0; s2 < ns; s2++) {
+            m = fmaxf(m, sval[s2 * ne + DH]);
+        }
+        float L = 0.f;
+        for (int s2 = 0; s2 < ns; s2++) {  // (split order, like the first form's lane-ordered sum)
+            const float ms = sval[s2 * ne + DH];
+            L += ((ms == -INFINITY) ? 0.f : __expf(ms - m)) * sval[s2 * ne + DH + 1];
+        }
+        const float inv = 1.f / (L + 1.e-6f);  // :1632
+        for (int d = tx; d < DH; d += 64) {
+            float o = 0.f;
+            for (int s2 = 0; s2 < ns; s2++) {
+                const float ms = sval[s2 * ne + DH];
+                o += ((ms == -INFINITY) ? 0.f : __expf(ms - m)) * sval[s2 * ne + d];
+            }
+            const unsigned b0 = f16_bits((f16)(o * inv));
+            const unsigned b1 = next_lane_u32(b0);
+            if ((d & 1) == 0) {
+                st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
+            }
+        }
+        return;
+    }
     ps_sweep<NPER>(gall, ng, tx, 64, tag, p.err, 2, [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
     if (p.ts && tx == 0) {  // (debug stamp 15: partials swept)
         p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + 0) * 16 + 15] = wall_clock64();
@@ -1125,6 +1233,18 @@ __device__ __forceinline__ void ps_attn_merge(const PersistParams& p, char* smem
         if ((d & 1) == 0) {
             st_granule_u32(&p.gc[((size_t)b * p.nh * DH + h * DH + d) >> 1], tag, b0 | (b1 << 16));
         }
+    }
+}
+
+// PS_MERGE_V2: both control waves of a split-0 workgroup sweep the (row, head)'s partials into LDS
+__device__ __forceinline__ void ps_attn_merge_sweep(const PersistParams& p, char* smem, const u64* gall, const unsigned tag,
+                                                    const int dh, const int tid2)
+{
+    float* sval = reinterpret_cast<float*>(smem);
+    ps_sweep<8>(gall, p.plan.nsplit * (dh + 2), tid2, PS_NC * 64, tag, p.err, 2,
+                [&](const int i, const unsigned v) { sval[i] = __uint_as_float(v); });
+    if (p.ts && tid2 == 0) {  // (debug stamp 15: partials swept)
+        p.ts[(((size_t)blockIdx.x * p.L + (tag & 255u) - 1u) * PS_NW + 0) * 16 + 15] = wall_clock64();
     }
 }
 
@@ -1300,6 +1420,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         q += (size_t)PS_NW * (E3 / PS_U) * 4;
         s.kbuf = smem + (((size_t)(q - smem) + 1023) & ~(size_t)1023);
     }
+    if (p.d_stop && *p.d_stop) {
+        return;  // every row has finished (a token of a multi-token graph behind the request's last one): uniform over the grid
+    }
     const int      step     = *p.d_step;
     const unsigned tag_base = (unsigned)step * 256u + 1u;
     if (p.ts && (threadIdx.x & 63) == 0) {  // kernel entry (slot 15 of the first layer)
@@ -1346,6 +1469,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             s.misc[33] = 0;  // control-wave pair barrier (+PS_NC per layer)
             s.misc[34] = 0;  // A3: streamer-wave barrier (+(PS_NW - PS_NC) per layer)
             s.misc[35] = 0;  // A3: control-wave barrier inside the attention
+            s.misc[39] = 0;  // control pair barrier of the partials' sweep (PS_MERGE_V2)
         }
         __syncthreads();
         if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
@@ -1429,7 +1553,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             ctx_hi = ps_rfl(ctx_hi);
             const int w = ps_rfl(wid);
             int       tb, te;
-            ps_wave_range(T1, w, p.plan.cs1, tb, te);
+            ps_wave_range_w(T1, w, p.plan.wt1, tb, te);
             int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
             sg1.lt   = s.lt1 + (size_t)w * E1;
             sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
@@ -1437,7 +1561,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
             ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
                                 sg1.nrot * PS_U * PS_NBUF);
-            ps_wave_range(T3, w, p.plan.cs3, tb, te);
+            ps_wave_range_w(T3, w, p.plan.wt3, tb, te);
             ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
             sg3.lt   = s.lt3 + (size_t)w * E3;
             sg3.bt   = s.bt3 + (size_t)w * (E3 / PS_U);
@@ -1981,7 +2105,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             // announce it through an LDS counter that gates every batch touching ctx; their own share is the END of the
             // workgroup's tile space, i.e. the out-proj pieces.
             if constexpr (CTRL) {
-                if constexpr (PS_CTRL_EARLY != 0) {
+                if constexpr (PS_CTRL_EARLY == 1 || PS_CTRL_EARLY == 2) {
                     // the weights of the control waves' share (the out-proj pieces) need nothing: requested before the
                     // wait for ctx (polls of this wave return behind them -- ctx is 6-10 us away anyway)
                     st.prime_lo();
@@ -1989,7 +2113,40 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                         st.prime_hi();
                     }
                 }
-                if (has_item && a_sp == 0 && wid == 0) {
+                if constexpr (PS_MERGE_V2 != 0) {
+                    if (has_item && a_sp == 0) {  // (both control waves; `live` is uniform over the workgroup)
+                        if (live) {
+                            ps_attn_merge_sweep(p, s.att, gall, tag, DH, tid);
+                            // pair barrier (an LDS counter of its own: + PS_NC per layer)
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (lane == 0) {
+                                atomicAdd(&s.misc[39], 1);
+                            }
+                            const int want = (l - p.l_begin + 1) * PS_NC;
+                            for (int spins = 0; ps_rfl(*(const volatile __attribute__((address_space(3))) int*)&s.misc[39]) < want;) {
+                                if (++spins > (PS_SPIN << 6)) {
+                                    __hip_atomic_store(p.err, 15, PS_RLX, PS_AGT);
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(0);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            if (wid == 0) {
+                                ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
+                            }
+                        }
+                        else {
+                            if (lane == 0) {
+                                atomicAdd(&s.misc[39], 1);  // (keeps the counter in step with the layers)
+                            }
+                            if (wid == 0) {
+                                ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
+                            }
+                        }
+                        stamp(l, 13);
+                    }
+                }
+                else if (has_item && a_sp == 0 && wid == 0) {
                     if (live) {
                         ps_attn_merge<DH>(p, s.att, gall, tag, a_h, a_b, tid);
                     }
@@ -1997,6 +2154,17 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                         ps_attn_publish_zero<DH>(p, tag, a_h, a_b, tid);
                     }
                     stamp(l, 13);
+                }
+                if constexpr (PS_CTRL_EARLY == 3 || PS_CTRL_EARLY == 4) {
+                    // ... requested AFTER the merge of the splits (round 3's PS_CTRL_EARLY 1 / 2 put the merging wave's polls of
+                    // the partials behind its own prefetch: ctx arrived 3 us later for everybody) and before the sweep of ctx,
+                    // which is several microseconds away: the share's first rotation lands under that wait, in the window where
+                    // the HBM has little else to do, instead of being requested when ctx has arrived (the control waves
+                    // finished P3 2-7 us after the streamer waves)
+                    st.prime_lo();
+                    if constexpr (PS_CTRL_EARLY == 3) {
+                        st.prime_hi();
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < M; m++) {
@@ -2027,7 +2195,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             }
             stamp(l, 9);
             if constexpr (!(CTRL && P3L)) {
-                st.template run<CTRL ? (PS_CTRL_EARLY != 2) : ((!A3F && PS_MID_ALL >= 2) ? PS_MID_ALL != 3 : EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
+                st.template run<CTRL ? (PS_CTRL_EARLY != 2 && PS_CTRL_EARLY != 3) : ((!A3F && PS_MID_ALL >= 2) ? PS_MID_ALL != 3 : EARLY == 0 ? !PS_FULL_P3 : EARLY != 2)>();
             }
             stamp(l, 10);
             __syncthreads();

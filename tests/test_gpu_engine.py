@@ -557,3 +557,58 @@ def test_fp16_kernels_can_be_retiled_in_place(gh, tiny, monkeypatch):
     # the caller's QKV kernel of layer 0 no longer holds the row-major matrix
     assert not np.array_equal(op.weights[2 * L].cpu().numpy().astype(np.float32).reshape(H, 3 * H),
                               np.asarray(w[2 * L], np.float32).reshape(H, 3 * H).astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_multi_token_graphs_equal_single_token_graphs(gh, tiny, monkeypatch, decode_path, B):
+    """FTCF_GRAPH_TOKENS tokens per captured graph (default 8; persistent path): the same tokens, lengths and LOOP COUNT as one
+    token per graph -- also when the rows finish on end_id in the middle of a graph (the launches behind the last token return at
+    once on the device's flag and the host's counters are set back to the device's: GptNeoX.cc:776-1048 leaves its loop at that
+    token), and when the token loop is driven in pieces through begin / step / finish."""
+    import ctypes as C
+    import torch
+    from fastertransformer4codefuse_amd import capi
+    if decode_path != "persistent":
+        pytest.skip("persistent-path-only")
+    cfg, w, layers, glob, z = tiny
+    S, out = 16, 30
+    ids_np = np.stack([z["prompt"], z["prompt"][::-1]]).astype(np.int32)[:B]
+    monkeypatch.setenv("FTCF_GRAPH_TOKENS", "1")
+    free = gh.run_op(gh.make_op(cfg, w), ids_np, [S] * B, out, cfg["vocab_size"], top_k=1, return_logits=False)
+    # an end_id that row 0 emits as its 6th new token: with 4 tokens per graph the request ends in the middle of a graph
+    cfg2 = dict(cfg, end_id=int(free["output_ids"][0, S + 5]))
+    res = {}
+    for n in (1, 4, 8):
+        monkeypatch.setenv("FTCF_GRAPH_TOKENS", str(n))
+        op = gh.make_op(cfg2, w)
+        r = gh.run_op(op, ids_np, [S] * B, out, cfg["vocab_size"], top_k=1, return_logits=False)
+        res[n] = (r["output_ids"].tolist(), r["sequence_lengths"].tolist(), r["cum_log_probs"].tolist(), op.stats()["decode_steps"])
+        rf = gh.run_op(gh.make_op(cfg, w), ids_np, [S] * B, out, cfg["vocab_size"], top_k=1, return_logits=False)
+        assert rf["output_ids"].tolist() == free["output_ids"].tolist()  # (no early end: whole graphs + single-token tail)
+    assert res[4] == res[1] and res[8] == res[1], (res[1][3], res[4][3], res[8][3])
+    if B == 1:
+        assert res[1][3] == 6  # the loop count of the reference: it leaves its loop at the token that finished the last row
+    # the loop in pieces: 3 + 9 + the rest, four tokens per graph
+    monkeypatch.setenv("FTCF_GRAPH_TOKENS", "4")
+    op = gh.make_op(cfg2, w)
+    ids = torch.from_numpy(ids_np).cuda()
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    out_ids = torch.zeros((B, 1, S + out), dtype=torch.int32, device="cuda")
+    seq = torch.zeros((B, 1), dtype=torch.int32, device="cuda")
+    top_k = np.array([1], np.int32)
+    fa = capi.ForwardArgs()
+    fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+    fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, out, 1
+    fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+    fa.output_ids, fa.sequence_lengths = out_ids.data_ptr(), seq.data_ptr()
+    L = capi.lib()
+    done, total_done = C.c_int(0), 0
+    capi.check(L.ftcf_gptneox_begin(op._h, C.byref(fa)))
+    for n in (3, 9, 100):
+        capi.check(L.ftcf_gptneox_step(op._h, n, C.byref(done)))
+        assert 0 <= done.value <= n
+        total_done += done.value
+    capi.check(L.ftcf_gptneox_finish(op._h))
+    torch.cuda.synchronize()
+    assert out_ids[:, 0].cpu().numpy().tolist() == res[1][0] and seq[:, 0].cpu().numpy().tolist() == res[1][1]
+    assert total_done == res[1][3]

@@ -26,6 +26,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MID = dict(head_num=8, size_per_head=64, inter_size=2048, num_layer=3, vocab_size=2048, rotary_dim=16, start_id=0, end_id=2)
 
 
+# the CodeFuse-13B shape (BASELINE.json configs 3 / 4) on bench.py's synthetic weights
+FULL13B = dict(layers=40, heads=40, head_dim=128, inter=20480, vocab=100864, rotary=32, dtype="int8")
+
+
+def request_13b():
+    import torch
+    g = torch.Generator().manual_seed(48)
+    return torch.randint(3, FULL13B["vocab"], (1, 192), generator=g, dtype=torch.int32), 6
+
+
 def requests(cfg, model):
     """name -> (ids, lens, n_out, sampling kwargs); shared by the workers and the checker."""
     if model == "tiny":
@@ -51,7 +61,7 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, model, int8_mode, world=2, extra_env=None):
+def _run_ranks(tmp_path, model, int8_mode, world=2, extra_env=None, timeout=600):
     port = str(_free_port())
     env = dict(os.environ, FTCF_PERSIST_NB="128", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
@@ -62,7 +72,7 @@ def _run_ranks(tmp_path, model, int8_mode, world=2, extra_env=None):
     logs = []
     for p in procs:
         try:
-            logs.append(p.communicate(timeout=600)[0])
+            logs.append(p.communicate(timeout=timeout)[0])
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -148,3 +158,38 @@ def test_two_processes_fall_back_together_when_the_windows_are_refused(gh, tmp_p
     ids, lens, n_out, kw = requests(cfg, "tiny")["one_row"]
     r1 = gh.run_op(op1, ids, lens, n_out, cfg["vocab_size"], **kw)
     assert res[0]["one_row.output_ids"].tolist() == r1["output_ids"].tolist()
+
+
+@pytest.mark.timeout(2400)
+def test_13b_tp2_shards_between_two_processes(tmp_path):
+    """BASELINE config 4 (CodeFuse-13B int8, TP = 2) as far as ONE GPU can run it: two PROCESSES, each holding its exact 6.9 GB
+    shard of the 40-layer model and 128 workgroups of the tensor-parallel persistent kernel, x' exchanged through the
+    IPC-mapped windows in every layer of every token (the prompt phase's collectives are host staged) -- against the TP = 1
+    engine on the whole model.  Until round 4 the product instantiation had only met 512-hidden models between processes."""
+    import argparse
+    import sys
+    import torch
+    from fastertransformer4codefuse_amd import capi
+    capi.require_gpu()
+    res, logs = _run_ranks(tmp_path, "13b", 1, timeout=2000)
+    assert not any("exchange windows unavailable" in lg for lg in logs), logs[0][-2000:]
+    assert res[0]["output_ids"].tolist() == res[1]["output_ids"].tolist()
+    np.testing.assert_array_equal(res[0]["logits"], res[1]["logits"])  # rank-ordered in-kernel sums: bit-identical on both ranks
+    got = (int(res[0]["decode_path"][0]), int(res[1]["decode_path"][0]))
+    if got == (0, 0) and int(res[0]["attempts"][0]) == 4:
+        pytest.xfail("the two processes' kernels were not co-scheduled in four attempts: in-kernel path not exercised")
+    assert got == (1, 1)
+    sys.path.insert(0, ROOT)
+    import bench
+    from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
+    a = argparse.Namespace(**FULL13B)
+    weights, int8_w, scales = bench.synth_weights(a, 1, torch.device("cuda", 0))
+    op1 = GptNeoXOp(None, 0, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, 2, 1, 1, 1, 2048, True, weights, int8_w, scales)
+    ids, n_out = request_13b()
+    S = ids.shape[1]
+    lens = torch.full((1,), S, dtype=torch.int32, device="cuda")
+    dbg = torch.zeros((n_out, 1, a.vocab), dtype=torch.float32, device="cuda")
+    o = op1.forward(ids.cuda(), lens, n_out, 1, torch.tensor([1], dtype=torch.int32), _debug_logits=dbg)
+    torch.cuda.synchronize()
+    # the shards are exact slices of the TP = 1 model: only the summation order of the row-split GEMMs differs
+    _check(o[0][:, 0].cpu().numpy(), dbg.cpu().numpy(), res[0]["output_ids"], res[0]["logits"], [S], "13B TP=2 processes vs TP=1", 5e-3)

@@ -25,6 +25,8 @@ def main():
     from tests import gpu_helpers as gh
     from tests.helpers import load_tiny, random_model, shard_weights
     from tests.test_gpu_tp_process import MID, requests
+    if model == "13b":
+        return main_13b(rank, world, out)
     if model == "tiny":
         cfg, w, _ = load_tiny()
     else:
@@ -49,6 +51,42 @@ def main():
         flag = torch.tensor([left])
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         res["attempts"] = np.array([attempt + 1])
+        del op
+        if int(flag.item()) == 0:
+            break
+    np.savez(out, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main_13b(rank, world, out):
+    """The product tensor-parallel instantiation at the CodeFuse-13B int8 TP = `world` SHARD SHAPE: this rank's exact shard of
+    bench.py's synthetic model (column / row slices of the TP = 1 tile images, the same scales: tests/test_gpu_fullsize._shard)."""
+    import argparse
+    import bench
+    from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp
+    from tests.test_gpu_fullsize import _shard
+    from tests.test_gpu_tp_process import FULL13B, request_13b
+    a = argparse.Namespace(**FULL13B)
+    full = (a,) + tuple(bench.synth_weights(a, 1, torch.device("cuda", 0)))
+    w, q8, sc = _shard(full, world, rank)
+    del full
+    torch.cuda.empty_cache()
+    ids, n_out = request_13b()
+    ids = ids.cuda()
+    lens = torch.full((1,), ids.shape[1], dtype=torch.int32, device="cuda")
+    res = {}
+    for attempt in range(4):  # (see main(): a run that left the in-kernel path is repeated with a fresh engine pair)
+        op = GptNeoXOp(dist.group.WORLD, rank, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, 2, world, 1, 1, 2048,
+                       True, w, q8, sc)
+        dbg = torch.zeros((n_out, 1, a.vocab), dtype=torch.float32, device="cuda")
+        o = op.forward(ids, lens, n_out, 1, torch.tensor([1], dtype=torch.int32), _debug_logits=dbg)
+        torch.cuda.synchronize()
+        path = op.stats()["decode_path"]
+        res = {"output_ids": o[0][:, 0].cpu().numpy(), "logits": dbg.cpu().numpy(), "decode_path": np.array([path]),
+               "attempts": np.array([attempt + 1])}
+        flag = torch.tensor([0 if path == 1 else 1])
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         del op
         if int(flag.item()) == 0:
             break
