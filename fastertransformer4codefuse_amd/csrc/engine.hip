@@ -997,6 +997,8 @@ enum { KIND_LN_GEMV = 0, KIND_SPLITK = 1, KIND_LM_HEAD = 2, KIND_FUSED = 3, KIND
 
 }  // namespace
 
+__global__ void k_transpose_gathered_logits(float* out, const float* in, int tp, int B, int vl);  // (defined below)
+
 struct ftcf_gptneox {
     ftcf_gptneox_config       cfg{};
     int                       H = 0, nhl = 0, hl = 0, il = 0, L = 0, V = 0, vl = 0, dh = 0;
@@ -1348,6 +1350,24 @@ struct ftcf_gptneox {
             }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, st));
         }
+    }
+
+    // vocabulary-split LM head (GptNeoX.cc:888-925): rank r has written its [B, V/TP] slice of `gath` ([TP][B][V/TP] fp32);
+    // all-gather it and transpose into out [B, V]
+    void allgather_logits(float* gath, float* out, int B, hipStream_t st)
+    {
+        const int tp = cfg.tensor_para_size;
+        float*    mine = gath + (size_t)cfg.tensor_para_rank * B * vl;
+        if (cfg.comm->local) {
+            local_allgather(cfg.comm, gath, (size_t)B * vl, false, st);
+        }
+        else if (cfg.comm->hx) {
+            hx_allgather_device(cfg.comm, gath, (size_t)B * vl, 4, st);
+        }
+        else {
+            FTCF_NCCL_CHECK(ncclAllGather(mine, gath, (size_t)B * vl, ncclFloat32, cfg.comm->comm, st));
+        }
+        hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, st, out, gath, tp, B, vl);
     }
 
     // ---------------------------------------------------------------------------------------------------------------
@@ -2405,16 +2425,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
             float* mine = gather + (size_t)cfg.tensor_para_rank * B * vl;
             timed(KIND_LM_HEAD, 2.0 * vl * H,
                   [&] { lm(lm_head + (size_t)cfg.tensor_para_rank * vl * H, mine, vl, vl); });
-            if (cfg.comm->local) {
-                local_allgather(cfg.comm, gather, (size_t)B * vl, false, stream);
-            }
-            else if (cfg.comm->hx) {
-                hx_allgather_device(cfg.comm, gather, (size_t)B * vl, 4, stream);
-            }
-            else {
-                FTCF_NCCL_CHECK(ncclAllGather(mine, gather, (size_t)B * vl, ncclFloat32, cfg.comm->comm, stream));
-            }
-            hipLaunchKernelGGL(k_transpose_gathered_logits, dim3(256), dim3(256), 0, stream, logits, gather, tp, B, vl);
+            allgather_logits(gather, logits, B, stream);
         }
         if (a.debug_logits) {
             FTCF_HIP_CHECK(hipMemcpyAsync(a.debug_logits + (size_t)(ses.next_step - S) * B * V, logits,
@@ -2913,7 +2924,7 @@ extern "C" int ftcf_gptneox_destroy(ftcf_gptneox_t h)
 // step is the general layer sequence of the engine (§4a: dual LayerNorm, burst / tiled GEMMs, fused residual) with the
 // attention replaced by k_mmha_paged, the LM head, and the engine's sampling kernels on per-slot arrays.  A sequence leaves
 // when it emits end_id or reaches max_new_tokens; its pages return to the free list at once.
-// Scope of this first version: parallel-residual models, tensor_para_size 1, fp16 / int8 engines, beam_width 1, top-k /
+// Scope: parallel-residual models, any tensor_para_size (round 4: one batcher per rank), fp16 / int8 engines, beam_width 1, top-k /
 // top-p / temperature sampling (no repetition penalty, stop words or callbacks).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_batcher_embed(f16* out, const f16* table, const int* tok, int H)
@@ -2966,6 +2977,7 @@ struct ftcf_batcher {
     f16 *kpool = nullptr, *vpool = nullptr;
     f16 *x = nullptr, *nrm = nullptr, *nrm2 = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
     float*    logits = nullptr;
+    float*    gather = nullptr;  // tensor parallel: [TP][max_batch][V / TP] slices of the LM head
     int *     d_pt = nullptr, *d_len = nullptr, *d_tok = nullptr, *d_topk = nullptr, *d_zero = nullptr, *d_prompt = nullptr, *d_plen = nullptr,
         *d_pout = nullptr, *d_pseq = nullptr, *d_pages_tmp = nullptr;
     uint8_t*     d_fin = nullptr;
@@ -3012,8 +3024,8 @@ struct ftcf_batcher {
     void init(ftcf_gptneox* eng, int mb, int page_tokens, int pages, int max_seq_len)
     {
         e = eng;
-        FTCF_CHECK_ARG(!e->fp32 && e->cfg.tensor_para_size == 1 && e->cfg.use_gptj_residual && (e->dh == 64 || e->dh == 128),
-                       "the batcher serves fp16 / int8 engines with parallel residual, tensor_para_size 1 and size_per_head 64 / 128");
+        FTCF_CHECK_ARG(!e->fp32 && e->cfg.use_gptj_residual && (e->dh == 64 || e->dh == 128),
+                       "the batcher serves fp16 / int8 engines with parallel residual and size_per_head 64 / 128");
         FTCF_CHECK_ARG(mb >= 1 && mb <= 64 && page_tokens >= 8 && pages >= 1 && max_seq_len >= 2, "bad batcher geometry");
         FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
         if (const char* c = getenv("FTCF_BATCHER_PREFILL_CHUNK")) {
@@ -3040,6 +3052,9 @@ struct ftcf_batcher {
         mid = dmalloc<f16>(B * il);
         ffn = dmalloc<f16>(B * H);
         logits = dmalloc<float>(B * V);
+        // tensor parallel (every rank runs its own batcher over its shard, fed the same requests in the same order: the
+        // schedulers take identical decisions, the decode step's collectives are the engine's): the LM head's [TP][B][V/TP] slices
+        gather = e->cfg.tensor_para_size > 1 ? dmalloc<float>(B * V) : nullptr;
         d_pt = dmalloc<int>(B * max_pages);
         d_len = dmalloc<int>(B);
         d_tok = dmalloc<int>(B);
@@ -3301,6 +3316,8 @@ struct ftcf_batcher {
         const int              B = max_batch, H = e->H, hl = e->hl, il = e->il, L = e->L, V = e->V;
         const bool             int8 = e->int8;
         const bool             dual = residual_dual_ln_supported(H);
+        const int              tp = e->cfg.tensor_para_size;
+        const bool             tp1 = tp == 1;  // (tensor parallel: the layer ends with residual + all-reduce, GptNeoXDecoder.cc:357-359)
         hipLaunchKernelGGL(k_batcher_embed, dim3(B), dim3(256), 0, st, x, e->wte, d_tok, H);
         if ((gemm_steps++ & 0x3ffff) == 0 && smallm_ws) {  // the tag space of the burst GEMMs wraps: start it clean
             FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
@@ -3312,7 +3329,7 @@ struct ftcf_batcher {
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
                 launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, st);
             }
-            else if (l == 0) {
+            else if (l == 0 || !tp1) {
                 launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm, nrm2, B, H,
                                         1e-5f, st);
             }
@@ -3376,22 +3393,33 @@ struct ftcf_batcher {
             }
             // (every slot's hidden state is recomputed from its token each step: the residual never aliases across steps,
             // so the fp32-sum variant of the context decoder applies to all layers)
-            if (dual) {
+            if (dual && tp1) {
                 const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
                 launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, (l > 0 && l < L - 1) ? 1 : 0, nx ? nx->ln1_g : nullptr,
                                         nx ? nx->ln1_b : nullptr, nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H,
                                         1e-5f, st);
             }
             else {
-                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, 1, (l > 0 && l < L - 1) ? 1 : 0, true, st);
+                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, tp, (l > 0 && l < L - 1) ? 1 : 0, true, st);
+                e->allreduce(x, (size_t)B * H, st);
             }
         }
-        if (B <= 4) {
-            launch_lm_head(x, e->lm_head, logits, B, V, H, V, st, e->final_g, e->final_b, 1e-5f);
-        }
-        else {
-            launch_layernorm(x, e->final_g, e->final_b, nrm, B, H, 1e-5f, true, st);
-            lm_head_dispatch(nrm, e->lm_head, logits, B, V, H, V, st);
+        {
+            // LM head; tensor parallel: rank r computes rows [r V/TP, (r+1) V/TP) of the replicated lm_head into its slice of
+            // `gather`, all-gather + transpose (GptNeoX.cc:888-925, as the engine's own step)
+            const int    rows = tp1 ? V : e->vl;
+            const f16*   Wr   = tp1 ? e->lm_head : e->lm_head + (size_t)e->cfg.tensor_para_rank * e->vl * H;
+            float*       out  = tp1 ? logits : gather + (size_t)e->cfg.tensor_para_rank * B * e->vl;
+            if (B <= 4) {
+                launch_lm_head(x, Wr, out, B, rows, H, rows, st, e->final_g, e->final_b, 1e-5f);
+            }
+            else {
+                launch_layernorm(x, e->final_g, e->final_b, nrm, B, H, 1e-5f, true, st);
+                lm_head_dispatch(nrm, Wr, out, B, rows, H, rows, st);
+            }
+            if (!tp1) {
+                e->allgather_logits(gather, logits, B, st);
+            }
         }
         SamplingParams sp{};
         sp.logits = logits;

@@ -119,6 +119,8 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (best > 1e29) {
         return pl;
     }
+    static const int qrot_env = getenv("FTCF_PERSIST_QROT") ? atoi(getenv("FTCF_PERSIST_QROT")) : 1;
+    const int        qrot_plan = ((qrot_env % NB) + NB) % NB;
     // per-wave shares of the two streams (1/16 of a nominal share): the control waves' from cs1 / cs3, the streamer waves' from
     // FTCF_PERSIST_WT1 / WT3 = six comma-separated integers for waves 2..7 (default 16 each)
     int  wt1[8], wt3[8];
@@ -162,8 +164,18 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
             }
             for (int w = 0; w < PS_NW; w++) {
                 int tb, te;
-                ps_wave_range_w(nr1 * KT, w, wt1, tb, te);
-                e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
+                if (PS_QKV_EARLY != 0) {  // (the wave's QKV slice, then its FFN1 slice: persist_device.hip.h ps_wave_range2_w)
+                    const int qbk = (b + qrot_plan) % NB;
+                    const int nqb = (int)((long)NT0h * (qbk + 1) / NB) - (int)((long)NT0h * qbk / NB);
+                    const int nfb = (int)((long)NFh * (b + 1) / NB) - (int)((long)NFh * b / NB);
+                    int       qa, qz, fa, fz;
+                    ps_wave_range2_w(nqb * KT, nfb * KT, w, wt1, qa, qz, fa, fz);
+                    e1 = std::max(e1, ps_wave_entries(nqb, nt1, qa, qz) + ps_wave_entries(nfb, nt1, fa, fz));
+                }
+                else {
+                    ps_wave_range_w(nr1 * KT, w, wt1, tb, te);
+                    e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
+                }
                 ps_wave_range_w(T3, w, wt3, tb, te);
                 const int en = ps_wave_entries(nB + nA, nt3, tb, te);
                 e3           = std::max(e3, en);

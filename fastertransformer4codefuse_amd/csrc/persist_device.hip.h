@@ -67,6 +67,19 @@ constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
 #ifndef PS_CTRL_EARLY
 #define PS_CTRL_EARLY 0
 #endif
+// Round 4.  PS_QKV_EARLY: every wave streams its slice of the QKV runs FIRST and its slice of the FFN1 runs after it (the first
+// form cut the flat [QKV | FFN1] tile space into contiguous shares: all runs ended together, q/k/v were published with mid at the
+// end of the stream and the attention waited 4.5 us for the slowest of its ~9 producer workgroups); the wave that flushes the
+// LAST QKV partial sums of the workgroup publishes q/k/v right there, from inside the stream, ~55 % of the stream before the
+// attention needs them: the hop disappears.  PS_KV_EARLY: the K rows of the workgroup's KV split are requested into register
+// batch R0 when its last batch has been consumed, the V rows into R1 after its last batch (two batches before the stream
+// ends): they land under the stream's tail and the epilogue instead of after it (26 MB per layer: 4 us at the full HBM rate).
+#ifndef PS_QKV_EARLY
+#define PS_QKV_EARLY 0
+#endif
+#ifndef PS_KV_EARLY
+#define PS_KV_EARLY 0
+#endif
 // PS_NF: register batches a wave keeps IN FLIGHT in the steady state (the fourth / third / second one has landed and
 // waits to be consumed).  Everything a compute unit has outstanding sits in ONE in-order return queue, and whatever the
 // chip has outstanding beyond bandwidth x unloaded latency only adds to the latency of every request -- the hand-off polls
@@ -215,6 +228,43 @@ __host__ __device__ inline void ps_wave_range_w(const int T, const int w, const 
     tb           = (int)((long)T * c0 / total) / PS_U * PS_U;
     te           = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
 }
+// PS_QKV_EARLY: the two slices of wave w -- [qb, qe) of the Tq tiles of the QKV runs, then [fb, fe) of the Tf tiles of the FFN1
+// runs, sized so that the waves' TOTALS follow the weights; slices start on batch boundaries
+__host__ __device__ inline void ps_wave_range2_w(const int Tq, const int Tf, const int w, const int* wt, int& qb, int& qe, int& fb,
+                                                 int& fe)
+{
+    int total = 0;
+    for (int i = 0; i < PS_NW; i++) {
+        total += wt[i];
+    }
+    total = total > 0 ? total : 1;
+    auto al   = [](long v) { return (int)(v / PS_U * PS_U); };
+    auto qend = [&](long c) { return c >= total ? Tq : al((long)Tq * c / total); };
+    auto fend = [&](long c) {
+        if (c >= total) {
+            return Tf;
+        }
+        long f = (long)(Tq + Tf) * c / total - qend(c);
+        f      = f < 0 ? 0 : (f > Tf ? Tf : f);
+        return al(f);
+    };
+    int c0 = 0;
+    for (int k = 0; k < PS_NW; k++) {  // flat order: waves PS_NC.. first, control waves last
+        const int i = (k + PS_NC) % PS_NW;
+        if (i == w) {
+            break;
+        }
+        c0 += wt[i];
+    }
+    const int c1 = c0 + wt[w];
+    qb = qend(c0);
+    qe = qend(c1);
+    fb = fend(c0);
+    fe = fend(c1);
+    if (fe < fb) {
+        fe = fb;
+    }
+}
 // table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
 template<typename NT>
 __host__ __device__ inline int ps_wave_entries(const int nruns, NT&& run_nt, const int tb, const int te)
@@ -250,6 +300,13 @@ template<bool INT8, int M, bool SIG = false>
 struct PsStream {
     static constexpr int TK = TileK<INT8>::value;
     int* sig = nullptr;  // SIG: LDS counter bumped after a PS_BT_SIGNAL batch
+    // PS_QKV_EARLY (first form of the kernel): the wave whose bump completes the workgroup's count publishes q/k/v
+    int             sig_full = 0;      // count that completes this layer
+    int             eq_n = 0;          // QKV runs of the workgroup x 16
+    const RunRec*   eq_rt = nullptr;   // their records (column group ids)
+    u64*            eq_g = nullptr;    // granule slab of q/k/v
+    unsigned        eq_tag = 0;
+    int             eq_hl3 = 0;        // 3 * Hl (row stride of the slab, halves)
     u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
     f32x4      acc;
     PsStage    g;
@@ -331,8 +388,33 @@ struct PsStream {
         }
         if constexpr (SIG) {
             if (bd & PS_BT_SIGNAL) {  // (DS operations of a wave execute in order: the flush above is visible first)
-                if (lane == 0) {
-                    atomicAdd(sig, 1);
+                if (eq_g == nullptr) {
+                    if (lane == 0) {
+                        atomicAdd(sig, 1);
+                    }
+                }
+                else {
+                    // the wave that completes the count has every wave's QKV partial sums in LDS (each bumped behind its own
+                    // flushes): q/k/v = y (no bias: the attention adds it, like the reference's) -> granules, from inside the stream
+                    int old = 0;
+                    if (lane == 0) {
+                        old = atomicAdd(sig, 1);
+                    }
+                    if (ps_rfl(old) + 1 == sig_full) {
+                        for (int idx = lane; idx < eq_n; idx += 64) {
+                            const int j = idx / (M * 16), r = idx % (M * 16), m = r >> 4, c = r & 15;
+                            float     v = 0.f;
+#pragma unroll
+                            for (int w = 0; w < PS_NW; w++) {
+                                v += part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                            }
+                            const unsigned b0 = f16_bits((f16)v);
+                            const unsigned b1 = next_lane_u32(b0);
+                            if ((c & 1) == 0) {
+                                st_granule_u32(eq_g + (((size_t)m * eq_hl3 + eq_rt[j].rid * 16 + c) >> 1), eq_tag, b0 | (b1 << 16));
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -408,6 +490,46 @@ struct PsStream {
         }
         consume(R0, last);
         consume(R1, last + 1);
+        consume(R2, last + 2);
+        consume(R3, last + 3);
+    }
+    // the same stream with two hooks in its tail: after0() runs when register batch R0 has been consumed for the last time,
+    // after1() when R1 has -- PS_KV_EARLY requests the K rows of the attention into R0 and the V rows into R1 there, two
+    // batches before the stream ends
+    template<bool HI, typename F0, typename F1>
+    __device__ __forceinline__ void run_hooked(F0&& after0, F1&& after1)
+    {
+        if constexpr (HI) {
+            prime_hi();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int last = (g.nrot - 1) * PS_NBUF;
+        for (int i = 0; i < last; i += PS_NBUF) {
+            consume(R0, i);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R0, i + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R1, i + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R2, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R2, i + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(R3, i + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            load(R3, i + 7);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        consume(R0, last);
+        __builtin_amdgcn_sched_barrier(0);
+        after0();
+        __builtin_amdgcn_sched_barrier(0);
+        consume(R1, last + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        after1();
+        __builtin_amdgcn_sched_barrier(0);
         consume(R2, last + 2);
         consume(R3, last + 3);
     }
@@ -491,14 +613,17 @@ __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 // attention of one (row b, head h, split sp) on the whole 8-wave workgroup
 // (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.hip.h::mmha_partial)
 // ---------------------------------------------------------------------------------------------------------------
-template<int DH, int UK, int NSW = 3 * DH / 2>
+// A8 (PS_KV_EARLY, UK == PS_U): the rows live in the stream's register batches too -- K in R0, V in R1 -- requested from inside
+// the first stream's tail (issue_k / issue_v) instead of after it
+template<int DH, int UK, int NSW = 3 * DH / 2, bool A8 = false>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
     static constexpr int NQ  = 3 * DH / 2;             // q | k | v granules (pairs of halves) of one head
     static constexpr int NB2 = (NQ + NSW - 1) / NSW;   // granules per sweeping thread (NSW threads sweep)
     static constexpr int KPI = 64 / LPK;
-    static constexpr bool ALIAS = UK > PS_U;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
+    static constexpr bool ALIAS = UK > PS_U || A8;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
     static_assert(UK <= 2 * PS_U, "K rows live in R0|R1, V rows in R2|R3");
+    static_assert(!A8 || UK == PS_U, "A8: one register batch of K rows, one of V rows");
     u32x4 kreg[ALIAS ? 1 : UK], vreg[ALIAS ? 1 : UK];
     template<typename ST>
     __device__ __forceinline__ u32x4& kr(ST& st, const int u)
@@ -513,11 +638,39 @@ struct PsAttn {
     template<typename ST>
     __device__ __forceinline__ u32x4& vr(ST& st, const int u)
     {
-        if constexpr (ALIAS) {
+        if constexpr (A8) {
+            return st.R1[u];
+        }
+        else if constexpr (ALIAS) {
             return u < PS_U ? st.R2[u % PS_U] : st.R3[u % PS_U];
         }
         else {
             return vreg[u];
+        }
+    }
+    // A8: the rows alone, K and V apart (the masks, lengths, rotary coefficients and bias follow with issue_impl<false>)
+    template<bool VROWS, typename ST>
+    __device__ __forceinline__ void issue_rows(const PersistParams& p, PsLayerC& lw, int h, int b, int sp, const int tx, ST& st,
+                                               const bool item)
+    {
+        const int lane = tx & 63, wid = tx >> 6;
+        const int sub = lane % LPK, grp = lane / LPK;
+        const int ck = (((p.s_max + p.plan.nsplit - 1) / p.plan.nsplit) + 15) & ~15;
+        const int tb = sp * ck;
+        const auto* rc = PS_G(f16, VROWS ? lw.v_cache : lw.k_cache) + ((size_t)b * p.nh + h) * p.s_max * DH;
+        int t_last = tb + ck - 1;
+        t_last     = t_last < p.s_max ? t_last : p.s_max - 1;
+        t_last     = item ? t_last : tb;
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+            int t = tb + u * PS_NW * KPI + wid * KPI + grp;
+            t     = t < t_last ? t : t_last;
+            if constexpr (VROWS) {
+                vr(st, u) = *PS_G(u32x4, rc + (size_t)t * DH + sub * 8);
+            }
+            else {
+                kr(st, u) = *PS_G(u32x4, rc + (size_t)t * DH + sub * 8);
+            }
         }
     }
     unsigned mask_bits, bias2[NB2];
@@ -1470,6 +1623,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             s.misc[34] = 0;  // A3: streamer-wave barrier (+(PS_NW - PS_NC) per layer)
             s.misc[35] = 0;  // A3: control-wave barrier inside the attention
             s.misc[39] = 0;  // control pair barrier of the partials' sweep (PS_MERGE_V2)
+            s.misc[36] = 0;  // PS_QKV_EARLY: waves that have flushed their QKV slice (+ per layer)
+            s.misc[37] = 0;  // PS_QKV_EARLY: waves without a QKV slice
         }
         __syncthreads();
         if ((int)threadIdx.x < nruns1) {  // P1: QKV column groups q0..q1, then FFN1 column groups f0..f1, full K each
@@ -1553,14 +1708,40 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             ctx_hi = ps_rfl(ctx_hi);
             const int w = ps_rfl(wid);
             int       tb, te;
-            ps_wave_range_w(T1, w, p.plan.wt1, tb, te);
-            int ent  = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
-            sg1.lt   = s.lt1 + (size_t)w * E1;
-            sg1.bt   = s.bt1 + (size_t)w * (E1 / PS_U);
-            sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
-            sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
-            ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
-                                sg1.nrot * PS_U * PS_NBUF);
+            int ent;
+            sg1.lt = s.lt1 + (size_t)w * E1;
+            sg1.bt = s.bt1 + (size_t)w * (E1 / PS_U);
+            if constexpr (PS_QKV_EARLY != 0) {
+                // this wave's slice of the QKV runs first, then its slice of the FFN1 runs; the batch that flushes its last QKV
+                // partial sum carries PS_BT_SIGNAL (a wave without QKV tiles is counted in misc[37] instead)
+                int qa, qz, fa2, fz;
+                ps_wave_range2_w(nq * KT, (f1 - f0) * KT, w, p.plan.wt1, qa, qz, fa2, fz);
+                auto      ntk = [&](int) { return KT; };
+                const int eq  = ps_wave_entries(nq, ntk, qa, qz);
+                ent           = eq + ps_wave_entries(f1 - f0, ntk, fa2, fz);
+                sg1.nrot      = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+                sg1.nrot      = sg1.nrot < 1 ? 1 : sg1.nrot;
+                unsigned* lt  = s.lt1 + (size_t)w * E1;
+                unsigned* bt  = s.bt1 + (size_t)w * (E1 / PS_U);
+                ps_build_tables<TK>(s.rt1, nq, qa, qz, lt, bt, eq, 0);
+                ps_build_tables<TK>(s.rt1 + nq, f1 - f0, fa2, fz, lt + eq, bt + eq / PS_U, sg1.nrot * PS_U * PS_NBUF - eq, nq);
+                if ((threadIdx.x & 63) == 0) {
+                    if (eq > 0) {
+                        bt[eq / PS_U - 1] |= PS_BT_SIGNAL;  // (the builder's lanes wrote it: same wave, DS order)
+                    }
+                    else {
+                        atomicAdd(&s.misc[37], 1);
+                    }
+                }
+            }
+            else {
+                ps_wave_range_w(T1, w, p.plan.wt1, tb, te);
+                ent      = ps_wave_entries(nruns1, [&](int j) { return s.rt1[j].nt; }, tb, te);
+                sg1.nrot = (ent + PS_U * PS_NBUF - 1) / (PS_U * PS_NBUF);
+                sg1.nrot = sg1.nrot < 1 ? 1 : sg1.nrot;
+                ps_build_tables<TK>(s.rt1, nruns1, tb, te, s.lt1 + (size_t)w * E1, s.bt1 + (size_t)w * (E1 / PS_U),
+                                    sg1.nrot * PS_U * PS_NBUF);
+            }
             ps_wave_range_w(T3, w, p.plan.wt3, tb, te);
             ent      = ps_wave_entries(nruns3, [&](int j) { return s.rt3[j].nt; }, tb, te);
             sg3.lt   = s.lt3 + (size_t)w * E3;
@@ -1618,7 +1799,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     auto body = [&](auto role) {
         constexpr bool    CTRL = decltype(role)::value;
         int               tid  = threadIdx.x;
-        PsStream<INT8, M> st;
+        PsStream<INT8, M, PS_QKV_EARLY != 0> st;
+        const int n_sig = PS_NW - ps_rfl(s.misc[37]);  // (PS_QKV_EARLY) waves that flush QKV partial sums
         auto stamp = [&](const int l, const int k) {
             const int lane = tid & 63, wid = tid >> 6;
             if (p.ts && lane == 0) {
@@ -1727,6 +1909,15 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             sg1.w0 = reinterpret_cast<const char*>(lw.w_qkv);
             sg1.w1 = reinterpret_cast<const char*>(lw.w_ffn1);
             st.bind(sg1, s.rsc, s.xs, s.part, tid);
+            if constexpr (PS_QKV_EARLY != 0) {
+                st.sig      = &s.misc[36];
+                st.sig_full = (l - p.l_begin + 1) * n_sig;
+                st.eq_n     = nq * M * 16;
+                st.eq_rt    = s.rt1;
+                st.eq_g     = p.gq;
+                st.eq_tag   = tag_base + (unsigned)l;
+                st.eq_hl3   = 3 * Hl;
+            }
             if constexpr (!CTRL) {
                 st.prime_lo();
                 if constexpr (PS_FULL_P1) {
@@ -1756,6 +1947,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
             sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
             st.bind(sg3, (A3 || PART3) ? s.rsc3 : s.rsc, s.xs, s.part3, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
+            if constexpr (PS_QKV_EARLY != 0) {
+                st.eq_g = nullptr;  // (P3's tables carry no PS_BT_SIGNAL)
+            }
         };
 
         load_sc1(p.l_begin);
@@ -1781,6 +1975,13 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             const bool i_has = bid < n_items;
             const int  i_sp = i_has ? bid % p.plan.nsplit : 0;
             const int  i_h = i_has ? (bid / p.plan.nsplit) % p.nh : 0, i_b = i_has ? (bid / p.plan.nsplit) / p.nh : 0;
+            // PS_KV_EARLY: the attention's K/V rows are requested from inside the first stream's tail into R0 / R1
+            constexpr bool KVE = PS_KV_EARLY != 0 && UK == PS_U && !A3 && !P3L && PS_EARLY_P3 == 0;
+            using AttnE = PsAttn<DH, UK, 3 * DH / 2, KVE>;
+            AttnE      ate;
+            const bool e_has = bid < n_items;
+            const int  e_sp = e_has ? bid % p.plan.nsplit : 0;
+            const int  e_h = e_has ? (bid / p.plan.nsplit) % p.nh : 0, e_b = e_has ? (bid / p.plan.nsplit) / p.nh : 0;
             stamp(l, 0);
             // =========================== S0: layer input -> xraw (control waves) =================================
             if constexpr (CTRL) {
@@ -1859,7 +2060,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 }
                 stamp(l, 2);
                 __syncthreads();
-                st.template run<CTRL || !PS_FULL_P1>();
+                if constexpr (KVE) {
+                    st.template run_hooked<CTRL || !PS_FULL_P1>(
+                        [&]() { ate.template issue_rows<false>(p, lw, e_h, e_b, e_sp, tid, st, e_has); },
+                        [&]() { ate.template issue_rows<true>(p, lw, e_h, e_b, e_sp, tid, st, e_has); });
+                }
+                else {
+                    st.template run<CTRL || !PS_FULL_P1>();
+                }
                 if constexpr (A3F && CTRL && !PS_A3_KV_LATE) {
                     at3.issue_ctrl(p, lw, i_h, i_b, i_sp, tid, st,
                                    (unsigned)(size_t)(__attribute__((address_space(3))) char*)s.kbuf, i_has);
@@ -1878,6 +2086,9 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                             v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
                         }
                         const int cg = s.rt1[j].rid;
+                        if (PS_QKV_EARLY != 0 && cg < NT0) {
+                            continue;  // (published from inside the stream by the wave that flushed the last QKV partial sum)
+                        }
                         f16       o;
                         if (cg < NT0) {
                             o = (f16)v;
@@ -1916,8 +2127,16 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             asm volatile("" : "+v"(tid));
             // (EARLY: see PS_EARLY_P3; the long form's K/V rows occupy the register batches)
             constexpr int EARLY = (UK > PS_U) ? 0 : PS_EARLY_P3;
-            using Attn          = PsAttn<DH, UK, (EARLY || A3F) ? PS_NC * 64 : 3 * DH / 2>;
-            Attn       at;
+            using Attn          = typename std::conditional<KVE, AttnE, PsAttn<DH, UK, (EARLY || A3F) ? PS_NC * 64 : 3 * DH / 2>>::type;
+            Attn       at_own;
+            Attn&      at = [&]() -> Attn& {
+                if constexpr (KVE) {
+                    return ate;
+                }
+                else {
+                    return at_own;
+                }
+            }();
             const bool has_item = bid < n_items;
             int        a_sp = 0, a_h = 0, a_b = 0;
             if (has_item) {
@@ -1933,7 +2152,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             stamp(l, 5);
             bool live = false;
             u64* gall = p.ga + ((size_t)a_b * p.nh + a_h) * p.plan.nsplit * (DH + 2);
-            if constexpr (Attn::ALIAS) {
+            if constexpr (KVE) {
+                // (the rows were requested in the first stream's tail; masks, lengths, rotary coefficients, bias follow here)
+                at.template issue_impl<false>(p, lw, a_h, a_b, a_sp, tid, st, has_item);
+            }
+            else if constexpr (Attn::ALIAS) {
                 // (rows in the stream's register batches: requested UNCONDITIONALLY -- a workgroup without an item reads
                 // item 0's rows for nothing -- because registers assigned under a condition carry their previous contents,
                 // here all four weight batches, around the layer loop: 30 spilled VGPRs)

@@ -350,3 +350,64 @@ def test_decode_steps_inside_an_admission_use_the_running_slots_sampling_paramet
     out = cb.run_all()
     assert out[rid2] == alone, (out[rid2], alone)
     assert len(out[g1]) <= 6 and g0 in out
+
+
+@pytest.mark.parametrize("tp,max_batch", [(2, 3), (2, 6), (4, 3)])
+def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch):
+    """Tensor parallelism inside the batcher (round 4; the reference's serving layer runs TP through its Triton backend,
+    triton_backend/gptneox/GptNeoXTritonModelInstance.cc): one batcher per rank over its shard, fed the same requests in the
+    same order -- the schedulers take identical decisions, the decode step's per-layer all-reduce and the vocabulary-split LM
+    head are the engine's collectives.  The ranks are threads of a local group on this one GPU (tests/test_gpu_tp_local.py);
+    every rank must emit the same events, and every request what the TP = 1 engine generates for it alone."""
+    import threading
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    from fastertransformer4codefuse_amd.gptneox_op import LocalTensorParallelGroup
+    from tests.helpers import shard_weights
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    rng = np.random.RandomState(8)
+    prompts = [z["prompt"].tolist(), z["prompt_b"].tolist(), z["prompt"][:5].tolist(), rng.randint(3, V, size=21).tolist(),
+               z["prompt_1"].tolist(), rng.randint(3, V, size=9).tolist()]
+    new = [8, 6, 11, 9, 5, 7]
+    op1 = gh.make_op(cfg, w)
+    ref = [_alone(gh, op1, p, n, V, end_id)[0] for p, n in zip(prompts, new)]
+    del op1
+    arrivals = {0: [0, 1], 2: [2, 3], 3: [4], 7: [5]}
+    group = LocalTensorParallelGroup()
+    res, err = [None] * tp, []
+    gate = threading.Barrier(tp)
+
+    def worker(r):
+        try:
+            op = gh.make_op(cfg, shard_weights(cfg, w, tp, r), tp=tp, rank=r, comm=group)
+            cb = ContinuousBatcher(op, max_batch=max_batch, page_tokens=8, num_pages=32, max_seq_len=64)
+            free0 = cb.status()["free_pages"]
+            events, ids, it, pending = [], {}, 0, dict(arrivals)
+            while pending or cb.busy():
+                for k in pending.pop(it, []):
+                    ids[cb.submit(prompts[k], new[k])] = k
+                gate.wait(timeout=120)  # (the ranks step together, like the ranks of a serving job)
+                events.append([(ids[rid], tok, fin) for rid, tok, fin in cb.step()])
+                it += 1
+                assert it < 2000
+            assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+            res[r] = events
+        except BaseException as e:  # noqa: BLE001
+            err.append((r, repr(e)))
+            gate.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(tp)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=400)
+    assert not err, err
+    assert all(x is not None for x in res), "a rank did not finish (stuck in a collective?)"
+    for r in range(1, tp):
+        assert res[r] == res[0], f"rank {r} saw different events"
+    got = {}
+    for evs in res[0]:
+        for k, tok, fin in evs:
+            got.setdefault(k, []).append(tok)
+    for k in range(len(prompts)):
+        assert got[k] == ref[k], (k, got[k], ref[k])
