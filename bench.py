@@ -387,6 +387,13 @@ def main():
                             "layer_allreduce": ("none" if tp == 1 else
                                                 "in-kernel exchange windows (peer-mapped, xGMI stores)"
                                                 if st["decode_path"] == 1 else "ncclAllReduce per layer"),
+                            # prompt phase: FTCF_PREFILL_OVERLAP unset = decided from data on THIS node (engine.hip
+                            # context_decoder_overlapped: one plain and one overlapped prompt phase are timed, the faster form stays)
+                            "prefill_overlap": {"mode": os.environ.get("FTCF_PREFILL_OVERLAP", "auto" if world > 1 else "off"),
+                                                "ran_in_the_last_request": bool(st.get("prefill_overlap", 0)),
+                                                "trial_ms_plain": st.get("prefill_ms_plain", 0.0),
+                                                "trial_ms_overlapped": st.get("prefill_ms_overlapped", 0.0)},
+                            "prompt_phase_allreduces_through_windows": st.get("window_allreduces", 0),
                             "fallback": fallback_note},
     }
     if a.fake_tp > 1:

@@ -127,6 +127,13 @@ struct ftcf_comm {
     std::vector<void*>          win;
     size_t                      win_bytes = 0;
     bool                        win_ok = false, win_tried = false;
+    // RCCL-free all-reduce of the prompt phase's messages through the same windows (k_window_allreduce): behind the granule
+    // area of the decode exchange lie 16 flags and four message buffers ([call parity][input | reduced], ar_cap bytes each)
+    size_t                      ar_flag_off = 0, ar_data_off = 0, ar_cap = 0;
+    unsigned                    ar_seq = 0;       // calls so far (every rank calls in the same order)
+    int*                        ar_sync = nullptr;  // device: two arrival counters + the sticky give-up word
+    bool                        ar_failed = false;
+    int                         ar_nb = 0;        // grid of the launches so far (the arrival counters count in its units)
 };
 
 #define FTCF_NCCL_CHECK(expr)                                                                                          \
@@ -408,6 +415,169 @@ __global__ void k_window_handshake(unsigned long long* const* win, int world, in
     if (!ok) {
         atomicExch(result, 0);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-shot all-reduce over the peer-mapped exchange windows (the reference's twoShotAllReduceKernel,
+// kernels/custom_ar_kernels.cu:202-260, for the messages its one-shot form is too small for): no RCCL call, no host in the
+// loop -- one launch per rank.
+//   A  copy x into the own window (buffer of this call's parity); the last workgroup to finish tells every peer (flag A)
+//   B  when every rank's flag A shows this call: reduce-scatter -- rank r adds chunk r of all ranks' inputs IN RANK ORDER in
+//      fp32, rounds once (the sum every rank would compute: the same bits everywhere), writes it to its window's result
+//      buffer and to x; the last workgroup tells every peer (flag B)
+//   C  when every flag B shows this call: all-gather -- chunk c comes from rank c's result buffer
+// Two parities of buffers: a peer can be at most one call behind (it posts its input of call k only after it has finished call
+// k - 1, and call k - 1 here needed that input), so the buffers of call k - 2 are free when call k overwrites them.  Flags carry
+// the call number (monotone, never reset while the window lives).  Every spin is bounded and reports through a sticky word.
+// ---------------------------------------------------------------------------------------------------------------------
+struct WinArParams {
+    unsigned long long* win[8];  // every rank's window as this rank addresses it
+    int                 tp, rank;
+    f16*                x;
+    size_t              count;  // halves, a multiple of 8 * tp
+    size_t              flag_off, data_off, cap;  // bytes
+    unsigned            seq;
+    int*                sync;  // [0] arrivals of step A, [1] of step B (monotone), [2] give-up word
+    long long           limit_ticks;
+};
+
+__device__ __forceinline__ bool winar_wait(const WinArParams& p, const size_t slot0, const long long t0)
+{
+    // lanes 0..tp-1 of every workgroup's first wave poll the tp flags of the OWN window
+    bool ok = true;
+    if ((int)threadIdx.x < p.tp) {
+        const auto* f = (const __attribute__((address_space(1))) unsigned long long*)(reinterpret_cast<char*>(p.win[p.rank]) + p.flag_off)
+                        + slot0 + threadIdx.x;
+        for (;;) {
+            if ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == p.seq) {
+                break;
+            }
+            if (wall_clock64() - t0 > p.limit_ticks
+                || __hip_atomic_load((__attribute__((address_space(1))) int*)&p.sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) {
+            __hip_atomic_store((__attribute__((address_space(1))) int*)&p.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return __syncthreads_and(ok ? 1 : 0) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_window_allreduce(const WinArParams p)
+{
+    typedef unsigned long long   u64;
+    typedef __attribute__((address_space(1))) u64 gu64;
+    const long long t0   = wall_clock64();
+    const int       par  = (int)(p.seq & 1u);
+    const size_t    n8   = p.count / 8, c8 = n8 / p.tp;  // 16-byte vectors in all / per chunk
+    char*           mine = reinterpret_cast<char*>(p.win[p.rank]);
+    u32x4*          X    = reinterpret_cast<u32x4*>(mine + p.data_off + (size_t)par * 2 * p.cap);
+    u32x4*          R    = reinterpret_cast<u32x4*>(mine + p.data_off + (size_t)par * 2 * p.cap + p.cap);
+    u32x4*          x8   = reinterpret_cast<u32x4*>(p.x);
+    const size_t    gsz  = (size_t)gridDim.x * blockDim.x, gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto tell = [&](const int which, const int arrivals_slot) {
+        // the last workgroup of this rank to arrive stores the call number into slot [rank] of every rank's flag array
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = atomicAdd(&p.sync[arrivals_slot], 1);
+            if ((unsigned)(old + 1) == p.seq * gridDim.x) {
+                for (int r = 0; r < p.tp; r++) {
+                    gu64* f = (gu64*)(reinterpret_cast<char*>(p.win[r]) + p.flag_off) + (size_t)which * 8 + p.rank;
+                    __hip_atomic_store(f, (u64)p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    };
+    // ---- A: the input into the own window ----
+    for (size_t i = gid; i < n8; i += gsz) {
+        X[i] = x8[i];
+    }
+    tell(0, 0);
+    // ---- B: reduce-scatter of chunk [rank] ----
+    if (!winar_wait(p, 0, t0)) {
+        return;
+    }
+    for (size_t i = gid; i < c8; i += gsz) {
+        const size_t at = (size_t)p.rank * c8 + i;
+        float        acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < p.tp; r++) {  // rank order: the same sum on every rank
+            const gu64* src = (const gu64*)(reinterpret_cast<char*>(p.win[r]) + p.data_off + (size_t)par * 2 * p.cap) + at * 2;
+            const u64   lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const u64   hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const u32x4 v  = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+            const f16x8 h  = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                acc[e] += (float)h[e];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            o[e] = (f16)acc[e];
+        }
+        const u32x4 ov = __builtin_bit_cast(u32x4, o);
+        R[at]  = ov;
+        x8[at] = ov;
+    }
+    tell(1, 1);
+    // ---- C: all-gather of the other ranks' chunks ----
+    if (!winar_wait(p, 8, t0)) {
+        return;
+    }
+    for (int k = 1; k < p.tp; k++) {
+        const int   c   = (p.rank + k) % p.tp;  // (every rank starts at another peer)
+        const gu64* src = (const gu64*)(reinterpret_cast<char*>(p.win[c]) + p.data_off + (size_t)par * 2 * p.cap + p.cap);
+        for (size_t i = gid; i < c8; i += gsz) {
+            const size_t at = (size_t)c * c8 + i;
+            const u64    lo = __hip_atomic_load(src + at * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const u64    hi = __hip_atomic_load(src + at * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            x8[at]          = u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        }
+    }
+}
+
+// true when the all-reduce went through the windows (else the caller uses its collective)
+static bool window_allreduce(ftcf_comm* c, f16* buf, size_t count, hipStream_t s)
+{
+    static const int on = getenv("FTCF_TP_WINAR") ? atoi(getenv("FTCF_TP_WINAR")) : 1;
+    // (not in a local group: its ranks are streams of ONE process on one device, and streams that share a hardware queue run
+    // their kernels one after the other -- a rank's kernel would wait for a peer's that cannot start: 2 s, give up, replay)
+    if (!on || c->local || !c->win_ok || c->ar_failed || c->ar_cap == 0 || c->world < 2 || c->world > 8 || count % ((size_t)8 * c->world) != 0
+        || count * 2 > c->ar_cap || count * 2 < (size_t)64 * 1024) {
+        return false;  // (small messages: the decode path has its own in-kernel exchange; RCCL / the emulation otherwise)
+    }
+    if (!c->ar_sync) {
+        FTCF_HIP_CHECK(hipMalloc((void**)&c->ar_sync, 64));
+        FTCF_HIP_CHECK(hipMemsetAsync(c->ar_sync, 0, 64, s));
+    }
+    // workgroups per rank: every rank's grid must be resident together with its peers' (ranks sharing one device -- the local
+    // group, two test processes -- split the compute units) and next to a GEMM on another stream
+    static const int nb_env = getenv("FTCF_TP_WINAR_NB") ? atoi(getenv("FTCF_TP_WINAR_NB")) : 0;
+    const int        shared = (c->local || c->hx) ? c->world : 1;
+    const int        nb     = nb_env > 0 ? nb_env : std::max(8, 128 / shared);
+    WinArParams      p{};
+    for (int r = 0; r < c->world; r++) {
+        p.win[r] = static_cast<unsigned long long*>(c->win[r]);
+    }
+    p.tp          = c->world;
+    p.rank        = c->rank;
+    p.x           = buf;
+    p.count       = count;
+    p.flag_off    = c->ar_flag_off;
+    p.data_off    = c->ar_data_off;
+    p.cap         = c->ar_cap;
+    p.seq         = ++c->ar_seq;
+    p.sync        = c->ar_sync;
+    p.limit_ticks = (long long)200000000;  // 100 MHz ticks: 2 s
+    hipLaunchKernelGGL(k_window_allreduce, dim3(nb), dim3(256), 0, s, p);
+    FTCF_HIP_CHECK(hipGetLastError());
+    c->ar_nb = nb;
+    return true;
 }
 
 static void comm_barrier(ftcf_comm* c, hipStream_t s, int* d_scratch)
@@ -1340,6 +1510,10 @@ struct ftcf_gptneox {
             Range r("ftcf.allreduce");
             hipStream_t st = on ? on : stream;
             FTCF_CHECK_ARG(cfg.comm && (cfg.comm->comm || cfg.comm->local || cfg.comm->hx), "tensor_para_size > 1 needs a communicator");
+            if (window_allreduce(cfg.comm, buf, count, st)) {
+                stats.window_allreduces++;
+                return;  // through the peer-mapped windows: no RCCL call (prompt-phase messages; k_window_allreduce)
+            }
             if (cfg.comm->local) {
                 local_allreduce(cfg.comm, buf, count, true, st);
                 return;
@@ -1519,16 +1693,35 @@ struct ftcf_gptneox {
     }
 
     hipEvent_t ov_done[2] = {nullptr, nullptr}, ov_red[2] = {nullptr, nullptr};
+    int        ov_trial = 0;             // auto mode: 0 the next eligible prompt phase runs plain, 1 overlapped, 2 decided
+    float      ov_ms[2] = {0.f, 0.f};    // ... what the two trials took (the slowest rank's time)
+    bool       ov_ran = false, ov_eligible = false;  // this request: ran overlapped / counts as a trial
     bool context_decoder_overlapped(int B, int S, const int* input_lengths, int s_max)
     {
         // OPT-IN (FTCF_PREFILL_OVERLAP=1; read per request, the tests flip it): on the one GPU the builder has, one rank's shard of
         // the 1024-token prompt phase takes 19.1 -> 27.6 ms (TP 2) / 10.3 -> 18.3 ms (TP 8) in two micro-batches -- GEMMs of 512
         // rows fill the chip worse than GEMMs of 1024 (profiles/r03_faketp_prefill.txt) -- and what the overlap hides (40 all-reduces
         // of 10 MiB over xGMI) cannot be measured without the peers.  Whoever has the node should measure both.
-        const int env = getenv("FTCF_PREFILL_OVERLAP") ? atoi(getenv("FTCF_PREFILL_OVERLAP")) : 0;
+        // Round 4: DECIDED FROM DATA on the node it runs on.  FTCF_PREFILL_OVERLAP = 0 / 1 forces it; unset or "auto" (the
+        // default for ranks joined by RCCL, i.e. a real multi-GPU job): the first eligible prompt phase of at least 512 tokens
+        // runs plain and is timed, the second one overlapped, every rank learns the slower rank's times (comm_max) and the
+        // engine keeps the faster form; ftcf_forward_stats says what ran and what the two trials took.
+        const char* ev  = getenv("FTCF_PREFILL_OVERLAP");
+        const bool  aut = (!ev || !strcmp(ev, "auto")) && cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->comm && !cfg.comm->local
+                         && !cfg.comm->hx && cfg.comm->world > 1;
+        const int   env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
         static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;
-        if (!env || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side || valu_form) {
+        ov_ran      = false;
+        ov_eligible = false;
+        if ((!env && !aut) || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side || valu_form) {
             return false;
+        }
+        if (aut) {
+            ov_eligible = (long)B * S >= 512 && (B >= 2 || (S / 2) / 64 * 64 >= 64);
+            const bool want = ov_eligible && (ov_trial == 1 || (ov_trial == 2 && ov_ms[1] < ov_ms[0]));
+            if (!want) {
+                return false;
+            }
         }
         // micro-batches: rows [r0[c], r1[c]) of the [B * S] row space; sequences [b0, b1) x tokens [s0, s1)
         int b0[2] = {0, 0}, b1[2] = {B, B}, s0[2] = {0, 0}, s1[2] = {S, S};
@@ -1543,6 +1736,7 @@ struct ftcf_gptneox {
             s1[0] = s0[1] = cut;
         }
         Range r("ftcf.GptNeoXContextDecoder.overlapped");
+        ov_ran = true;
         bind_layers();
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         for (int c = 0; c < 2; c++) {
@@ -2066,6 +2260,7 @@ struct ftcf_gptneox {
     int  step(int max_steps);
     void finish();
     bool persist_failed = false;  // the persistent kernel gave up on a hand-off during the last request
+    bool winar_failed = false;    // ... or the exchange-window all-reduce of the prompt phase did
     int  persist_fail_once = 0;
     void forward(const ftcf_forward_args& a)
     {
@@ -2075,6 +2270,15 @@ struct ftcf_gptneox {
             finish();
         }
         catch (const Error&) {
+            if (winar_failed && !persist_failed) {
+                winar_failed = false;
+                FT_LOG_WARNING(cfg.device, "exchange-window all-reduce gave up: replaying the request with the communicator's own "
+                                           "all-reduce (it stays there)");
+                begin(a);
+                step(a.output_len);
+                finish();
+                return;
+            }
             if (!persist_failed) {
                 throw;
             }
@@ -2133,6 +2337,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     FTCF_CHECK_ARG(K >= 1 && K <= BEAM_MAX_K, "beam_width must be in [1, 64]");
     FTCF_HIP_CHECK(hipSetDevice(cfg.device));
     abandon_session();  // (a request left open -- begin / step without finish, or a step that threw -- must not leak its graph)
+    stats.window_allreduces = 0;
     // everything the caller enqueued on its stream (input tensors) happens-before the engine's work
     FTCF_HIP_CHECK(hipEventRecord(ev_user, user_stream));
     FTCF_HIP_CHECK(hipStreamWaitEvent(stream, ev_user, 0));
@@ -2141,10 +2346,28 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     ses.K = K;  // (decoder path selection reads it)
     const int  tpn     = cfg.tensor_para_size;
     const bool want_tp = tpn > 1 && persist && persist_tp && K == 1 && B <= 2 && cfg.use_gptj_residual && tpn <= PERSIST_MAX_TP;
-    if (want_tp) {
+    // message buffers of the RCCL-free prompt-phase all-reduce (k_window_allreduce) behind the granules of the decode exchange
+    static const int winar_on = getenv("FTCF_TP_WINAR") ? atoi(getenv("FTCF_TP_WINAR")) : 1;
+    static const int winar_mb = getenv("FTCF_TP_WINAR_MB") ? atoi(getenv("FTCF_TP_WINAR_MB")) : 16;
+    const bool want_ar = tpn > 1 && tpn <= 8 && winar_on && !fp32 && cfg.comm && !cfg.comm->local && !cfg.comm->ar_failed;
+    if (want_tp || want_ar) {
         // (collective: every rank sees the same request shape) room for two rows: [tp][2 * H / 2] granules
-        // (two planes by layer parity: persist_device.hip.h ps_tp_exchange)
-        comm_ensure_window(cfg.comm, (size_t)2 * tpn * H * 8, stream);
+        // (two planes by layer parity: persist_device.hip.h ps_tp_exchange), then 16 flags, then four message buffers
+        const size_t gran = ((size_t)2 * tpn * H * 8 + 4095) & ~(size_t)4095;
+        const size_t cap  = want_ar ? (size_t)std::max(1, winar_mb) << 20 : 0;
+        const bool   had  = cfg.comm->win_ok && cfg.comm->win_bytes >= gran + 4096 + 4 * cap;
+        comm_ensure_window(cfg.comm, gran + 4096 + 4 * cap, stream);
+        if (cfg.comm->win_ok && cfg.comm->win_bytes >= gran + 4096 + 4 * cap && cap > 0 && (!had || cfg.comm->ar_cap != cap)) {
+            cfg.comm->ar_flag_off = gran;  // (a fresh window is zero: the call numbers start over)
+            cfg.comm->ar_data_off = gran + 4096;
+            cfg.comm->ar_cap      = cap;
+            if (!had) {
+                cfg.comm->ar_seq = 0;
+                if (cfg.comm->ar_sync) {
+                    FTCF_HIP_CHECK(hipMemsetAsync(cfg.comm->ar_sync, 0, 64, stream));
+                }
+            }
+        }
     }
     plan(B, S, total, K);
     if (want_tp && pplan.ok) {
@@ -2594,6 +2817,18 @@ void ftcf_gptneox::finish()
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ses.e0, ses.e1));
     stats.prefill_ms   = ms;
     stats.decode_steps = ses.steps;
+    if (ov_eligible && ov_trial < 2) {  // a trial of the auto mode: every rank keeps the slowest rank's time
+        const int us   = comm_max(cfg.comm, (int)(ms * 1000.f), stream, tp_scratch);
+        ov_ms[ov_trial] = us * 1e-3f;
+        ov_trial++;
+        if (ov_trial == 2) {
+            FT_LOG_INFO(cfg.device, "prompt-phase all-reduce overlap (auto): plain %.2f ms, overlapped %.2f ms -> %s", ov_ms[0], ov_ms[1],
+                        ov_ms[1] < ov_ms[0] ? "overlapped from now on" : "plain from now on");
+        }
+    }
+    stats.prefill_overlap        = ov_ran ? 1 : 0;
+    stats.prefill_ms_plain       = ov_ms[0];
+    stats.prefill_ms_overlapped  = ov_ms[1];
     event_pool.push_back(ses.e0);
     event_pool.push_back(ses.e1);
     ses.e0 = ses.e1 = nullptr;
@@ -2623,6 +2858,21 @@ void ftcf_gptneox::finish()
     }
     if (pplan.ok && cfg.tensor_para_size > 1) {
         ps_error = comm_max(cfg.comm, ps_error, stream, tp_scratch);  // every rank learns of any rank's failure
+    }
+    if (cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->ar_seq > 0 && !cfg.comm->ar_failed) {
+        // the window all-reduce's sticky give-up word (a peer that never arrived: its bounded waits ran out), agreed on
+        int ar_err = 0;
+        FTCF_HIP_CHECK(hipMemcpy(&ar_err, cfg.comm->ar_sync + 2, sizeof(int), hipMemcpyDeviceToHost));
+        if (!tp_scratch) {
+            FTCF_HIP_CHECK(hipMalloc((void**)&tp_scratch, 256));
+            FTCF_HIP_CHECK(hipMemsetAsync(tp_scratch, 0, 256, stream));
+        }
+        ar_err = comm_max(cfg.comm, ar_err, stream, tp_scratch);
+        if (ar_err != 0) {
+            cfg.comm->ar_failed = true;  // this communicator keeps RCCL (or the emulation) for the prompt phase from now on
+            winar_failed        = true;
+            throw Error(-2, "exchange-window all-reduce gave up waiting for a peer (its kernel was not running next to this one)");
+        }
     }
     if (smallm_error != 0) {
         throw Error(-2, "batched decode GEMM: a split-K reducer gave up waiting for its sibling workgroups' partial sums");

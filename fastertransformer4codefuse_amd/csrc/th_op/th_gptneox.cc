@@ -272,6 +272,10 @@ public:
         d["gemv_bytes"]    = s.gemv_bytes;
         d["gemv_kind"]     = s.gemv_kind;
         d["decode_path"]   = s.decode_path;
+        d["prefill_overlap"]       = s.prefill_overlap;
+        d["prefill_ms_plain"]      = s.prefill_ms_plain;
+        d["prefill_ms_overlapped"] = s.prefill_ms_overlapped;
+        d["window_allreduces"]     = s.window_allreduces;
         return d;
     }
 

@@ -208,6 +208,14 @@ typedef struct {
                               3 MMHA||FFN1, 4 persistent decode layers, 5 batched-decode burst GEMM pair */
     int   decode_path;     /* decoder of the last request: 0 per-stage launches, 1 persistent layers (one launch per
                               token, or per layer with tensor parallelism), 2 general (batched GEMM) path */
+    /* tensor parallel, prompt phase: did the last request run its per-layer all-reduce on the side stream under the other
+     * micro-batch's GEMMs (FTCF_PREFILL_OVERLAP = 1, or chosen by the auto mode), and what the auto mode's two timed trials
+     * took (plain / overlapped, ms, the slowest rank's; 0 until that trial has run) */
+    int   prefill_overlap;
+    float prefill_ms_plain, prefill_ms_overlapped;
+    /* all-reduces of the last request that went through the peer-mapped exchange windows instead of RCCL (the two-shot kernel
+     * for prompt-phase messages; FTCF_TP_WINAR=0 switches it off, FTCF_TP_WINAR_MB sizes its buffers: 16) */
+    int   window_allreduces;
 } ftcf_forward_stats;
 
 int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gptneox_weights* w, ftcf_gptneox_t* out);

@@ -129,6 +129,13 @@ def test_two_processes_on_one_gpu_exchange_through_ipc_windows(gh, tmp_path, mod
             # kernel that is not scheduled next to this one: nothing guarantees two processes co-run on one GPU)
             pytest.xfail("the two processes' kernels were not co-scheduled in six attempts: in-kernel path not exercised")
         assert got == (want, want), name
+        if model == "mid" and B == 4:
+            # the prompt phase's per-layer all-reduce (160 rows x 512: 160 KB) went through the IPC-mapped windows -- the
+            # two-shot kernel, no RCCL, no host staging -- in every layer, on both ranks (round 4)
+            if int(res[0][name + ".window_allreduces"][0]) == 0 and any("exchange-window all-reduce gave up" in lg for lg in logs):
+                pytest.xfail("the two processes' all-reduce kernels were not co-scheduled: the request was replayed on the host-staged path")
+            assert int(res[0][name + ".window_allreduces"][0]) >= cfg["num_layer"], res[0][name + ".window_allreduces"]
+            assert int(res[1][name + ".window_allreduces"][0]) == int(res[0][name + ".window_allreduces"][0])
         o = orc.Model(dict(cfg, fp16=1, int8_mode=int8_mode), lay, glob).generate(ids, lens, n_out, return_logits=True)
         _check(o["output_ids"], o["logits"], res[0][name + ".output_ids"], res[0][name + ".logits"], lens, f"{model} {name} vs oracle", frac)
         r1 = gh.run_op(op1, ids, lens, n_out, cfg["vocab_size"], **kw)
@@ -179,6 +186,7 @@ def test_13b_tp2_shards_between_two_processes(tmp_path):
     if got == (0, 0) and int(res[0]["attempts"][0]) == 4:
         pytest.xfail("the two processes' kernels were not co-scheduled in four attempts: in-kernel path not exercised")
     assert got == (1, 1)
+    assert int(res[0]["window_allreduces"][0]) >= FULL13B["layers"]  # the 1.9 MB prompt-phase messages: two-shot window kernel
     sys.path.insert(0, ROOT)
     import bench
     from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp

@@ -46,6 +46,7 @@ def main():
             res[name + ".output_ids"] = r["output_ids"]
             res[name + ".logits"] = r["logits"]
             res[name + ".decode_path"] = np.array([st["decode_path"]])
+            res[name + ".window_allreduces"] = np.array([st["window_allreduces"]])
             if ids.shape[0] <= 2 and st["decode_path"] != 1 and os.environ.get("FTCF_TEST_EXPECT_FALLBACK") != "1":
                 left = 1
         flag = torch.tensor([left])
@@ -84,6 +85,7 @@ def main_13b(rank, world, out):
         torch.cuda.synchronize()
         path = op.stats()["decode_path"]
         res = {"output_ids": o[0][:, 0].cpu().numpy(), "logits": dbg.cpu().numpy(), "decode_path": np.array([path]),
+               "window_allreduces": np.array([op.stats()["window_allreduces"]]),
                "attempts": np.array([attempt + 1])}
         flag = torch.tensor([0 if path == 1 else 1])
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
