@@ -1,0 +1,841 @@
+// Continuous batching over a paged K/V cache (include/ftcf.h `ftcf_batcher_*`): split out of engine.hip in round 4.
+#include "engine.hip.h"
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Continuous batching over a paged K/V cache (no counterpart in the reference, whose serving layer -- the
+// Triton backend -- allocates the cache per request, GptNeoX.cc:84-156).
+//
+// A batcher borrows an engine (weights, streams, kernels) and owns
+//   * a K/V POOL of fixed-size pages, [L][page][head][P tokens][dh] fp16, shared by all sequences, with a free list;
+//   * `max_batch` SLOTS: page table, length, last token, sampling parameters of the sequence living there;
+//   * a queue of waiting requests.
+// One iteration (ftcf_batcher_step) = ADMIT waiting requests into free slots while their pages (prompt + max_new_tokens,
+// reserved up front: a running sequence never has to be preempted) are available, then ONE decode step for all running
+// slots.  Admission runs the prompt through the engine's own context path (ftcf_gptneox_forward with output_len 1: prefill +
+// first token sampled by the engine's dynamic decode) and scatters the prompt's K/V into the slot's pages; the decode
+// step is the general layer sequence of the engine (§4a: dual LayerNorm, burst / tiled GEMMs, fused residual) with the
+// attention replaced by k_mmha_paged, the LM head, and the engine's sampling kernels on per-slot arrays.  A sequence leaves
+// when it emits end_id or reaches max_new_tokens; its pages return to the free list at once.
+// Scope: parallel-residual models, any tensor_para_size (round 4: one batcher per rank), fp16 / int8 engines, beam_width 1, top-k /
+// top-p / temperature sampling (no repetition penalty, stop words or callbacks).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_batcher_embed(f16* out, const f16* table, const int* tok, int H)
+{
+    const int  id  = tok[blockIdx.x];
+    const f16* src = table + (size_t)id * H;
+    f16*       dst = out + (size_t)blockIdx.x * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+        *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+    }
+}
+// d_tok[b] = the token the sampling kernels just wrote into slot b's history (time-major [max_len][B], position len[b])
+__global__ void k_batcher_last_token(int* tok, const int* hist, const int* len, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        tok[b] = hist[(size_t)len[b] * B + b];
+    }
+}
+__global__ void k_batcher_tick(DecodeState* gemm_state)
+{
+    gemm_state->step = (gemm_state->step + 1) & 0x7ffff;  // part of the burst GEMMs' granule tags (19 bits)
+}
+
+struct ftcf_batcher {
+    struct Request {
+        long             id;
+        std::vector<int> prompt;
+        int              max_new, top_k;
+        float            top_p, temperature, repetition_penalty = 1.f;
+        uint64_t         seed;
+        std::vector<std::vector<int>> stop;  // stop sequences (token ids)
+    };
+    struct Slot {
+        bool             active = false;
+        long             id = 0;
+        int              len = 0, generated = 0, max_new = 0;
+        std::vector<int> pages;
+        // the request's own token history (prompt + generated) and stop sequences: the stop criterion
+        // (stop_criteria_kernels.cu:24-83: finished AFTER the sequence has been emitted) is the scheduler's, on the host,
+        // which sees every token anyway
+        std::vector<int>              hist;
+        std::vector<std::vector<int>> stop;
+        float                         repetition_penalty = 1.f;
+    };
+    ftcf_gptneox* e = nullptr;
+    int           max_batch = 0, P = 0, num_pages = 0, max_pages = 0, max_len = 0;
+    size_t        pool_layer_elems = 0;
+    // device
+    f16 *kpool = nullptr, *vpool = nullptr;
+    f16 *x = nullptr, *nrm = nullptr, *nrm2 = nullptr, *qkv = nullptr, *ctx = nullptr, *att = nullptr, *mid = nullptr, *ffn = nullptr;
+    float*    logits = nullptr;
+    float*    gather = nullptr;  // tensor parallel: [TP][max_batch][V / TP] slices of the LM head
+    int *     d_pt = nullptr, *d_len = nullptr, *d_tok = nullptr, *d_topk = nullptr, *d_zero = nullptr, *d_prompt = nullptr, *d_plen = nullptr,
+        *d_pout = nullptr, *d_pseq = nullptr, *d_pages_tmp = nullptr;
+    uint8_t*     d_fin = nullptr;
+    float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr, *d_rep = nullptr;
+    int*         d_hist = nullptr;  // [max_len + 1][max_batch] time-major token history of the slots (repetition penalty)
+    int *        d_sw = nullptr;    // admission: stop words of the ragged batch, the reference's [n][2][Lw] layout
+    uint64_t *   d_seed = nullptr, *d_draws = nullptr;
+    DecodeState *d_state = nullptr, *d_gstate = nullptr;
+    void*        samp_ws = nullptr;
+    float*       smallm_ws = nullptr;
+    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..320 rows)
+    // chunked admission: with slots running, a prompt longer than this is prefilled alone, `prefill_chunk` tokens at a time, one
+    // decode step of the running slots between two chunks (FTCF_BATCHER_PREFILL_CHUNK; 0 = whole prompts)
+    int prefill_chunk = 512;
+    size_t       smallm_partial = 0;
+    unsigned     smallm_seq = 0;
+    long         gemm_steps = 0;
+    std::vector<void*> owned;
+    // host
+    std::vector<Slot>   slots;
+    std::deque<Request> waiting;
+    std::vector<int>    free_pages;
+    long                next_id = 1;
+    int                 max_prompt = 0;
+
+    template<typename T>
+    T* dmalloc(size_t n, bool zero = true)
+    {
+        void* p = nullptr;
+        FTCF_HIP_CHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+        if (zero) {
+            FTCF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+        }
+        owned.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+    ~ftcf_batcher()
+    {
+        for (void* p : owned) {
+            (void)hipFree(p);
+        }
+    }
+
+    void init(ftcf_gptneox* eng, int mb, int page_tokens, int pages, int max_seq_len)
+    {
+        e = eng;
+        FTCF_CHECK_ARG(!e->fp32 && e->cfg.use_gptj_residual && (e->dh == 64 || e->dh == 128),
+                       "the batcher serves fp16 / int8 engines with parallel residual and size_per_head 64 / 128");
+        FTCF_CHECK_ARG(mb >= 1 && mb <= 64 && page_tokens >= 8 && pages >= 1 && max_seq_len >= 2, "bad batcher geometry");
+        FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
+        if (const char* c = getenv("FTCF_BATCHER_PREFILL_CHUNK")) {
+            prefill_chunk = std::max(0, atoi(c));
+        }
+        max_batch = mb;
+        P         = page_tokens;
+        num_pages = pages;
+        max_pages = (max_seq_len + P - 1) / P;
+        max_len   = max_pages * P;
+        max_prompt = max_seq_len - 1;
+        FTCF_CHECK_ARG(mmha_paged_smem_bytes(e->dh, max_pages, max_len) <= 64 * 1024, "max_seq_len too large for the paged attention");
+        const int    H = e->H, hl = e->hl, il = e->il, L = e->L, V = e->V;
+        const size_t B = (size_t)max_batch;
+        pool_layer_elems = (size_t)num_pages * e->nhl * P * e->dh;
+        kpool = dmalloc<f16>((size_t)L * pool_layer_elems, false);
+        vpool = dmalloc<f16>((size_t)L * pool_layer_elems, false);
+        x = dmalloc<f16>(B * H);
+        nrm = dmalloc<f16>(B * H);
+        nrm2 = dmalloc<f16>(B * H);
+        qkv = dmalloc<f16>(B * 3 * hl);
+        ctx = dmalloc<f16>(B * hl);
+        att = dmalloc<f16>(B * H);
+        mid = dmalloc<f16>(B * il);
+        ffn = dmalloc<f16>(B * H);
+        logits = dmalloc<float>(B * V);
+        // tensor parallel (every rank runs its own batcher over its shard, fed the same requests in the same order: the
+        // schedulers take identical decisions, the decode step's collectives are the engine's): the LM head's [TP][B][V/TP] slices
+        gather = e->cfg.tensor_para_size > 1 ? dmalloc<float>(B * V) : nullptr;
+        d_pt = dmalloc<int>(B * max_pages);
+        d_len = dmalloc<int>(B);
+        d_tok = dmalloc<int>(B);
+        d_topk = dmalloc<int>(B);
+        d_zero = dmalloc<int>(B);
+        d_fin = dmalloc<uint8_t>(B);
+        d_ptopk = dmalloc<float>(B);
+        d_ptopp = dmalloc<float>(B);
+        d_temp = dmalloc<float>(B);
+        d_cum = dmalloc<float>(B);
+        d_rep = dmalloc<float>(B);
+        d_hist = dmalloc<int>((size_t)(max_len + 2) * B);
+        d_sw = dmalloc<int>(B * 2 * STOP_LW);
+        d_seed = dmalloc<uint64_t>(B);
+        d_draws = dmalloc<uint64_t>(B);
+        d_state = dmalloc<DecodeState>(1);
+        d_gstate = dmalloc<DecodeState>(1);
+        d_prompt = dmalloc<int>(B * max_seq_len);
+        d_plen = dmalloc<int>(B);
+        d_pout = dmalloc<int>(B * (max_seq_len + 1));
+        d_pseq = dmalloc<int>(B);
+        d_pages_tmp = dmalloc<int>(max_pages);
+        samp_ws = dmalloc<char>(sampling_workspace_bytes(max_batch, V), false);
+        if (max_batch > 4 && max_batch <= e->SMALLM_MAX_ROWS) {
+            const bool i8 = e->int8;
+            const int  bc = std::min(max_batch, 16);  // 16 rows per launch
+            smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(bc, il, H, i8)
+                             + gemm_smallm_workspace_bytes(bc, H, hl, i8) + gemm_smallm_workspace_bytes(bc, H, il, i8);
+            smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
+        }
+        if (max_batch > 16 && max_batch <= 320) {
+            tiled_ws = dmalloc<float>(gemm_tiled_workspace_bytes() / 4);
+        }
+        std::vector<uint8_t> fin(max_batch, 1);
+        FTCF_HIP_CHECK(hipMemcpy(d_fin, fin.data(), max_batch, hipMemcpyHostToDevice));
+        slots.assign(max_batch, Slot{});
+        free_pages.resize(num_pages);
+        for (int i = 0; i < num_pages; i++) {
+            free_pages[i] = num_pages - 1 - i;
+        }
+    }
+
+    static constexpr int STOP_LW = 64;  // total stop-word tokens per request (the [2][Lw] word list of the admission)
+    long submit(const int* ids, int n, int max_new, int top_k, float top_p, float temperature, uint64_t seed,
+                float repetition_penalty = 1.f, const int* stop_words = nullptr, int stop_len = 0)
+    {
+        FTCF_CHECK_ARG(repetition_penalty > 0.f, "repetition_penalty must be positive");
+        FTCF_CHECK_ARG(stop_len >= 0 && stop_len <= STOP_LW && (stop_len == 0 || stop_words), "bad stop word list");
+        // (the decode step stages total_len = max_len + 2 history entries: the same bound as launch_dynamic_decode's)
+        FTCF_CHECK_ARG(((size_t)max_len + 2) * 8 <= 60 * 1024 || repetition_penalty == 1.f,
+                       "max_seq_len too large for the repetition-penalty staging buffer");
+        FTCF_CHECK_ARG(ids && n >= 1 && max_new >= 1, "empty prompt or max_new_tokens < 1");
+        FTCF_CHECK_ARG(n + max_new <= max_len && n <= max_prompt, "prompt + max_new_tokens exceed the batcher's max_seq_len");
+        FTCF_CHECK_ARG((n + max_new + P - 1) / P <= num_pages, "the request needs more pages than the pool has");
+        FTCF_CHECK_ARG(top_k >= 0 && top_k <= 1024 && top_p >= 0.f && top_p <= 1.f && temperature > 0.f, "bad sampling parameters");
+        for (int i = 0; i < n; i++) {
+            FTCF_CHECK_ARG(ids[i] >= 0 && ids[i] < e->V, "token id out of range");
+        }
+        Request r;
+        r.id = next_id++;
+        r.prompt.assign(ids, ids + n);
+        r.max_new = max_new;
+        r.top_k = top_k;
+        r.top_p = top_p;
+        r.temperature = temperature;
+        r.seed = seed;
+        r.repetition_penalty = repetition_penalty;
+        // to_word_list_format (codefuse_example.py:26-53): [0][..] flat ids, [1][..] cumulative end offsets, -1 padded
+        for (int i = 0, start = 0; i < stop_len; i++) {
+            const int end = stop_words[stop_len + i];
+            if (end < 0) {
+                break;
+            }
+            FTCF_CHECK_ARG(end > start && end <= stop_len, "bad stop word offsets");
+            r.stop.emplace_back(stop_words + start, stop_words + end);
+            start = end;
+        }
+        waiting.push_back(std::move(r));
+        return waiting.back().id;
+    }
+
+    struct Event {
+        long id;
+        int  token, finished;
+    };
+    std::vector<Event>* hook_ev = nullptr;  // where the decode steps inside a chunked admission put their events
+    std::deque<Event>   outbox;             // events of an iteration that did not fit the caller's arrays
+    ftcf_token_callback_fn on_token = nullptr;  // called for every event the moment it exists (inside step())
+    void*                  on_token_user = nullptr;
+    void emit(std::vector<Event>& ev, const Event& x)
+    {
+        ev.push_back(x);
+        if (on_token) {
+            on_token(on_token_user, x.id, x.token, x.finished);
+        }
+    }
+
+    // the first tokens of an admission reach the callback only when the admission is known to have succeeded: a failed one is
+    // rolled back and retried, and a streaming consumer must not see its first tokens twice
+    void fire(const std::vector<Event>& ev, const size_t from)
+    {
+        if (on_token) {
+            for (size_t i = from; i < ev.size(); i++) {
+                on_token(on_token_user, ev[i].id, ev[i].token, ev[i].finished);
+            }
+        }
+    }
+
+    // stop_criteria_kernels.cu:24-83: does the history END with one of the request's stop sequences?
+    static bool hits_stop_word(const Slot& s)
+    {
+        for (const auto& wd : s.stop) {
+            if (!wd.empty() && s.hist.size() >= wd.size() && std::equal(wd.begin(), wd.end(), s.hist.end() - wd.size())) {
+                return true;
+            }
+        }
+        return false;
+    }
+    void release(Slot& s)
+    {
+        for (int pg : s.pages) {
+            free_pages.push_back(pg);
+        }
+        s.pages.clear();
+        s.active = false;
+    }
+
+    // prompts -> ONE ragged batch through the engine's context path (+ first tokens) -> pages of their slots
+    void admit(const std::vector<int>& sis, const std::vector<Request>& rs, std::vector<Event>& ev)
+    {
+        Range        rg("ftcf.batcher.admit");
+        hipStream_t  st = e->stream;
+        const int    n  = (int)sis.size();
+        int          S  = 0;
+        for (const Request& r : rs) {
+            S = std::max(S, (int)r.prompt.size());
+        }
+        std::vector<int>      ids((size_t)n * S, e->cfg.end_id), lens(n), topk(n);
+        std::vector<float>    topp(n), temp(n), rep(n);
+        bool                  any_stop = false;
+        std::vector<int>      sw((size_t)n * 2 * STOP_LW, 0);
+        std::vector<uint64_t> seed(n);
+        for (int i = 0; i < n; i++) {
+            const Request& r = rs[i];
+            std::copy(r.prompt.begin(), r.prompt.end(), ids.begin() + (size_t)i * S);
+            lens[i] = (int)r.prompt.size();
+            topk[i] = r.top_k;
+            topp[i] = r.top_p;
+            temp[i] = r.temperature;
+            rep[i]  = r.repetition_penalty;
+            seed[i] = r.seed;
+            {  // the request's stop sequences in the reference's word-list layout (the engine samples the FIRST token)
+                int* ids_row = sw.data() + (size_t)i * 2 * STOP_LW;
+                int* off_row = ids_row + STOP_LW;
+                std::fill(off_row, off_row + STOP_LW, -1);
+                int pos = 0, k = 0;
+                for (const auto& wd : r.stop) {
+                    std::copy(wd.begin(), wd.end(), ids_row + pos);
+                    pos += (int)wd.size();
+                    off_row[k++] = pos;
+                    any_stop = true;
+                }
+            }
+            Slot&     s = slots[sis[i]];
+            const int need = (lens[i] + r.max_new + P - 1) / P;
+            s.pages.clear();
+            for (int k = 0; k < need; k++) {
+                s.pages.push_back(free_pages.back());
+                free_pages.pop_back();
+            }
+        }
+        FTCF_HIP_CHECK(hipMemcpy(d_prompt, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+        FTCF_HIP_CHECK(hipMemcpy(d_plen, lens.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        ftcf_forward_args a{};
+        a.input_ids = d_prompt;
+        a.input_lengths = d_plen;
+        a.batch_size = n;
+        a.max_input_len = S;
+        a.output_len = 1;
+        a.beam_width = 1;
+        a.top_k = topk.data();
+        a.n_top_k = n;
+        a.top_p = topp.data();
+        a.n_top_p = n;
+        a.temperature = temp.data();
+        a.n_temperature = n;
+        a.repetition_penalty = rep.data();
+        a.n_repetition_penalty = n;
+        if (any_stop) {
+            FTCF_HIP_CHECK(hipMemcpy(d_sw, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+            a.stop_words_list = d_sw;
+            a.stop_words_len = STOP_LW;
+        }
+        a.random_seed = seed.data();
+        a.n_random_seed = n;
+        a.output_ids = d_pout;
+        a.sequence_lengths = d_pseq;
+        e->forward(a);  // host synchronous: K/V of row i, positions [0, len_i), are in the engine's cache [L][n][nh][S + 1][dh]
+        std::vector<int> out((size_t)n * (S + 1));
+        FTCF_HIP_CHECK(hipMemcpy(out.data(), d_pout, out.size() * 4, hipMemcpyDeviceToHost));
+        const size_t row_kv = (size_t)e->nhl * (S + 1) * e->dh;  // one row of one layer of the engine's cache
+        for (int i = 0; i < n; i++) {
+            const Request& r  = rs[i];
+            const int      si = sis[i], len = lens[i];
+            Slot&          s  = slots[si];
+            // the engine's output rows are compacted (prompt, then the generated tokens: invokeGatherTree removes the padding)
+            const int        first = out[(size_t)i * (S + 1) + len];
+            std::vector<int> row(max_pages, 0);
+            std::copy(s.pages.begin(), s.pages.end(), row.begin());
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_pt + (size_t)si * max_pages, row.data(), (size_t)max_pages * 4, hipMemcpyHostToDevice, st));
+            launch_scatter_kv_to_pages(e->k_cache + (size_t)i * row_kv, e->v_cache + (size_t)i * row_kv, kpool, vpool,
+                                       d_pt + (size_t)si * max_pages, e->L, e->nhl, e->dh, S + 1, len, P, pool_layer_elems, st,
+                                       (size_t)n * row_kv);
+            // per-slot state of the decode steps
+            const int      keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);  // BaseSamplingLayer: (0, 0) = greedy
+            const float    ptk = (r.top_p == 0.f) ? 1.f : r.top_p;
+            const uint8_t  zero8 = 0;
+            const uint64_t one = 1;
+            const float    zf = 0.f;
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, &len, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_tok + si, &first, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_topk + si, &keff, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopk + si, &ptk, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_ptopp + si, &r.top_p, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_temp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_rep + si, &r.repetition_penalty, 4, hipMemcpyHostToDevice, st));
+            // the slot's token history, time-major column si: prompt, then the first token
+            s.hist.assign(r.prompt.begin(), r.prompt.end());
+            s.hist.push_back(first);
+            s.stop = r.stop;
+            s.repetition_penalty = r.repetition_penalty;
+            FTCF_HIP_CHECK(hipMemcpy2DAsync(d_hist + si, (size_t)max_batch * 4, s.hist.data(), 4, 4, s.hist.size(),
+                                            hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_seed + si, &r.seed, 8, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_draws + si, &one, 8, hipMemcpyHostToDevice, st));  // draw 0 went to the first token
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, &zf, 4, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, &zero8, 1, hipMemcpyHostToDevice, st));
+            FTCF_HIP_CHECK(hipStreamSynchronize(st));  // the host temporaries above die here
+            s.active = true;
+            s.id = r.id;
+            s.len = len;
+            s.generated = 1;
+            s.max_new = r.max_new;
+            const int done = (first == e->cfg.end_id || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
+            ev.push_back(Event{r.id, first, done});  // (the token callback fires when the admission has succeeded: step())
+            if (done) {
+                const uint8_t one8 = 1;
+                FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                release(s);
+            }
+        }
+    }
+
+    // one token for every running slot
+    void decode(std::vector<Event>& ev)
+    {
+        Range                  rg("ftcf.batcher.decode");
+        hipStream_t            st = e->stream;
+        const int              B = max_batch, H = e->H, hl = e->hl, il = e->il, L = e->L, V = e->V;
+        const bool             int8 = e->int8;
+        const bool             dual = residual_dual_ln_supported(H);
+        const int              tp = e->cfg.tensor_para_size;
+        const bool             tp1 = tp == 1;  // (tensor parallel: the layer ends with residual + all-reduce, GptNeoXDecoder.cc:357-359)
+        hipLaunchKernelGGL(k_batcher_embed, dim3(B), dim3(256), 0, st, x, e->wte, d_tok, H);
+        if ((gemm_steps++ & 0x3ffff) == 0 && smallm_ws) {  // the tag space of the burst GEMMs wraps: start it clean
+            FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
+        }
+        hipLaunchKernelGGL(k_batcher_tick, dim3(1), dim3(1), 0, st, d_gstate);
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = e->layers[l];
+            if (!dual) {
+                launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
+                launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, st);
+            }
+            else if (l == 0 || !tp1) {
+                launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm, nrm2, B, H,
+                                        1e-5f, st);
+            }
+            MmhaPagedParams mp{};
+            mp.qkv = qkv;
+            mp.qkv_bias = w.qkv.bias;
+            mp.kpool = kpool + (size_t)l * pool_layer_elems;
+            mp.vpool = vpool + (size_t)l * pool_layer_elems;
+            mp.page_table = d_pt;
+            mp.len = d_len;
+            mp.finished = d_fin;
+            mp.B = B;
+            mp.nh = e->nhl;
+            mp.dh = e->dh;
+            mp.rot = e->cfg.rotary_embedding_dim;
+            mp.P = P;
+            mp.max_pages = max_pages;
+            mp.ctx = ctx;
+            if (smallm_ws && e->decode_branches && e->side) {
+                // the attention branch and the FFN branch on two streams, as the engine's batched decode
+                const int    bc = std::min(B, 16);
+                const size_t o_qkv = 0, o_f1 = o_qkv + gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8),
+                             o_out = o_f1 + gemm_smallm_workspace_bytes(bc, il, H, int8),
+                             o_f2  = o_out + gemm_smallm_workspace_bytes(bc, H, hl, int8);
+                auto one = [&](const SmallmDesc& d0, size_t off, hipStream_t s2) {
+                    for (int r0 = 0; r0 < B; r0 += 16) {
+                        SmallmDesc d = d0;
+                        d.A          = d0.A + (size_t)r0 * d0.k;
+                        d.C          = d0.C + (size_t)r0 * d0.n;
+                        launch_gemm_smallm_group(&d, 1, smallm_ws, smallm_partial, std::min(16, B - r0), int8, s2, &d_gstate->step,
+                                                 &smallm_seq, off);
+                    }
+                };
+                const size_t offs[4] = {o_qkv, o_f1, o_out, o_f2};
+                GemmFn burst = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int, int n, int k,
+                                   hipStream_t s2, int slot) { one(SmallmDesc{A, dw.kernel, dw.scale, bias, act, C, n, k}, offs[slot], s2); };
+                FTCF_HIP_CHECK(hipEventRecord(e->ev_fork, st));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                DecoderSelfAttentionLayer{burst, H, hl}.forward_paged(nrm, qkv, ctx, att, w, mp, max_len, B, st);
+                FfnLayer{burst, H, il}.forward(nrm2, mid, ffn, w, B, e->side);
+                FTCF_HIP_CHECK(hipEventRecord(e->ev_join, e->side));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->ev_join, 0));
+            }
+            else if (smallm_ws && B <= 16) {
+                const SmallmDesc p1[2] = {{nrm, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv, 3 * hl, H},
+                                          {nrm2, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid, il, H}};
+                launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
+                launch_mmha_paged(mp, max_len, st);
+                const SmallmDesc p3[2] = {{ctx, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att, H, hl},
+                                          {mid, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn, H, il}};
+                launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, B, int8, st, &d_gstate->step, &smallm_seq);
+            }
+            else {
+                GemmFn plain = [&](const f16* A, const DenseWeight& dw, const f16* bias, int act, f16* C, int m, int n, int k,
+                                   hipStream_t s2, int) {
+                    gemm_dispatch(A, dw.kernel, dw.scale, bias, act, C, m, n, k, int8, s2, nullptr, 0, e->num_cu, nullptr, nullptr,
+                                  s2 == st ? tiled_ws : nullptr);
+                };
+                DecoderSelfAttentionLayer{plain, H, hl}.forward_paged(nrm, qkv, ctx, att, w, mp, max_len, B, st);
+                FfnLayer{plain, H, il}.forward(nrm2, mid, ffn, w, B, st);
+            }
+            // (every slot's hidden state is recomputed from its token each step: the residual never aliases across steps,
+            // so the fp32-sum variant of the context decoder applies to all layers)
+            if (dual && tp1) {
+                const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
+                launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, (l > 0 && l < L - 1) ? 1 : 0, nx ? nx->ln1_g : nullptr,
+                                        nx ? nx->ln1_b : nullptr, nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H,
+                                        1e-5f, st);
+            }
+            else {
+                launch_add_bias_attn_ffn_residual(x, ffn, att, x, w.ffn2.bias, B, H, tp, (l > 0 && l < L - 1) ? 1 : 0, true, st);
+                e->allreduce(x, (size_t)B * H, st);
+            }
+        }
+        {
+            // LM head; tensor parallel: rank r computes rows [r V/TP, (r+1) V/TP) of the replicated lm_head into its slice of
+            // `gather`, all-gather + transpose (GptNeoX.cc:888-925, as the engine's own step)
+            const int    rows = tp1 ? V : e->vl;
+            const f16*   Wr   = tp1 ? e->lm_head : e->lm_head + (size_t)e->cfg.tensor_para_rank * e->vl * H;
+            float*       out  = tp1 ? logits : gather + (size_t)e->cfg.tensor_para_rank * B * e->vl;
+            if (B <= 4) {
+                launch_lm_head(x, Wr, out, B, rows, H, rows, st, e->final_g, e->final_b, 1e-5f);
+            }
+            else {
+                launch_layernorm(x, e->final_g, e->final_b, nrm, B, H, 1e-5f, true, st);
+                lm_head_dispatch(nrm, Wr, out, B, rows, H, rows, st);
+            }
+            if (!tp1) {
+                e->allgather_logits(gather, logits, B, st);
+            }
+        }
+        SamplingParams sp{};
+        sp.logits = logits;
+        sp.B = B;
+        sp.V = V;
+        sp.max_input_len = 0;
+        sp.end_id = e->cfg.end_id;
+        sp.input_lengths = d_zero;
+        sp.top_k = d_topk;
+        sp.top_p_topk = d_ptopk;
+        sp.top_p_topp = d_ptopp;
+        sp.temperature = d_temp;
+        sp.random_seed = d_seed;
+        sp.draw_counter = d_draws;
+        sp.apply_temperature = host_any_temperature ? 1 : 0;
+        sp.apply_repetition = host_any_repetition ? 1 : 0;  // (BaseSamplingLayer.cc:283-313: skipped when every row has 1.0)
+        sp.repetition_penalty = d_rep;
+        sp.return_cum_log_probs = 1;
+        // every slot has its own step: its history is column b of the time-major d_hist, positions [0, len[b]]; the sampled
+        // token goes to position len[b] + 1 (the penalty of sampling_penalty_kernels.cu:367-425 reads the whole history)
+        sp.output_ids = d_hist;
+        sp.row_len = d_len;
+        sp.total_len = max_len + 2;
+        sp.finished = d_fin;
+        sp.seq_len = d_len;     // + 1 per sampled token: the slot's length
+        sp.cum_log_probs = d_cum;
+        sp.pad_count = d_zero;
+        sp.state = d_state;     // step stays 0
+        sp.ws = samp_ws;
+        sp.max_top_k = host_max_top_k;
+        sp.any_top_p = host_any_top_p;
+        DynamicDecodeLayer{}.forward(sp, st, false);  // (the stop / length criteria are the scheduler's: no finish step)
+        hipLaunchKernelGGL(k_batcher_last_token, dim3(1), dim3(64), 0, st, d_tok, d_hist, d_len, B);
+        std::vector<int>     tok(B);
+        std::vector<uint8_t> fin(B);
+        int                  gemm_err = 0;
+        FTCF_HIP_CHECK(hipMemcpyAsync(tok.data(), d_tok, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(fin.data(), d_fin, (size_t)B, hipMemcpyDeviceToHost, st));
+        if (smallm_ws) {  // sticky flag of the burst GEMMs' in-launch split-K reduction (the engine's finish() reads its own)
+            FTCF_HIP_CHECK(hipMemcpyAsync(&gemm_err, reinterpret_cast<char*>(smallm_ws) + smallm_partial, sizeof(int),
+                                          hipMemcpyDeviceToHost, st));
+        }
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        if (gemm_err != 0) {
+            // the tokens of this step are not to be trusted: nothing is reported, the slots keep their state (lengths and
+            // draw counters advanced on the device: the requests cannot be resumed exactly), the flag is cleared for the caller's
+            // next attempt
+            FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
+            FTCF_HIP_CHECK(hipStreamSynchronize(st));
+            throw Error(-2, "batcher decode: a split-K reducer of the batched GEMM gave up waiting for its sibling workgroups");
+        }
+        for (int si = 0; si < B; si++) {
+            Slot& s = slots[si];
+            if (!s.active) {
+                continue;
+            }
+            s.len += 1;
+            s.generated += 1;
+            s.hist.push_back(tok[si]);
+            const int done = (fin[si] || s.generated >= s.max_new || hits_stop_word(s)) ? 1 : 0;
+            emit(ev, Event{s.id, tok[si], done});
+            if (done) {
+                if (!fin[si]) {
+                    const uint8_t one8 = 1;
+                    FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                }
+                release(s);
+            }
+        }
+    }
+
+    int  host_max_top_k = 1, host_any_top_p = 0;
+    bool host_any_temperature = false, host_any_repetition = false;
+    std::vector<int>   slot_topk;
+    std::vector<float> slot_temp;
+
+    void step(std::vector<Event>& ev)
+    {
+        FTCF_HIP_CHECK(hipSetDevice(e->cfg.device));
+        if (slot_topk.empty()) {
+            slot_topk.assign(max_batch, 1);
+            slot_temp.assign(max_batch, 1.f);
+        }
+        // the running slots first (a request admitted in this iteration has its first token already)
+        bool any = false;
+        for (const Slot& s : slots) {
+            any |= s.active;
+        }
+        if (any) {
+            decode(ev);
+        }
+        // admissions: as many of the queue's head requests as there are free slots and pages, prefilled as ONE ragged batch
+        std::vector<int>     sis;
+        std::vector<Request> rs;
+        int                  pages_left = (int)free_pages.size();
+        for (int si = 0; si < max_batch && !waiting.empty(); si++) {
+            if (slots[si].active) {
+                continue;
+            }
+            const Request& r    = waiting.front();
+            const int      need = ((int)r.prompt.size() + r.max_new + P - 1) / P;
+            if (pages_left < need) {
+                break;  // FIFO: nobody overtakes the head of the queue
+            }
+            pages_left -= need;
+            const int keff = (r.top_k == 0 && r.top_p == 0.f) ? 1 : std::min(r.top_k, 1024);
+            slot_topk[si]  = keff;
+            slot_temp[si]  = r.temperature;
+            sis.push_back(si);
+            rs.push_back(std::move(waiting.front()));
+            waiting.pop_front();
+        }
+        bool any_long = false;
+        for (const Request& r : rs) {
+            any_long |= prefill_chunk > 0 && (int)r.prompt.size() > prefill_chunk;
+        }
+        if (!sis.empty() && any && any_long) {
+            // slots are running and a long prompt arrives: one request at a time, its prompt phase in chunks with a decode step of
+            // the running slots after every chunk (events of those steps are final whatever happens to the admission)
+            while (!sis.empty()) {
+                const std::vector<int>     one_si{sis.front()};
+                const std::vector<Request> one_r{rs.front()};
+                std::vector<Event>         own, between;
+                bool                       running = false;
+                for (const Slot& s : slots) {
+                    running |= s.active;
+                }
+                try {
+                    if (running) {
+                        hook_ev          = &between;
+                        e->prefill_chunk = prefill_chunk;
+                        e->prefill_hook  = [this] {
+                            bool live = false;
+                            for (const Slot& s : slots) {
+                                live |= s.active;
+                            }
+                            if (live) {
+                                refresh_host_flags();
+                                decode(*hook_ev);
+                            }
+                        };
+                    }
+                    admit(one_si, one_r, own);
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
+                }
+                catch (...) {
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
+                    (void)hipDeviceSynchronize();
+                    (void)hipGetLastError();
+                    ev.insert(ev.end(), between.begin(), between.end());
+                    for (const int si : sis) {  // this request and the ones not yet admitted go back to the queue's head
+                        release(slots[si]);
+                        const uint8_t one8 = 1;
+                        (void)hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice);
+                    }
+                    for (size_t i = rs.size(); i-- > 0;) {
+                        waiting.push_front(std::move(rs[i]));
+                    }
+                    throw;
+                }
+                ev.insert(ev.end(), between.begin(), between.end());
+                ev.insert(ev.end(), own.begin(), own.end());
+                fire(own, 0);
+                sis.erase(sis.begin());
+                rs.erase(rs.begin());
+            }
+        }
+        if (!sis.empty()) {
+            const size_t ev0 = ev.size();
+            try {
+                admit(sis, rs, ev);
+            }
+            catch (...) {
+                // the whole admission is rolled back: pages to the pool, slots free, the requests back at the head of the
+                // queue in their order, their events dropped (the caller sees the exception, not half an admission)
+                (void)hipDeviceSynchronize();
+                (void)hipGetLastError();
+                for (const int si : sis) {
+                    release(slots[si]);
+                    const uint8_t one8 = 1;
+                    (void)hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice);
+                }
+                for (size_t i = rs.size(); i-- > 0;) {
+                    waiting.push_front(std::move(rs[i]));
+                }
+                ev.resize(ev0);
+                throw;
+            }
+            fire(ev, ev0);
+        }
+        refresh_host_flags();
+    }
+    // host view of the running slots' sampling parameters (kernel selection and LDS sizing of the sampling kernels): after every
+    // admission, and before a decode step that runs inside an admission (a request admitted a moment ago is already running)
+    void refresh_host_flags()
+    {
+        host_max_top_k = 1;
+        host_any_top_p = 0;
+        host_any_temperature = false;
+        host_any_repetition = false;
+        for (int si = 0; si < max_batch; si++) {
+            if (slots[si].active) {
+                host_any_repetition |= (slots[si].repetition_penalty != 1.f);
+                host_max_top_k = std::max(host_max_top_k, slot_topk[si]);
+                host_any_top_p |= (slot_topk[si] == 0);
+                host_any_temperature |= (slot_temp[si] != 1.f);
+            }
+        }
+    }
+};
+
+extern "C" int ftcf_batcher_create(ftcf_gptneox_t engine, int max_batch, int page_tokens, int num_pages, int max_seq_len,
+                                   ftcf_batcher_t* out)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(engine && out, "NULL argument");
+        require_device();
+        auto b = std::make_unique<ftcf_batcher>();
+        b->init(engine, max_batch, page_tokens, num_pages, max_seq_len);
+        *out = b.release();
+    });
+}
+extern "C" int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k,
+                                   float top_p, float temperature, unsigned long long seed, long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit(prompt_ids, prompt_len, max_new_tokens, top_k, top_p, temperature, (uint64_t)seed);
+    });
+}
+extern "C" int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k,
+                                      float top_p, float temperature, float repetition_penalty, unsigned long long seed,
+                                      const int* stop_words, int stop_len, long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit(prompt_ids, prompt_len, max_new_tokens, top_k, top_p, temperature, (uint64_t)seed,
+                                repetition_penalty, stop_words, stop_len);
+    });
+}
+extern "C" int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_ids && tokens && finished && n_events, "NULL argument");
+        FTCF_CHECK_ARG(capacity >= 2 * b->max_batch, "event arrays must hold 2 * max_batch entries");
+        if (b->outbox.empty()) {  // (else: the rest of the previous iteration's events first)
+            std::vector<ftcf_batcher::Event> ev;
+            try {
+                b->step(ev);
+            }
+            catch (...) {
+                b->outbox.insert(b->outbox.end(), ev.begin(), ev.end());  // tokens of decode steps that did run are not lost
+                throw;
+            }
+            b->outbox.insert(b->outbox.end(), ev.begin(), ev.end());
+        }
+        int n = 0;
+        for (; n < capacity && !b->outbox.empty(); n++) {
+            request_ids[n] = b->outbox.front().id;
+            tokens[n]      = b->outbox.front().token;
+            finished[n]    = b->outbox.front().finished;
+            b->outbox.pop_front();
+        }
+        *n_events = n;
+    });
+}
+extern "C" int ftcf_batcher_set_token_callback(ftcf_batcher_t b, ftcf_token_callback_fn fn, void* user)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        b->on_token      = fn;
+        b->on_token_user = user;
+    });
+}
+extern "C" int ftcf_batcher_status(ftcf_batcher_t b, int* waiting, int* running, int* free_pages)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        int run = 0;
+        for (const auto& s : b->slots) {
+            run += s.active ? 1 : 0;
+        }
+        if (waiting) {
+            *waiting = (int)b->waiting.size();
+        }
+        if (running) {
+            *running = run + (b->outbox.empty() ? 0 : 1);  // (events still to be fetched keep the batcher "busy")
+        }
+        if (free_pages) {
+            *free_pages = (int)b->free_pages.size();
+        }
+    });
+}
+extern "C" int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b, "NULL argument");
+        int hit = 0;
+        for (auto it = b->waiting.begin(); it != b->waiting.end(); ++it) {
+            if (it->id == request_id) {
+                b->waiting.erase(it);
+                hit = 1;
+                break;
+            }
+        }
+        for (int si = 0; si < b->max_batch && !hit; si++) {
+            ftcf_batcher::Slot& s = b->slots[si];
+            if (s.active && s.id == request_id) {
+                FTCF_HIP_CHECK(hipSetDevice(b->e->cfg.device));
+                const uint8_t one8 = 1;
+                FTCF_HIP_CHECK(hipMemcpy(b->d_fin + si, &one8, 1, hipMemcpyHostToDevice));
+                b->release(s);
+                hit = 1;
+            }
+        }
+        if (found) {
+            *found = hit;
+        }
+    });
+}
+extern "C" int ftcf_batcher_destroy(ftcf_batcher_t b)
+{
+    return guarded([&] { delete b; });
+}
