@@ -487,6 +487,13 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     sp.state = state;
     sp.h_flags = h_flags;
     sp.ws = samp_ws;
+    if (!fp32 && H % 8 == 0) {  // k_greedy_decode prepares the next token's input itself (no k_step_prologue launch then)
+        sp.next_x    = x;
+        sp.wte       = wte;
+        sp.rot_table = rot_table;
+        sp.H         = H;
+        sp.rot       = cfg.rotary_embedding_dim;
+    }
 
     BeamParams bp{};
     if (K > 1) {
@@ -549,8 +556,12 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
         decoder32(B, s_max);
     }
     else if (with_decoder) {
-            launch_step_prologue(x, wte, step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
-                                 stream, &state->all_finished);
+            // (an all-greedy batch: the previous token's k_greedy_decode has written this token's embedding row and rotary
+            // table already -- unless this is the request's first dynamic-decode step, a one-token prompt)
+            if (!(ses.K == 1 && ses.sp.next_x && ses.steps > 0 && dynamic_decode_is_fused(ses.sp, true))) {
+                launch_step_prologue(x, wte, step_ids, &state->step, rot_table, pad_count, B, H, cfg.rotary_embedding_dim,
+                                     stream, &state->all_finished);
+            }
             decoder(B, s_max);
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4

@@ -311,7 +311,7 @@ struct DecodeState {  // device resident, one per engine
     int step;         // current step (max_input_len .. total-1)
     int all_finished;
     int steps_done;
-    int pad;
+    int pad;          // ticket counter of k_greedy_decode (zero between launches)
 };
 struct SamplingParams {
     float*       logits;  // [B, V] fp32 (modified in place)
@@ -344,7 +344,15 @@ struct SamplingParams {
     // continuous batching: every row has its OWN step -- row b's token history is output_ids[0 .. row_len[b]] (time-major
     // as always), the new token goes to position row_len[b] + 1.  NULL: the batch-wide state->step
     const int*      row_len;
+    // k_greedy_decode only: the NEXT token's prologue (k_step_prologue: embedding row of the token just chosen + the rotary table
+    // of the next step) done by the workgroup that finishes the step; next_x NULL: the engine launches k_step_prologue itself
+    f16*            next_x;     // [B, H]
+    const f16*      wte;        // [V, H]
+    float*          rot_table;  // [B, rot / 2, 2]
+    int             H, rot;
 };
+// does launch_dynamic_decode(p, s, finish) take the one-launch path of an all-greedy batch (k_greedy_decode)?
+bool dynamic_decode_is_fused(const SamplingParams& p, bool finish);
 // beam search (beam_width > 1): OnlineBeamSearchLayer semantics, rows bb = batch * K + beam
 constexpr int BEAM_MAX_K = 64;  // online_softmax_beamsearch_kernels.cu:691-695
 struct BeamParams {

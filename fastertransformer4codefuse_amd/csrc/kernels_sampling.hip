@@ -10,6 +10,7 @@
 // is a fixed launch sequence (hipGraph friendly); the host only reads a pinned "all finished" word.
 #include "ftcf_common.h"
 #include "kernels.h"
+#include "attn_device.hip.h"  // rotary_coef (the next token's prologue inside k_greedy_decode)
 
 #include <mutex>
 
@@ -913,11 +914,8 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
 }
 
 // ---- step 4: stop words, length criterion, bookkeeping (single block) -----------------------------------------
-__global__ void k_decode_finish(const SamplingParams p)
+__device__ __forceinline__ void decode_finish_body(const SamplingParams& p)
 {
-    if (p.state->all_finished) {
-        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
-    }
     __shared__ int s_all;
     const int      step = p.state->step;
     if (threadIdx.x == 0) {
@@ -971,6 +969,182 @@ __global__ void k_decode_finish(const SamplingParams p)
     }
 }
 
+__global__ void k_decode_finish(const SamplingParams p)
+{
+    if (p.state->all_finished) {
+        return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
+    }
+    decode_finish_body(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole dynamic-decode step of an ALL-GREEDY batch in ONE launch (round 4).  The general pipeline is four launches
+// (k_decode_prep 4.7 us, k_topk_stage1 11.8, k_sample 7.5, k_decode_finish 4.2 at V = 100864: 28 us of a 2.66 ms token, and 2 %
+// of a TP = 8 rank's token); when every row has top_k = 1 and nothing touches the logits but the min-length mask -- the
+// reference's default request, and the headline's -- the same results come out of one: 32 slices per row keep their logits in
+// registers for the arg max (`better`: highest value, lowest id) and the soft-max statistics return_cum_log_probs needs
+// (sampling_topp_kernels.cu:1296-1345 addBiasSoftMax), write-through partials + a ticket, and the workgroup that draws the
+// last ticket picks every row's token exactly as k_sample does for k = 1 (sampling_topk_kernels.cu:210-311: probability of the
+// best token under the row's soft-max, the uniform draw consumed, cum_log_probs, sequence length, finished) and then runs the
+// step's bookkeeping (decode_finish_body: stop words, length criterion, padding counts, step counter).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GREEDY_SLICES = 32;
+constexpr int GREEDY_MAXE   = 16;  // logits per thread: V <= 32 * 256 * 16 = 131072
+
+__global__ __launch_bounds__(256) void k_greedy_decode(const SamplingParams p, float* part)
+{
+    if (p.state->all_finished) {
+        return;
+    }
+    __shared__ float redv[4];
+    __shared__ int   redi[4];
+    __shared__ int   s_last;
+    const int        b = blockIdx.y, blk = blockIdx.x, V = p.V;
+    const int        slice = (V + GREEDY_SLICES - 1) / GREEDY_SLICES;
+    if (!p.finished[b]) {
+        const int    i0 = blk * slice;
+        const int    n  = max(0, min(slice, V - i0));
+        const float* l  = p.logits + (size_t)b * V + i0;
+        // min_length (sampling_penalty_kernels.cu:485-520): end_id cannot be chosen yet
+        const bool mask_end = p.min_length && (p.seq_len[b] + 1 - p.max_input_len < p.min_length[b]);
+        float      vals[GREEDY_MAXE];
+        const int  ne = n > (int)threadIdx.x ? (n - (int)threadIdx.x + 255) / 256 : 0;
+#pragma unroll
+        for (int j = 0; j < GREEDY_MAXE; j++) {
+            vals[j] = (j < ne) ? l[threadIdx.x + 256 * j] : -INFINITY;
+        }
+        VI    best{-INFINITY, 0x7fffffff};
+        float lmax = -FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < GREEDY_MAXE; j++) {
+            if (j < ne) {
+                const int i = threadIdx.x + 256 * j;
+                if (mask_end && i0 + i == p.end_id) {
+                    vals[j] = -FLT_MAX;
+                }
+                const float v = vals[j];
+                lmax          = fmaxf(lmax, v);
+                if (best.i == 0x7fffffff || better(v, i, best.v, best.i)) {
+                    best.v = v;
+                    best.i = i;
+                }
+            }
+        }
+        lmax = wave_max(lmax);
+        if ((threadIdx.x & 63) == 0) {
+            redv[threadIdx.x >> 6] = lmax;
+        }
+        __syncthreads();
+        const float m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+        __syncthreads();
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < GREEDY_MAXE; j++) {
+            if (j < ne) {
+                se += __expf(vals[j] - m);
+            }
+        }
+        se = wave_sum(se);
+        if ((threadIdx.x & 63) == 0) {
+            redv[threadIdx.x >> 6] = se;
+        }
+        __syncthreads();
+        const float sum = (redv[0] + redv[1]) + (redv[2] + redv[3]);
+        __syncthreads();
+        const VI r = block_best(best, redv, redi);
+        if (threadIdx.x == 0) {
+            // {best value, its id, slice max, slice sum of exponentials}: write-through stores (the reader may sit on another XCD)
+            typedef __attribute__((address_space(1))) unsigned gu32;
+            gu32* o = (gu32*)(part + ((size_t)b * GREEDY_SLICES + blk) * 4);
+            __hip_atomic_store(o + 0, __float_as_uint(n > 0 ? r.v : -INFINITY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 1, (unsigned)(n > 0 ? i0 + r.i : 0x7fffffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 2, __float_as_uint(n > 0 ? m : -FLT_MAX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 3, __float_as_uint(n > 0 ? sum : 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // ---- ticket: the last workgroup of the launch finishes the step ----
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's partial has been acknowledged (write-through)
+        const int total = GREEDY_SLICES * p.B;
+        const int t     = __hip_atomic_fetch_add(&p.state->pad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last          = (t == total - 1) ? 1 : 0;
+        if (s_last) {
+            __hip_atomic_store(&p.state->pad, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next token
+        }
+    }
+    __syncthreads();
+    if (!s_last) {
+        return;
+    }
+    const int step = p.state->step;
+    for (int row = 0; row < p.B; row++) {
+        int* out_id = p.output_ids + (size_t)step * p.B + row;
+        if (p.finished[row]) {
+            if (threadIdx.x == 0) {
+                *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242
+            }
+            continue;
+        }
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        const gu32* q = (const gu32*)(part + (size_t)row * GREEDY_SLICES * 4);
+        VI          cand{-INFINITY, 0x7fffffff};
+        if (threadIdx.x < GREEDY_SLICES) {
+            cand.v = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            cand.i = (int)__hip_atomic_load(q + threadIdx.x * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the row's soft-max from the slice statistics, as k_sample: lane q of the first wave holds slice q's {max, sum} (one round
+        // trip for all 32 -- a serial walk by one thread was 96 dependent loads: 10 us of this 17 us kernel)
+        float mq = -FLT_MAX, sq = 0.f;
+        if (p.return_cum_log_probs && threadIdx.x < GREEDY_SLICES) {
+            mq = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sq = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const float row_max = wave_max(mq);                           // (valid in the first wave: thread 0 uses it)
+        const float tot     = wave_sum(sq * __expf(mq - row_max));    // (lanes without a slice add 0 * exp(.) = 0)
+        const VI r = block_best(cand, redv, redi);
+        if (threadIdx.x == 0) {
+            float prob = 1.f;
+            if (p.return_cum_log_probs) {
+                prob = __expf(r.v - row_max) / (tot + 1e-6f);
+            }
+            p.draw_counter[row] += 1;  // (the top-k layer draws its uniform number for k = 1 too: sampling_topk_kernels.cu:283)
+            int id = r.i;
+            if (id == 0x7fffffff || id < 0) {
+                id = 0;
+            }
+            *out_id = id;
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                p.cum_log_probs[row] += logf(prob);
+            }
+            p.seq_len[row] += 1;  // :305-308
+            p.finished[row] = (id == p.end_id);
+        }
+        __syncthreads();
+    }
+    __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
+    decode_finish_body(p);
+    if (p.next_x) {
+        // the next token's prologue (k_step_prologue: decoding_kernels.cu:145-191 embedding lookup + the step's rotary table)
+        __syncthreads();  // (thread 0 advanced the step counter)
+        const int nstep = p.state->step;
+        for (int row = 0; row < p.B; row++) {
+            if ((int)threadIdx.x < p.rot / 2) {
+                const int pos = (nstep - 1) - (p.pad_count ? p.pad_count[row] : 0);
+                float     cs, sn;
+                rotary_coef(threadIdx.x, p.rot, pos, cs, sn);
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2]     = cs;
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2 + 1] = sn;
+            }
+            const int  id  = p.output_ids[(size_t)(nstep - 1) * p.B + row];
+            const f16* src = p.wte + (size_t)id * p.H;
+            f16*       dst = p.next_x + (size_t)row * p.H;
+            for (int i = threadIdx.x * 8; i < p.H; i += blockDim.x * 8) {
+                *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+            }
+        }
+    }
+}
+
 void launch_decode_finish(const SamplingParams& p, hipStream_t s)
 {
     hipLaunchKernelGGL(k_decode_finish, dim3(1), dim3(64), 0, s, p);
@@ -990,10 +1164,24 @@ size_t sampling_workspace_bytes(int B, int V)
            + (size_t)B * 2 * nv * sizeof(float);
 }
 
+bool dynamic_decode_is_fused(const SamplingParams& p, bool finish)
+{
+    static const int greedy_on = getenv("FTCF_GREEDY_FUSED") ? atoi(getenv("FTCF_GREEDY_FUSED")) : 1;
+    return greedy_on && finish && p.max_top_k == 1 && !p.any_top_p && !p.apply_temperature && !p.apply_repetition && !p.optional_last_tokens
+           && !p.row_len && p.V <= GREEDY_SLICES * 256 * GREEDY_MAXE && p.B <= 1024 && p.rot / 2 <= 256
+           && (size_t)p.B * GREEDY_SLICES * 16 <= sampling_workspace_bytes(p.B, p.V);
+}
+
 void launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish)
 {
     float* cand_v = reinterpret_cast<float*>(p.ws);
     int*   cand_i = reinterpret_cast<int*>(cand_v + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX);
+    // every row greedy, nothing but the min-length mask touches the logits, the step's bookkeeping follows: one launch
+    if (dynamic_decode_is_fused(p, finish)) {
+        hipLaunchKernelGGL(k_greedy_decode, dim3(GREEDY_SLICES, p.B), dim3(256), 0, s, p, cand_v);
+        FTCF_HIP_CHECK(hipGetLastError());
+        return;
+    }
     size_t prep_smem = 0;
     if (p.optional_last_tokens) {
         prep_smem = std::max(prep_smem, (size_t)((p.V + 31) / 32) * 4);
@@ -1055,6 +1243,7 @@ __global__ void k_decode_init(uint8_t* finished, int* seq_len, float* cum_log_pr
             st->step         = max_input_len;
             st->all_finished = 0;
             st->steps_done   = 0;
+            st->pad          = 0;  // (the ticket of k_greedy_decode)
         }
     }
     const int len = input_lengths[b];
