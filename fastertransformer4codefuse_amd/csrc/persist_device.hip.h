@@ -80,6 +80,10 @@ constexpr bool PS_FULL_P1 = PS_FULL_P1_V, PS_FULL_P3 = PS_FULL_P3_V;
 #ifndef PS_KV_EARLY
 #define PS_KV_EARLY 0
 #endif
+// PS_ATT_WP: the eight-wave attention with wave-private soft-max statistics (PsAttn::compute_wp: three barriers instead of five)
+#ifndef PS_ATT_WP
+#define PS_ATT_WP 0
+#endif
 // PS_NF: register batches a wave keeps IN FLIGHT in the steady state (the fourth / third / second one has landed and
 // waits to be consumed).  Everything a compute unit has outstanding sits in ONE in-order return queue, and whatever the
 // chip has outstanding beyond bandwidth x unloaded latency only adds to the latency of every request -- the hand-off polls
@@ -1057,6 +1061,167 @@ struct PsAttn {
             ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
             ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
         }
+    }
+    // Round 4 (PS_ATT_WP): the same split on the eight waves with WAVE-PRIVATE soft-max statistics.  compute() below takes five
+    // workgroup barriers (q/k/v staged, rotary, maxima, exponentials, outputs) and sends every score through LDS twice; here a
+    // wave runs its own keys -- 4 (dh = 128) or 8 (dh = 64) per register row, UK rows -- through the whole soft-max against ITS
+    // OWN maximum (scores, probabilities and the weighted V rows never leave its registers), and the eight {maximum, sum,
+    // un-normalised output} triples are combined like the splits of a (row, head) are: three barriers, no score buffer.  The
+    // arithmetic is compute_ctrl's (decoder_masked_multihead_attention_template.hpp:1099-1919 with fp32 probabilities);
+    // against compute() only the reference point of the exponentials differs (own maximum, rescaled at the end).
+    template<bool APPEND = true, typename ST>
+    __device__ __forceinline__ bool compute_wp(const PersistParams& p, PsLayerC& lw, char* smem, u64* gout, const unsigned tag, int h,
+                                               int b, const int tx, ST& st)
+    {
+        const int lane = tx & 63, wid = tx >> 6;
+        const int sub = lane % LPK, grp = lane / LPK;
+        if (fin) {
+            return false;  // :1176
+        }
+        int t_end = t_beg + chunk;
+        if (t_end > tl + 1) {
+            t_end = tl + 1;
+        }
+        if (t_beg > tl) {  // empty split
+            if (tx < DH) {
+                st_granule(&gout[tx], tag, 0.f);
+            }
+            if (tx == 0) {
+                st_granule(&gout[DH], tag, -INFINITY);
+                st_granule(&gout[DH + 1], tag, 0.f);
+            }
+            return true;
+        }
+        const bool owns_cur     = (tl >= t_beg && tl < t_end);
+        const int  t_cached_end = owns_cur ? tl : t_end;
+        f16*   s_q   = reinterpret_cast<f16*>(smem);
+        f16*   s_k   = s_q + DH;
+        f16*   s_v   = s_k + DH;
+        float* s_red = reinterpret_cast<float*>(s_v + DH);  // [NW] maxima | [NW] sums | [NW][DH] outputs
+        __syncthreads();  // q | k | v (+ bias) written by sweep_qkv
+        if (p.rot > 0 && tx < p.rot / 2) {
+            const int j = tx;
+            f16       a = s_q[j], c = s_q[j + p.rot / 2];
+            rotary_apply(a, c, rot_cs, rot_sn);
+            s_q[j]             = a;
+            s_q[j + p.rot / 2] = c;
+            if (owns_cur) {
+                f16 ka = s_k[j], kc2 = s_k[j + p.rot / 2];
+                rotary_apply(ka, kc2, rot_cs, rot_sn);
+                s_k[j]             = ka;
+                s_k[j + p.rot / 2] = kc2;
+            }
+        }
+        __syncthreads();
+        if (APPEND && owns_cur && tx < DH) {  // append to the cache (:1397, :1837)
+            ((__attribute__((address_space(1))) f16*)lw.k_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_k[tx];
+            ((__attribute__((address_space(1))) f16*)lw.v_cache)[(((size_t)b * p.nh + h) * p.s_max + tl) * DH + tx] = s_v[tx];
+        }
+        const float inv_sqrt_dh = rsqrtf((float)DH);
+        const f16x8 qv          = *reinterpret_cast<const f16x8*>(s_q + sub * 8);
+        float       sc[UK];
+        float       lmax = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+            const f16x8 kv = __builtin_bit_cast(f16x8, kr(st, u));
+            float       a  = 0.f;
+            a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
+            a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
+            a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
+            a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
+            a              = group_sum_dpp<LPK>(a) * inv_sqrt_dh;
+            const int  t   = t_beg + u * PS_NW * KPI + wid * KPI + grp;
+            // (rows beyond tlength were fetched speculatively and may hold anything; masked tokens: weight 0)
+            const bool ok = t < t_cached_end && ((mask_bits >> u) & 1u) == 0u;
+            sc[u]         = ok ? a : -INFINITY;
+            lmax          = fmaxf(lmax, sc[u]);
+        }
+        float cur_p = -INFINITY;  // wave 0: the current token from LDS (:1407-1437)
+        if (owns_cur && wid == 0) {
+            float a = 0.f;
+            if (lane < LPK) {
+                const f16x8 kv = *reinterpret_cast<const f16x8*>(s_k + lane * 8);
+                const f16x8 q8 = *reinterpret_cast<const f16x8*>(s_q + lane * 8);
+                a              = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
+                a              = dot2(f16x2{q8[2], q8[3]}, f16x2{kv[2], kv[3]}, a);
+                a              = dot2(f16x2{q8[4], q8[5]}, f16x2{kv[4], kv[5]}, a);
+                a              = dot2(f16x2{q8[6], q8[7]}, f16x2{kv[6], kv[7]}, a);
+            }
+            cur_p = wave_sum_dpp(a) * inv_sqrt_dh;
+            lmax  = fmaxf(lmax, cur_p);
+        }
+        const float m_w = wave_max_dpp(lmax);
+        float       acc[8];
+        float       lsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UK; u++) {
+            const bool  ok  = sc[u] != -INFINITY;
+            const float pt  = ok ? __expf(sc[u] - m_w) : 0.f;
+            const u32x4 raw = vr(st, u);
+            const u32x4 vz  = {ok ? raw.x : 0u, ok ? raw.y : 0u, ok ? raw.z : 0u, ok ? raw.w : 0u};
+            const f16x8 vv  = __builtin_bit_cast(f16x8, vz);
+            lsum += (sub == 0) ? pt : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+            }
+        }
+        if (owns_cur && wid == 0) {
+            const float pt = __expf(cur_p - m_w);
+            lsum += (lane == 0) ? pt : 0.f;
+            if (grp == 0) {
+                const f16x8 vv = *reinterpret_cast<const f16x8*>(s_v + sub * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    acc[j] = fmaf(pt, (float)vv[j], acc[j]);
+                }
+            }
+        }
+        const float l_w = wave_sum_dpp(lsum);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            acc[j] = across_groups_sum<LPK>(acc[j]);
+        }
+        float* s_o = s_red + 2 * PS_NW;  // [NW][DH]
+        if (grp == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                s_o[wid * DH + sub * 8 + j] = acc[j];
+            }
+        }
+        if (lane == 0) {
+            s_red[wid]         = m_w;
+            s_red[PS_NW + wid] = l_w;
+        }
+        __syncthreads();
+        float m_loc = s_red[0];
+#pragma unroll
+        for (int w = 1; w < PS_NW; w++) {
+            m_loc = fmaxf(m_loc, s_red[w]);
+        }
+        float wgt[PS_NW], ls = 0.f;
+#pragma unroll
+        for (int w = 0; w < PS_NW; w++) {  // wave order: deterministic
+            wgt[w] = (s_red[w] == -INFINITY) ? 0.f : __expf(s_red[w] - m_loc);
+            ls += wgt[w] * s_red[PS_NW + w];
+        }
+        if (tx < DH) {
+            float o = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_NW; w++) {
+                o += wgt[w] * s_o[w * DH + tx];
+            }
+            st_granule(&gout[tx], tag, o);
+        }
+        if (tx == 0) {
+            st_granule(&gout[DH], tag, m_loc);
+            st_granule(&gout[DH + 1], tag, ls);
+        }
+        return true;
     }
     // returns false when the row is finished (nothing published)
     // APPEND false: the caller appends the current token's K / V to the cache itself, after the call (append_current) -- the
@@ -2266,7 +2431,12 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 }
                 at.sweep_qkv(p, s.att, tag, a_h, a_b, tid);
                 stamp(l, 6);
-                live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
+                if constexpr (PS_ATT_WP != 0) {
+                    live = at.compute_wp(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
+                }
+                else {
+                    live = at.compute(p, lw, s.att, gall + (size_t)a_sp * (DH + 2), tag, a_h, a_b, tid, st);
+                }
             }
             if constexpr (!A3F) {
 #ifndef PS_MID_ALL
