@@ -161,7 +161,11 @@ __device__ __forceinline__ bool winar_wait(const WinArParams& p, const size_t sl
             __hip_atomic_store((__attribute__((address_space(1))) int*)&p.sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    return __syncthreads_and(ok ? 1 : 0) != 0;
+    const bool all_ok = __syncthreads_and(ok ? 1 : 0) != 0;
+    // acquire at system scope: nothing of this workgroup reads the peers' buffers out of a line cached before their flags
+    // showed this call (the writers release with __threadfence_system() before they store the flag)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    return all_ok;
 }
 
 __global__ __launch_bounds__(256) void k_window_allreduce(const WinArParams p)
