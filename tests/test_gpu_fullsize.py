@@ -226,12 +226,12 @@ def test_full_depth_13b_int8_follows_the_oracle(full):
           ["%.2e" % (np.abs(lg[t, 0] - ref["logits"][t, 0]).max() / scale) for t in range(out)])
     for t in range(out):
         err = np.abs(lg[t, 0] - ref["logits"][t, 0]).max() / scale
-        # 40 layers of fp16 activations with different (but each exact-in-fp32) summation orders on the two sides: 2e-2 of the
-        # logit range; the argmax must agree unless the oracle's own top-2 margin is inside that band
-        assert err <= 2e-2, (t, err)
+        # 40 layers of fp16 activations with different (but each exact-in-fp32) summation orders on the two sides: measured
+        # 1.8e-3 .. 2.2e-3 of the logit range over the eight steps (profiles/r04_notes.md), the bound is twice the worst; the argmax must agree unless the oracle's own top-2 margin is inside that band
+        assert err <= 4.5e-3, (t, err)
         if tok[0, S + t] != ref["output_ids"][0, S + t]:
             top2 = np.sort(ref["logits"][t, 0])[-2:]
-            assert top2[1] - top2[0] <= 2e-2 * scale, (t, "token flip without a near tie")
+            assert top2[1] - top2[0] <= 4.5e-3 * scale, (t, "token flip without a near tie")
             break
 
 

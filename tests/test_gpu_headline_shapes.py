@@ -133,11 +133,11 @@ def test_1024_token_prompt_at_the_13b_layer_shape_against_the_oracle(capi, dtype
         err = np.abs(lg[t, 0] - ref["logits"][t, 0]).max() / scale
         worst = max(worst, err)
         # the first token's logits come out of the PROMPT phase (1024-row tiled GEMMs, MFMA prompt attention over 1024 keys),
-        # the next two out of the decode path over a 1024-token cache; measured 1.3e-3 / 1.6e-3 (int8 / fp16) of the logit
-        # range: twice that, like the other oracle tests at this layer shape
-        assert err <= 4e-3, (dtype, t, err)
+        # the next two out of the decode path over a 1024-token cache; measured 8.9e-4 / 9.2e-4 (int8 / fp16) of the logit
+        # range (profiles/r04_notes.md): the bound is twice that
+        assert err <= 2e-3, (dtype, t, err)
         if tok[0, S + t] != ref["output_ids"][0, S + t]:
             top2 = np.sort(ref["logits"][t, 0])[-2:]
-            assert top2[1] - top2[0] <= 4e-3 * scale, (dtype, t, "token flip without a near tie")
+            assert top2[1] - top2[0] <= 2e-3 * scale, (dtype, t, "token flip without a near tie")
             break
     print(f"1024-token prompt, {dtype}: worst logit error {worst:.2e} of the range")
