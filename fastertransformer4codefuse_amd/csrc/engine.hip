@@ -423,6 +423,9 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         in_len = tiled_len;
     }
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, in_len, state, B, S, s_max, stream, K);
+    if (B <= 4 && !fp32) {  // the tagged partials of k_lm_head_greedy: a tag is the step, and steps repeat from request to request
+        FTCF_HIP_CHECK(hipMemsetAsync(samp_ws, 0, lm_head_greedy_partial_bytes(B), stream));
+    }
     if (S > 1 && K > 1 && fp32) {
         launch32_prompt_embedding(F(px), nullptr, F(wte), a.input_ids, batch, S, H, stream);
         launch_tile_prompt_ids(step_ids, a.input_ids, batch, K, S, stream);
@@ -581,7 +584,14 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
                 lm_head_dispatch(nrm, Wrows, out, B, rows, H, ld, stream);
             }
         };
+        // one GPU, <= 4 rows, an all-greedy step: the LM head launch picks the tokens, closes the step and prepares the next
+        // token's input itself (k_lm_head_greedy) -- nothing is launched behind it
+        const bool lm_greedy = !lm_done && tp == 1 && fuse_ln && ses.K == 1 && lm_head_greedy_ok(ses.sp, H);
         if (lm_done) {
+        }
+        else if (lm_greedy) {
+            timed(KIND_LM_HEAD, 2.0 * V * H,
+                  [&] { launch_lm_head_greedy(x, lm_head, logits, H, final_g, final_b, 1e-5f, ses.sp, stream); });
         }
         else if (tp == 1) {
             timed(KIND_LM_HEAD, 2.0 * V * H, [&] { lm(lm_head, logits, V, V); });
@@ -600,7 +610,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
     if (ses.K > 1) {
         dynamic_decode_layer.forward(ses.bp, ses.sp, stream);
     }
-    else {
+    else if (!lm_greedy) {
         dynamic_decode_layer.forward(ses.sp, stream);
     }
 }
@@ -817,6 +827,10 @@ void ftcf_gptneox::finish()
             throw Error(-2, "exchange-window all-reduce gave up waiting for a peer (its kernel was not running next to this one)");
         }
     }
+    if (h_flags[2] != 0) {  // k_lm_head_greedy's finishing workgroup never saw some workgroup's partial (cannot happen: bounded all the same)
+        h_flags[2] = 0;
+        throw Error(-2, "LM head + greedy decode: the finishing workgroup gave up waiting for the partials of the launch");
+    }
     if (smallm_error != 0) {
         throw Error(-2, "batched decode GEMM: a split-K reducer gave up waiting for its sibling workgroups' partial sums");
     }
@@ -1022,7 +1036,7 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
             e->use_graph = atoi(m) != 0;
         }
         FTCF_HIP_CHECK(hipHostMalloc((void**)&e->h_flags, 64, hipHostMallocDefault));
-        e->h_flags[0] = e->h_flags[1] = 0;
+        e->h_flags[0] = e->h_flags[1] = e->h_flags[2] = 0;
         FTCF_HIP_CHECK(hipStreamSynchronize(e->stream));
         if (e->bounce) {
             (void)hipFree(e->bounce);

@@ -387,6 +387,14 @@ void   launch_gather_tree_beam(int* output_ids, int* sequence_lengths, const int
                                int end_id, hipStream_t s);
 size_t sampling_workspace_bytes(int B, int V);
 void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish = true);
+// LM head (final LayerNorm fused, as launch_lm_head with gamma) + the all-greedy dynamic decode of the token + the next token's
+// prologue in ONE launch (k_lm_head_greedy): one GPU, <= 4 rows, a step launch_dynamic_decode would run as k_greedy_decode.
+// The workgroups' partials are tagged with the step: the first lm_head_greedy_partial_bytes(B) bytes of the sampling workspace
+// must be zero at the start of a request.
+bool   lm_head_greedy_ok(const SamplingParams& p, int K);
+size_t lm_head_greedy_partial_bytes(int B);
+void   launch_lm_head_greedy(const f16* x, const f16* W, float* logits, int K, const f16* gamma, const f16* beta, float eps,
+                             const SamplingParams& p, hipStream_t s);
 void   launch_decode_init(uint8_t* finished, int* seq_len, float* cum_log_probs, int* pad_count, uint8_t* masked_tokens,
                           uint64_t* draw_counter, const int* input_lengths, DecodeState* st, int B, int max_input_len,
                           int s_max, hipStream_t s, int beam_width = 1);

@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "gemv_device.hip.h"
+#include "lm_head_device.hip.h"
 
 namespace ftcf {
 
@@ -184,90 +185,8 @@ __global__ __launch_bounds__(256) void k_lm_head(const f16* __restrict__ x, cons
     }
     f16*   xs  = reinterpret_cast<f16*>(smem);  // [M][K]
     float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2);
-    if (gamma) {
-        // fused final LayerNorm (GptNeoX.cc:854-863 invokeGeneralLayerNorm, half2-path numerics): every block
-        // normalises the tiny [M,K] hidden state itself instead of paying a kernel boundary for it
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-            const f16* xr   = x + (size_t)m * K;
-            float      s[2] = {0.f, 0.f};
-            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float f = (float)v[j];
-                    s[0] += f;
-                    s[1] += f * f;
-                }
-            }
-            block_sum<2>(s, red);
-            const float mean = s[0] / (float)K;
-            const float rstd = rsqrtf(s[1] / (float)K - mean * mean + eps);
-            const f16   mh = (f16)mean, rh = (f16)rstd;
-            for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-                const f16x8 v  = *reinterpret_cast<const f16x8*>(xr + i);
-                const f16x8 gg = *reinterpret_cast<const f16x8*>(gamma + i);
-                const f16x8 bb = *reinterpret_cast<const f16x8*>(beta + i);
-                f16x8       o;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    o[j] = (((v[j] - mh) * rh) * gg[j]) + bb[j];
-                }
-                *reinterpret_cast<f16x8*>(xs + (size_t)m * K + i) = o;
-            }
-        }
-    }
-    else {
-        for (int i = threadIdx.x * 8; i < M * K; i += 256 * 8) {
-            *reinterpret_cast<f16x8*>(xs + i) = *reinterpret_cast<const f16x8*>(x + i);
-        }
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nwaves = gridDim.x * 4;
-    constexpr int R  = 4;
-    for (int r0 = (blockIdx.x * 4 + wid) * R; r0 < n_rows; r0 += nwaves * R) {
-        float acc[R][M];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                acc[r][m] = 0.f;
-            }
-        }
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            u32x4 w[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int row = (r0 + r < n_rows) ? (r0 + r) : (n_rows - 1);
-                w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)row * K + k));
-            }
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const f16x8 xv = *reinterpret_cast<const f16x8*>(xs + (size_t)m * K + k);
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const f16x8 b = __builtin_bit_cast(f16x8, w[r]);
-                    float       a = acc[r][m];
-                    a             = dot2(f16x2{b[0], b[1]}, f16x2{xv[0], xv[1]}, a);
-                    a             = dot2(f16x2{b[2], b[3]}, f16x2{xv[2], xv[3]}, a);
-                    a             = dot2(f16x2{b[4], b[5]}, f16x2{xv[4], xv[5]}, a);
-                    a             = dot2(f16x2{b[6], b[7]}, f16x2{xv[6], xv[7]}, a);
-                    acc[r][m]     = a;
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const float v = wave_sum(acc[r][m]);
-                if (lane == 0 && r0 + r < n_rows) {
-                    logits[(size_t)m * ldc + r0 + r] = v;
-                }
-            }
-        }
-    }
+    lm_head_stage_x<M>(x, K, gamma, beta, eps, xs, red);
+    lm_head_rows<M>(W, logits, n_rows, K, ldc, xs, [](int, int, float) {});
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include "ftcf_common.h"
 #include "kernels.h"
 #include "attn_device.hip.h"  // rotary_coef (the next token's prologue inside k_greedy_decode)
+#include "lm_head_device.hip.h"  // k_lm_head_greedy
 
 #include <mutex>
 
@@ -914,10 +915,11 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
 }
 
 // ---- step 4: stop words, length criterion, bookkeeping (single block) -----------------------------------------
-__device__ __forceinline__ void decode_finish_body(const SamplingParams& p)
+// DEFER_HOST: the caller writes the pinned host flags itself, as the launch's last stores (decode_publish_host)
+template<bool DEFER_HOST = false>
+__device__ __forceinline__ int decode_finish_body(const SamplingParams& p, const int step, const int steps_done = -1)
 {
     __shared__ int s_all;
-    const int      step = p.state->step;
     if (threadIdx.x == 0) {
         s_all = 1;
     }
@@ -959,13 +961,25 @@ __device__ __forceinline__ void decode_finish_body(const SamplingParams& p)
         }
     }
     __syncthreads();
+    const int all = s_all;
     if (threadIdx.x == 0) {
-        p.state->all_finished = s_all;
-        p.state->steps_done += 1;
-        p.h_flags[1] = step;
-        __threadfence_system();
-        p.h_flags[0] = s_all;
+        p.state->all_finished = all;
+        p.state->steps_done   = (steps_done >= 0 ? steps_done : p.state->steps_done) + 1;
+        if constexpr (!DEFER_HOST) {
+            p.h_flags[1] = step;
+            __threadfence_system();
+            p.h_flags[0] = all;
+        }
         p.state->step = step + 1;
+    }
+    return all;
+}
+// (the host reads the flags behind an event of the stream, never while the launch runs: engine.hip step())
+__device__ __forceinline__ void decode_publish_host(const SamplingParams& p, const int step, const int all)
+{
+    if (threadIdx.x == 0) {
+        p.h_flags[1] = step;
+        p.h_flags[0] = all;
     }
 }
 
@@ -974,7 +988,196 @@ __global__ void k_decode_finish(const SamplingParams p)
     if (p.state->all_finished) {
         return;  // a token of a multi-token graph behind the request's last one (engine.hip step()): nothing to do
     }
-    decode_finish_body(p);
+    decode_finish_body(p, p.state->step);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail of an all-greedy step, run by the ONE workgroup (256 threads) that drew the launch's last ticket (k_greedy_decode,
+// k_lm_head_greedy): every row's token from the slices' partials part[B][nsl][4] = {best value, its id, slice max, slice sum of
+// exponentials} exactly as k_sample does for k = 1 (sampling_topk_kernels.cu:210-311: probability of the best token under the
+// row's soft-max, the uniform draw consumed, cum_log_probs, sequence length, finished), the step's bookkeeping
+// (decode_finish_body) and the NEXT token's prologue (k_step_prologue: decoding_kernels.cu:145-191 embedding lookup + the
+// step's rotary table).  Everything here is a chain of dependent memory round trips on the token's critical path (this tail
+// was 10 of k_greedy_decode's 17 us): a row's state is requested together with its partials, the embedding row as soon as the
+// token is known, the pinned host flags are the last stores.
+// ---------------------------------------------------------------------------------------------------------------------
+// TAGGED: the partials are granules {tag, value} (part: [B][nsl][4] 8-byte words, the value in the low half) written by
+// workgroups that may still be running: a batch of partials is re-read until every tag is `tag` (bounded: a give-up sets
+// p.h_flags[2] and the step is finished on what is there).
+constexpr int GREEDY_MAXQ = 4;  // partials of a row a thread requests together
+constexpr int GREEDY_SPINS = 1 << 20;
+template<bool TAGGED = false>
+__device__ __forceinline__ void greedy_finish(const SamplingParams& p, const float* part, const int nsl, const int step,
+                                              const unsigned tag = 0u)
+{
+    __shared__ float x_v[2][4], x_m[2][4], x_s[2][4];
+    __shared__ int   x_i[2][4];
+    __shared__ int   s_ids[8];
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int       steps_done = 0;
+    if (threadIdx.x == 0) {
+        steps_done = p.state->steps_done;
+    }
+    int picked = 0;
+    for (int row = 0; row < p.B; row++) {
+        int* out_id = p.output_ids + (size_t)step * p.B + row;
+        if (p.finished[row]) {
+            if (threadIdx.x == 0) {
+                *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242
+                if (row < 8) {
+                    s_ids[row] = p.end_id;
+                }
+            }
+            continue;
+        }
+        // thread 0's view of the row's state travels with the partials
+        uint64_t draws = 0;
+        float    cum   = 0.f;
+        int      slen  = 0;
+        if (threadIdx.x == 0) {
+            draws = p.draw_counter[row];
+            slen  = p.seq_len[row];
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                cum = p.cum_log_probs[row];
+            }
+        }
+        const gu32* q = (const gu32*)(part + (size_t)row * nsl * 4);
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+        const gu64* qg = (const gu64*)(reinterpret_cast<const unsigned long long*>(part) + (size_t)row * nsl * 4);
+        VI    cand{-INFINITY, 0x7fffffff};
+        float mq = -FLT_MAX, sq = 0.f;
+#pragma unroll 1
+        for (int j0 = 0; j0 < nsl; j0 += 256 * GREEDY_MAXQ) {  // (GREEDY_MAXQ partials of a thread travel together)
+            unsigned pv[GREEDY_MAXQ][4];
+            if constexpr (TAGGED) {
+                int spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < GREEDY_MAXQ; j++) {
+                        const int sl = j0 + threadIdx.x + 256 * j;
+                        const int sc = sl < nsl ? sl : nsl - 1;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const unsigned long long g = __hip_atomic_load(qg + (size_t)sc * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pv[j][e] = (unsigned)g;
+                            ok &= (unsigned)(g >> 32) == tag;
+                        }
+                    }
+                    if (__syncthreads_and(ok ? 1 : 0)) {
+                        break;
+                    }
+                    if (++spins > GREEDY_SPINS) {
+                        if (threadIdx.x == 0) {
+                            p.h_flags[2] = 1;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            else {
+#pragma unroll
+                for (int j = 0; j < GREEDY_MAXQ; j++) {
+                    const int sl = j0 + threadIdx.x + 256 * j;
+                    const int sc = sl < nsl ? sl : nsl - 1;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        pv[j][e] = __hip_atomic_load(q + (size_t)sc * 4 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < GREEDY_MAXQ; j++) {
+                if (j0 + (int)threadIdx.x + 256 * j < nsl) {
+                    const float v = __uint_as_float(pv[j][0]);
+                    const int   i = (int)pv[j][1];
+                    if (better(v, i, cand.v, cand.i)) {
+                        cand.v = v;
+                        cand.i = i;
+                    }
+                    const float m2 = __uint_as_float(pv[j][2]), s2 = __uint_as_float(pv[j][3]);
+                    const float mn = fmaxf(mq, m2);
+                    sq             = sq * __expf(mq - mn) + s2 * __expf(m2 - mn);
+                    mq             = mn;
+                }
+            }
+        }
+        const VI    wb = wave_best(cand);
+        const float wm = wave_max(mq);
+        const float ws = wave_sum(sq * __expf(mq - wm));  // (threads without a slice add 0 * exp(.) = 0)
+        const int   pb = (picked++) & 1;                  // (two sets of slots: one barrier per row)
+        if (lane == 0) {
+            x_v[pb][wid] = wb.v;
+            x_i[pb][wid] = wb.i;
+            x_m[pb][wid] = wm;
+            x_s[pb][wid] = ws;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            VI    r{x_v[pb][0], x_i[pb][0]};
+            float row_max = x_m[pb][0];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                if (better(x_v[pb][w], x_i[pb][w], r.v, r.i)) {
+                    r.v = x_v[pb][w];
+                    r.i = x_i[pb][w];
+                }
+                row_max = fmaxf(row_max, x_m[pb][w]);
+            }
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                tot += x_s[pb][w] * __expf(x_m[pb][w] - row_max);
+            }
+            float prob = 1.f;
+            if (p.return_cum_log_probs) {
+                prob = __expf(r.v - row_max) / (tot + 1e-6f);
+            }
+            p.draw_counter[row] = draws + 1;  // (the top-k layer draws its uniform number for k = 1 too: sampling_topk_kernels.cu:283)
+            int id = r.i;
+            if (id == 0x7fffffff || id < 0) {
+                id = 0;
+            }
+            *out_id = id;
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                p.cum_log_probs[row] = cum + logf(prob);
+            }
+            p.seq_len[row]  = slen + 1;  // :305-308
+            p.finished[row] = (id == p.end_id);
+            if (row < 8) {
+                s_ids[row] = id;
+            }
+        }
+    }
+    __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
+    if (p.next_x) {
+        // the next token's embedding rows: requested now, under the bookkeeping below
+        for (int row = 0; row < p.B; row++) {
+            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
+            const f16* src = p.wte + (size_t)id * p.H;
+            f16*       dst = p.next_x + (size_t)row * p.H;
+            for (int i = threadIdx.x * 8; i < p.H; i += blockDim.x * 8) {
+                *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+            }
+        }
+    }
+    const int all = decode_finish_body<true>(p, step, steps_done);  // (thread 0's value is the one that is used)
+    if (p.next_x) {
+        __syncthreads();  // (the padding counts of this step: decode_finish_body)
+        const int nstep = step + 1;
+        for (int row = 0; row < p.B; row++) {
+            if ((int)threadIdx.x < p.rot / 2) {
+                const int pos = (nstep - 1) - (p.pad_count ? p.pad_count[row] : 0);
+                float     cs, sn;
+                rotary_coef(threadIdx.x, p.rot, pos, cs, sn);
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2]     = cs;
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2 + 1] = sn;
+            }
+        }
+    }
+    decode_publish_host(p, step, all);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -996,6 +1199,7 @@ __global__ __launch_bounds__(256) void k_greedy_decode(const SamplingParams p, f
     if (p.state->all_finished) {
         return;
     }
+    const int step0 = p.state->step;  // (same cache line as the flag: the finishing workgroup does not pay a round trip for it)
     __shared__ float redv[4];
     __shared__ int   redi[4];
     __shared__ int   s_last;
@@ -1076,73 +1280,149 @@ __global__ __launch_bounds__(256) void k_greedy_decode(const SamplingParams p, f
     if (!s_last) {
         return;
     }
-    const int step = p.state->step;
-    for (int row = 0; row < p.B; row++) {
-        int* out_id = p.output_ids + (size_t)step * p.B + row;
-        if (p.finished[row]) {
-            if (threadIdx.x == 0) {
-                *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242
-            }
-            continue;
-        }
-        typedef __attribute__((address_space(1))) unsigned gu32;
-        const gu32* q = (const gu32*)(part + (size_t)row * GREEDY_SLICES * 4);
-        VI          cand{-INFINITY, 0x7fffffff};
-        if (threadIdx.x < GREEDY_SLICES) {
-            cand.v = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            cand.i = (int)__hip_atomic_load(q + threadIdx.x * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the row's soft-max from the slice statistics, as k_sample: lane q of the first wave holds slice q's {max, sum} (one round
-        // trip for all 32 -- a serial walk by one thread was 96 dependent loads: 10 us of this 17 us kernel)
-        float mq = -FLT_MAX, sq = 0.f;
-        if (p.return_cum_log_probs && threadIdx.x < GREEDY_SLICES) {
-            mq = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            sq = __uint_as_float(__hip_atomic_load(q + threadIdx.x * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        const float row_max = wave_max(mq);                           // (valid in the first wave: thread 0 uses it)
-        const float tot     = wave_sum(sq * __expf(mq - row_max));    // (lanes without a slice add 0 * exp(.) = 0)
-        const VI r = block_best(cand, redv, redi);
-        if (threadIdx.x == 0) {
-            float prob = 1.f;
-            if (p.return_cum_log_probs) {
-                prob = __expf(r.v - row_max) / (tot + 1e-6f);
-            }
-            p.draw_counter[row] += 1;  // (the top-k layer draws its uniform number for k = 1 too: sampling_topk_kernels.cu:283)
-            int id = r.i;
-            if (id == 0x7fffffff || id < 0) {
-                id = 0;
-            }
-            *out_id = id;
-            if (p.return_cum_log_probs && p.cum_log_probs) {
-                p.cum_log_probs[row] += logf(prob);
-            }
-            p.seq_len[row] += 1;  // :305-308
-            p.finished[row] = (id == p.end_id);
-        }
-        __syncthreads();
+    greedy_finish(p, part, GREEDY_SLICES, step0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LM head + the all-greedy dynamic decode of the token in ONE launch (one GPU, <= 4 rows: the headline's token).  The wave
+// that produces a logit keeps the arg max and the soft-max statistics of its vocabulary rows as it goes (wave-uniform
+// registers: the logits never come back from memory), the workgroup publishes ONE partial per row as granules {step tag,
+// value}, and the workgroup dispatched LAST runs greedy_finish on them, re-reading until every tag is this token's.  Against
+// k_lm_head + k_greedy_decode: one launch boundary, the re-read of the logits and the slices' reductions leave the token's
+// critical path.  The logits are still stored (debug taps, tests).  (A first version elected the finisher with two levels of
+// tickets: 192 -> 182 us per launch against 160 + 14.7 for the two kernels -- 2048 arrivals inside the launch's last
+// microseconds cost more than the boundary they replace.)
+// ---------------------------------------------------------------------------------------------------------------------
+template<int M>
+__global__ __launch_bounds__(256, 8) void k_lm_head_greedy(const f16* __restrict__ x, const f16* __restrict__ W,
+                                                        float* __restrict__ logits, const int K,
+                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                        const float eps, const SamplingParams p, unsigned long long* part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.state->all_finished) {
+        return;  // every row has finished: a token of a multi-token graph behind the request's last one
     }
-    __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
-    decode_finish_body(p);
-    if (p.next_x) {
-        // the next token's prologue (k_step_prologue: decoding_kernels.cu:145-191 embedding lookup + the step's rotary table)
-        __syncthreads();  // (thread 0 advanced the step counter)
-        const int nstep = p.state->step;
-        for (int row = 0; row < p.B; row++) {
-            if ((int)threadIdx.x < p.rot / 2) {
-                const int pos = (nstep - 1) - (p.pad_count ? p.pad_count[row] : 0);
-                float     cs, sn;
-                rotary_coef(threadIdx.x, p.rot, pos, cs, sn);
-                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2]     = cs;
-                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2 + 1] = sn;
-            }
-            const int  id  = p.output_ids[(size_t)(nstep - 1) * p.B + row];
-            const f16* src = p.wte + (size_t)id * p.H;
-            f16*       dst = p.next_x + (size_t)row * p.H;
-            for (int i = threadIdx.x * 8; i < p.H; i += blockDim.x * 8) {
-                *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+    const int step0 = p.state->step;
+    __shared__ float w_v[4][M], w_m[4][M], w_s[4][M];
+    __shared__ int   w_i[4][M];
+    f16*   xs  = reinterpret_cast<f16*>(smem);  // [M][K]
+    float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2);
+    // min_length (sampling_penalty_kernels.cu:485-520): end_id cannot be chosen yet
+    bool mask_end[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        mask_end[m] = p.min_length && (p.seq_len[m] + 1 - p.max_input_len < p.min_length[m]);
+    }
+    lm_head_stage_x<M>(x, K, gamma, beta, eps, xs, red);
+    VI    best[M];
+    float vmax[M], ssum[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        best[m] = VI{-INFINITY, 0x7fffffff};
+        vmax[m] = -FLT_MAX;
+        ssum[m] = 0.f;
+    }
+    lm_head_rows<M>(W, logits, p.V, K, p.V, xs, [&](const int m, const int row, float v) {
+#pragma unroll
+        for (int mm = 0; mm < M; mm++) {  // (compile-time indices keep the statistics in registers)
+            if (mm == m) {
+                if (mask_end[mm] && row == p.end_id) {
+                    v = -FLT_MAX;
+                }
+                if (best[mm].i == 0x7fffffff || better(v, row, best[mm].v, best[mm].i)) {
+                    best[mm].v = v;
+                    best[mm].i = row;
+                }
+                const float mn = fmaxf(vmax[mm], v);
+                ssum[mm]       = ssum[mm] * __expf(vmax[mm] - mn) + __expf(v - mn);
+                vmax[mm]       = mn;
             }
         }
+    });
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            w_v[wid][m] = best[m].v;
+            w_i[wid][m] = best[m].i;
+            w_m[wid][m] = vmax[m];
+            w_s[wid][m] = ssum[m];
+        }
     }
+    __syncthreads();
+    const int      nb  = gridDim.x;
+    const unsigned tag = (unsigned)step0 + 1u;
+    if (threadIdx.x == 0) {
+        typedef __attribute__((address_space(1))) unsigned long long gu64;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            VI    r{w_v[0][m], w_i[0][m]};
+            float mx = w_m[0][m];
+#pragma unroll
+            for (int w = 1; w < 4; w++) {
+                if (better(w_v[w][m], w_i[w][m], r.v, r.i)) {
+                    r.v = w_v[w][m];
+                    r.i = w_i[w][m];
+                }
+                mx = fmaxf(mx, w_m[w][m]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                sum += w_s[w][m] * __expf(w_m[w][m] - mx);
+            }
+            // granules {tag, value}, write-through (the reader sits on another XCD); a workgroup without a vocabulary row leaves
+            // the neutral partial {-inf, no id, -FLT_MAX, 0}
+            gu64*                    o  = (gu64*)(part + ((size_t)m * nb + blockIdx.x) * 4);
+            const unsigned long long hi = (unsigned long long)tag << 32;
+            __hip_atomic_store(o + 0, hi | __float_as_uint(r.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 1, hi | (unsigned)r.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 2, hi | __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 3, hi | __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if ((int)blockIdx.x != nb - 1) {
+        return;  // nothing waits for these stores
+    }
+    // the workgroup dispatched last closes the step: no ticket (2048 arrivals at a few addresses inside the launch's last
+    // microseconds cost more than the launch boundary they replace: measured), it re-reads the partials until they carry this
+    // token's tag
+    greedy_finish<true>(p, reinterpret_cast<const float*>(part), nb, step0, tag);
+}
+
+size_t lm_head_greedy_partial_bytes(int B)
+{
+    return (size_t)B * 2048 * 4 * sizeof(unsigned long long);  // granules [B][<= 2048 workgroups][4]
+}
+
+bool lm_head_greedy_ok(const SamplingParams& p, int K)
+{
+    static const int on = getenv("FTCF_LM_GREEDY") ? atoi(getenv("FTCF_LM_GREEDY")) : 1;
+    return on && p.B <= 4 && K % 8 == 0 && dynamic_decode_is_fused(p, true) && p.next_x
+           && lm_head_greedy_partial_bytes(p.B) <= sampling_workspace_bytes(p.B, p.V);
+}
+
+void launch_lm_head_greedy(const f16* x, const f16* W, float* logits, int K, const f16* gamma, const f16* beta, float eps,
+                           const SamplingParams& p, hipStream_t s)
+{
+    FTCF_CHECK_ARG(lm_head_greedy_ok(p, K), "LM head + greedy decode: not an eligible step");
+    const size_t smem = (size_t)p.B * (K + 8) * 2 + 64;
+    int          grid = (p.V + 15) / 16;
+    if (grid > 2048) {
+        grid = 2048;
+    }
+    unsigned long long* part = reinterpret_cast<unsigned long long*>(p.ws);
+#define FTCF_LMG(MM)                                                                                                   \
+    hipLaunchKernelGGL((k_lm_head_greedy<MM>), dim3(grid), dim3(256), smem, s, x, W, logits, K, gamma, beta, eps, p, part)
+    switch (p.B) {
+        case 1: FTCF_LMG(1); break;
+        case 2: FTCF_LMG(2); break;
+        case 3: FTCF_LMG(3); break;
+        default: FTCF_LMG(4); break;
+    }
+#undef FTCF_LMG
+    FTCF_HIP_CHECK(hipGetLastError());
 }
 
 void launch_decode_finish(const SamplingParams& p, hipStream_t s)
