@@ -4,6 +4,7 @@
     cb = ContinuousBatcher(op, max_batch=8, page_tokens=64, num_pages=512, max_seq_len=2048)
     rid = cb.submit(prompt_ids, max_new_tokens=128)          # greedy; top_k / top_p / temperature / seed /
                                                              # repetition_penalty / stop_words optional
+    bid = cb.submit_beam(prompt_ids, 128, beam_width=4)      # beam search: one event (bid, -1, True), then cb.beam_result(bid)
     while cb.busy():
         for request_id, token, finished in cb.step():
             ...
@@ -58,6 +59,33 @@ class ContinuousBatcher:
             sw.ctypes.data_as(C.POINTER(C.c_int)) if sw is not None else None, int(sw_len), C.byref(rid)))
         return int(rid.value)
 
+    def submit_beam(self, prompt_ids, max_new_tokens, beam_width, beam_search_diversity_rate=0.0, len_penalty=0.0, temperature=1.0,
+                    repetition_penalty=1.0):
+        """A beam-search request (GptNeoXOp.forward with beam_width > 1).  step() reports one event for it, (request_id, -1, True),
+        when it has finished; beam_result(request_id) then returns what forward returns for one prompt."""
+        ids = np.ascontiguousarray(prompt_ids, dtype=np.int32).reshape(-1)
+        rid = C.c_long(0)
+        capi.check(capi.lib().ftcf_batcher_submit_beam(
+            self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), int(ids.size), int(max_new_tokens), int(beam_width),
+            C.c_float(beam_search_diversity_rate), C.c_float(len_penalty), C.c_float(temperature), C.c_float(repetition_penalty),
+            C.byref(rid)))
+        return int(rid.value)
+
+    def beam_result(self, request_id):
+        """(output_ids [beam_width, prompt_len + max_new_tokens], sequence_lengths [beam_width], cum_log_probs [beam_width]) of a
+        finished beam request, once; None while it is running or when the id is unknown."""
+        k, t = C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().ftcf_batcher_beam_result(self._h, C.c_long(int(request_id)), None, None, None, 0, C.byref(k), C.byref(t)))
+        if k.value == 0:
+            return None
+        ids = np.zeros((k.value, t.value), dtype=np.int32)
+        lens = np.zeros(k.value, dtype=np.int32)
+        cum = np.zeros(k.value, dtype=np.float32)
+        capi.check(capi.lib().ftcf_batcher_beam_result(
+            self._h, C.c_long(int(request_id)), ids.ctypes.data_as(C.POINTER(C.c_int)), lens.ctypes.data_as(C.POINTER(C.c_int)),
+            cum.ctypes.data_as(C.POINTER(C.c_float)), int(ids.size), C.byref(k), C.byref(t)))
+        return ids, lens, cum
+
     def set_token_callback(self, fn):
         """fn(request_id, token, finished) is called from inside step() for every token the moment it is on the host (between
         the chunks of a long admission as well); None unsets.  The events are still returned by step()."""
@@ -95,7 +123,8 @@ class ContinuousBatcher:
         it = 0
         while self.busy():
             for rid, tok, _ in self.step():
-                out.setdefault(rid, []).append(tok)
+                if tok >= 0:  # (a beam request's only event carries -1: its hypotheses come from beam_result)
+                    out.setdefault(rid, []).append(tok)
             it += 1
             if it > max_iterations:
                 raise RuntimeError("the batcher did not drain")

@@ -1,6 +1,8 @@
 // Continuous batching over a paged K/V cache (include/ftcf.h `ftcf_batcher_*`): split out of engine.hip in round 4.
 #include "engine.hip.h"
 
+#include <set>
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Continuous batching over a paged K/V cache (no counterpart in the reference, whose serving layer -- the
@@ -17,8 +19,8 @@
 // step is the general layer sequence of the engine (§4a: dual LayerNorm, burst / tiled GEMMs, fused residual) with the
 // attention replaced by k_mmha_paged, the LM head, and the engine's sampling kernels on per-slot arrays.  A sequence leaves
 // when it emits end_id or reaches max_new_tokens; its pages return to the free list at once.
-// Scope: parallel-residual models, any tensor_para_size (round 4: one batcher per rank), fp16 / int8 engines, beam_width 1, top-k /
-// top-p / temperature sampling (no repetition penalty, stop words or callbacks).
+// Scope: parallel-residual models, any tensor_para_size (round 4: one batcher per rank), fp16 / int8 engines; top-k / top-p /
+// temperature sampling with repetition penalty, stop words and a token callback; beam search (round 4: BeamGroup below).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_batcher_embed(f16* out, const f16* table, const int* tok, int H)
 {
@@ -42,6 +44,44 @@ __global__ void k_batcher_tick(DecodeState* gemm_state)
     gemm_state->step = (gemm_state->step + 1) & 0x7ffff;  // part of the burst GEMMs' granule tags (19 bits)
 }
 
+// beam groups (see ftcf_batcher::BeamGroup): copy-on-write of K/V pages, every layer of both pools; pairs = {src, dst} page ids
+__global__ void k_batcher_copy_pages(f16* kpool, f16* vpool, const int* pairs, size_t page_elems, size_t pool_layer_elems)
+{
+    f16*         pool = blockIdx.z ? vpool : kpool;
+    const int    src = pairs[2 * blockIdx.x], dst = pairs[2 * blockIdx.x + 1];
+    const u32x4* sp = reinterpret_cast<const u32x4*>(pool + (size_t)blockIdx.y * pool_layer_elems + (size_t)src * page_elems);
+    u32x4*       dp = reinterpret_cast<u32x4*>(pool + (size_t)blockIdx.y * pool_layer_elems + (size_t)dst * page_elems);
+    for (size_t i = threadIdx.x; i < page_elems / 8; i += blockDim.x) {
+        dp[i] = sp[i];
+    }
+}
+// the sampling kernels' view of `finished`: the rows of beam groups are not theirs (merge = 0: make the view, 1: take the
+// sampled rows' new flags back)
+__global__ void k_batcher_sampling_view(uint8_t* sfin, uint8_t* fin, const uint8_t* isbeam, int B, int merge)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        if (!merge) {
+            sfin[b] = fin[b] | isbeam[b];
+        }
+        else if (!isbeam[b]) {
+            fin[b] = sfin[b];
+        }
+    }
+}
+__global__ void k_batcher_set_step(DecodeState* st, int step)
+{
+    st->step = step;
+}
+// a group's beams after k_beam_batch: next input token = the word chosen for the beam, one more cached position
+__global__ void k_batcher_beam_advance(int* tok, int* len, const int* out_row, int K)
+{
+    if ((int)threadIdx.x < K) {
+        tok[threadIdx.x] = out_row[threadIdx.x];
+        len[threadIdx.x] += 1;
+    }
+}
+
 struct ftcf_batcher {
     struct Request {
         long             id;
@@ -50,6 +90,8 @@ struct ftcf_batcher {
         float            top_p, temperature, repetition_penalty = 1.f;
         uint64_t         seed;
         std::vector<std::vector<int>> stop;  // stop sequences (token ids)
+        int              beam_width = 1;     // > 1: a beam group (submit_beam)
+        float            diversity = 0.f, len_penalty = 0.f;
     };
     struct Slot {
         bool             active = false;
@@ -62,7 +104,30 @@ struct ftcf_batcher {
         std::vector<int>              hist;
         std::vector<std::vector<int>> stop;
         float                         repetition_penalty = 1.f;
+        int                           group = -1;  // a beam of the group whose first slot this is (-1: an ordinary sequence)
     };
+    // Beam search inside the batcher (round 4; the reference's serving layer runs beam requests through the same decoder:
+    // triton_backend/gptneox/GptNeoXTritonModelInstance.cc).  A request of beam width K lives in K CONSECUTIVE slots -- its
+    // beams ride in the same batched GEMMs as everybody else's rows -- and is scored by the engine's own beam kernels
+    // (launch_beam_search with batch 1: OnlineBeamSearchLayer semantics, kernels_sampling.hip) on per-group state.  The cache
+    // indirection of the reference (BaseBeamSearchLayer.cu:30-62: which beam's cache row holds position t) is replaced by what a
+    // paged cache is for: after every step beam k's page list becomes a copy of its parent's (pages are reference counted),
+    // and only the page the next token will be appended to is copied when it is shared (copy-on-write, all layers, one launch
+    // per step); the attention kernel is the ordinary paged one.  The prompt's pages are written once and shared by all beams.
+    struct BeamGroup {
+        long id = 0;
+        int  si = 0, K = 0, n = 0, max_new = 0, generated = 0, budget = 0;
+        bool penalised = false;  // repetition_penalty != 1
+        std::vector<std::vector<int>> lists;  // page list of every beam
+    };
+    struct BeamResult {
+        int                K = 0, total = 0;
+        std::vector<int>   ids, lens;
+        std::vector<float> cum;
+    };
+    std::map<int, BeamGroup>   groups;        // by first slot
+    std::map<long, BeamResult> beam_results;  // finished beam requests until they are fetched
+    std::vector<int>           page_ref;      // references to a page (ordinary sequences: 1)
     ftcf_gptneox* e = nullptr;
     int           max_batch = 0, P = 0, num_pages = 0, max_pages = 0, max_len = 0;
     size_t        pool_layer_elems = 0;
@@ -74,6 +139,13 @@ struct ftcf_batcher {
     int *     d_pt = nullptr, *d_len = nullptr, *d_tok = nullptr, *d_topk = nullptr, *d_zero = nullptr, *d_prompt = nullptr, *d_plen = nullptr,
         *d_pout = nullptr, *d_pseq = nullptr, *d_pages_tmp = nullptr;
     uint8_t*     d_fin = nullptr;
+    // beam groups: the sampling kernels' view of d_fin, which slots are beams, per-group state of the beam kernels
+    uint8_t *    d_sfin = nullptr, *d_isbeam = nullptr;
+    int *        d_bout = nullptr, *d_bpar = nullptr, *d_bseq = nullptr, *d_bin = nullptr, *d_pairs = nullptr, *d_bres = nullptr,
+        *d_bres_len = nullptr;
+    float *      d_btemp = nullptr, *d_brep = nullptr, *d_bdiv = nullptr, *d_blen = nullptr;
+    DecodeState* d_bstate = nullptr;
+    void*        beam_ws = nullptr;
     float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr, *d_rep = nullptr;
     int*         d_hist = nullptr;  // [max_len + 1][max_batch] time-major token history of the slots (repetition penalty)
     int *        d_sw = nullptr;    // admission: stop words of the ragged batch, the reference's [n][2][Lw] layout
@@ -154,6 +226,21 @@ struct ftcf_batcher {
         d_topk = dmalloc<int>(B);
         d_zero = dmalloc<int>(B);
         d_fin = dmalloc<uint8_t>(B);
+        d_sfin = dmalloc<uint8_t>(B);
+        d_isbeam = dmalloc<uint8_t>(B);
+        d_bout = dmalloc<int>(B * (max_len + 2));
+        d_bpar = dmalloc<int>(B * (max_len + 2));
+        d_bres = dmalloc<int>(B * (max_len + 2));
+        d_bres_len = dmalloc<int>(B);
+        d_bseq = dmalloc<int>(B);
+        d_bin = dmalloc<int>(B);
+        d_pairs = dmalloc<int>(2 * B);
+        d_btemp = dmalloc<float>(B);
+        d_brep = dmalloc<float>(B);
+        d_bdiv = dmalloc<float>(B);
+        d_blen = dmalloc<float>(B);
+        d_bstate = dmalloc<DecodeState>(B);
+        beam_ws = dmalloc<char>(beam_workspace_bytes(1, std::min(max_batch, BEAM_MAX_K)));
         d_ptopk = dmalloc<float>(B);
         d_ptopp = dmalloc<float>(B);
         d_temp = dmalloc<float>(B);
@@ -188,6 +275,37 @@ struct ftcf_batcher {
         for (int i = 0; i < num_pages; i++) {
             free_pages[i] = num_pages - 1 - i;
         }
+        page_ref.assign(num_pages, 0);
+    }
+    int take_page()
+    {
+        if (free_pages.empty()) {
+            throw Error(-2, "batcher: the page pool is exhausted (a reservation was wrong)");
+        }
+        const int pg = free_pages.back();
+        free_pages.pop_back();
+        page_ref[pg] = 1;
+        return pg;
+    }
+    void drop_page(const int pg)
+    {
+        if (--page_ref[pg] == 0) {
+            free_pages.push_back(pg);
+        }
+    }
+    // pages promised to running beam groups but not yet taken (a group takes its pages as its beams diverge: at most
+    // budget = K * pages of one full-length sequence)
+    int reserved_pages() const
+    {
+        int r = 0;
+        for (const auto& kv : groups) {
+            std::set<int> held;
+            for (const auto& l : kv.second.lists) {
+                held.insert(l.begin(), l.end());
+            }
+            r += std::max(0, kv.second.budget - (int)held.size());
+        }
+        return r;
     }
 
     static constexpr int STOP_LW = 64;  // total stop-word tokens per request (the [2][Lw] word list of the admission)
@@ -225,6 +343,38 @@ struct ftcf_batcher {
             r.stop.emplace_back(stop_words + start, stop_words + end);
             start = end;
         }
+        waiting.push_back(std::move(r));
+        return waiting.back().id;
+    }
+
+    // a beam-search request (GptNeoXOp.forward with beam_width > 1: OnlineBeamSearchLayer): K consecutive slots; one event when
+    // it has finished (token = -1), the K hypotheses through beam_result()
+    long submit_beam(const int* ids, int n, int max_new, int beam_width, float diversity, float len_penalty, float temperature,
+                     float repetition_penalty)
+    {
+        FTCF_CHECK_ARG(beam_width >= 2 && beam_width <= BEAM_MAX_K && beam_width <= max_batch,
+                       "beam_width must be in [2, 64] and fit the batcher's slots");
+        FTCF_CHECK_ARG(repetition_penalty > 0.f && temperature > 0.f, "repetition_penalty and temperature must be positive");
+        FTCF_CHECK_ARG(((size_t)max_len + 2) * 8 <= 60 * 1024 || repetition_penalty == 1.f,
+                       "max_seq_len too large for the repetition-penalty staging buffer");
+        FTCF_CHECK_ARG(ids && n >= 1 && max_new >= 1, "empty prompt or max_new_tokens < 1");
+        FTCF_CHECK_ARG(n + max_new <= max_len && n <= max_prompt, "prompt + max_new_tokens exceed the batcher's max_seq_len");
+        FTCF_CHECK_ARG(beam_width * ((n + max_new + P - 1) / P) <= num_pages, "the request needs more pages than the pool has");
+        for (int i = 0; i < n; i++) {
+            FTCF_CHECK_ARG(ids[i] >= 0 && ids[i] < e->V, "token id out of range");
+        }
+        Request r;
+        r.id = next_id++;
+        r.prompt.assign(ids, ids + n);
+        r.max_new = max_new;
+        r.top_k = 1;
+        r.top_p = 0.f;
+        r.temperature = temperature;
+        r.seed = 0;
+        r.repetition_penalty = repetition_penalty;
+        r.beam_width = beam_width;
+        r.diversity = diversity;
+        r.len_penalty = len_penalty;
         waiting.push_back(std::move(r));
         return waiting.back().id;
     }
@@ -269,7 +419,7 @@ struct ftcf_batcher {
     void release(Slot& s)
     {
         for (int pg : s.pages) {
-            free_pages.push_back(pg);
+            drop_page(pg);
         }
         s.pages.clear();
         s.active = false;
@@ -315,8 +465,7 @@ struct ftcf_batcher {
             const int need = (lens[i] + r.max_new + P - 1) / P;
             s.pages.clear();
             for (int k = 0; k < need; k++) {
-                s.pages.push_back(free_pages.back());
-                free_pages.pop_back();
+                s.pages.push_back(take_page());
             }
         }
         FTCF_HIP_CHECK(hipMemcpy(d_prompt, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
@@ -397,6 +546,271 @@ struct ftcf_batcher {
                 const uint8_t one8 = 1;
                 FTCF_HIP_CHECK(hipMemcpy(d_fin + si, &one8, 1, hipMemcpyHostToDevice));
                 release(s);
+            }
+        }
+    }
+
+    // ---- beam groups ------------------------------------------------------------------------------------------------
+    void upload_group_tables(const BeamGroup& g, hipStream_t st)
+    {
+        std::vector<int> rows((size_t)g.K * max_pages, 0);
+        for (int k = 0; k < g.K; k++) {
+            std::copy(g.lists[k].begin(), g.lists[k].end(), rows.begin() + (size_t)k * max_pages);
+        }
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_pt + (size_t)g.si * max_pages, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));  // (the host temporary dies here)
+    }
+    // every unfinished beam gets a page of its OWN for position `pos` (the next append): a fresh one on a page boundary, a copy
+    // of the shared one otherwise
+    void prepare_append(BeamGroup& g, const int pos, const std::vector<uint8_t>& fin, hipStream_t st)
+    {
+        std::vector<int> pairs;
+        for (int k = 0; k < g.K; k++) {
+            if (fin[k]) {
+                continue;  // (a finished beam appends nothing: it keeps what it shares)
+            }
+            std::vector<int>& l = g.lists[k];
+            if (pos / P >= (int)l.size()) {
+                l.push_back(take_page());
+            }
+            else if (page_ref[l[pos / P]] > 1) {
+                const int old = l[pos / P], pg = take_page();
+                pairs.push_back(old);
+                pairs.push_back(pg);
+                drop_page(old);
+                l[pos / P] = pg;
+            }
+        }
+        if (!pairs.empty()) {
+            FTCF_HIP_CHECK(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, st));
+            const size_t page_elems = (size_t)e->nhl * P * e->dh;
+            hipLaunchKernelGGL(k_batcher_copy_pages, dim3((unsigned)pairs.size() / 2, e->L, 2), dim3(256), 0, st, kpool, vpool, d_pairs,
+                               page_elems, pool_layer_elems);
+            FTCF_HIP_CHECK(hipGetLastError());
+            FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        upload_group_tables(g, st);
+    }
+    void release_group(const int si)
+    {
+        auto it = groups.find(si);
+        if (it == groups.end()) {
+            return;
+        }
+        BeamGroup&           g = it->second;
+        std::vector<uint8_t> ones(g.K, 1), zeros(g.K, 0);
+        for (int k = 0; k < g.K; k++) {
+            for (int pg : g.lists[k]) {
+                drop_page(pg);
+            }
+            slots[si + k].active = false;
+            slots[si + k].group  = -1;
+        }
+        (void)hipMemcpy(d_fin + si, ones.data(), g.K, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_isbeam + si, zeros.data(), g.K, hipMemcpyHostToDevice);
+        groups.erase(it);
+    }
+    // gatherTree over the group's steps (decoding_kernels.cu:452-583, as GptNeoXOp.forward returns its beams: [K][n + max_new]
+    // ids padded with end_id, lengths, cum_log_probs), the result parked until it is fetched, the slots and pages freed
+    void finish_group(const int si, std::vector<Event>& ev)
+    {
+        BeamGroup&  g = groups.at(si);
+        hipStream_t st = e->stream;
+        const int   total = g.n + g.max_new;
+        launch_gather_tree_beam(d_bres + (size_t)si * (max_len + 2), d_bres_len + si, d_bout + (size_t)si * (max_len + 2),
+                                d_bpar + (size_t)si * (max_len + 2), d_bseq + si, d_bin + si, 1, g.K, g.n, total, e->cfg.end_id, st);
+        BeamResult r;
+        r.K     = g.K;
+        r.total = total;
+        r.ids.resize((size_t)g.K * total);
+        r.lens.resize(g.K);
+        r.cum.resize(g.K);
+        FTCF_HIP_CHECK(hipMemcpyAsync(r.ids.data(), d_bres + (size_t)si * (max_len + 2), r.ids.size() * 4, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(r.lens.data(), d_bres_len + si, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(r.cum.data(), d_cum + si, (size_t)g.K * 4, hipMemcpyDeviceToHost, st));
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        const long id    = g.id;
+        beam_results[id] = std::move(r);
+        release_group(si);
+        emit(ev, Event{id, -1, 1});
+    }
+    // prompt -> the engine's own beam-search request of ONE step (prefill of the K tiled rows, first beam step) -> the group's
+    // state; the prompt's K/V are scattered once (beam 0's rows) into pages all beams share
+    void admit_beam(const int si, const Request& r, std::vector<Event>& ev)
+    {
+        Range       rg("ftcf.batcher.admit_beam");
+        hipStream_t st = e->stream;
+        const int   K = r.beam_width, n = (int)r.prompt.size(), need = (n + r.max_new + P - 1) / P;
+        BeamGroup   g;
+        g.id      = r.id;
+        g.si      = si;
+        g.K       = K;
+        g.n       = n;
+        g.max_new = r.max_new;
+        g.budget  = K * need;
+        g.penalised = r.repetition_penalty != 1.f;
+        FTCF_HIP_CHECK(hipMemcpy(d_prompt, r.prompt.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        FTCF_HIP_CHECK(hipMemcpy(d_plen, &n, 4, hipMemcpyHostToDevice));
+        ftcf_forward_args a{};
+        a.input_ids = d_prompt;
+        a.input_lengths = d_plen;
+        a.batch_size = 1;
+        a.max_input_len = n;
+        a.output_len = 1;
+        a.beam_width = K;
+        a.temperature = &r.temperature;
+        a.n_temperature = 1;
+        a.repetition_penalty = &r.repetition_penalty;
+        a.n_repetition_penalty = 1;
+        a.beam_search_diversity_rate = &r.diversity;
+        a.n_beam_search_diversity_rate = 1;
+        a.len_penalty = &r.len_penalty;
+        a.n_len_penalty = 1;
+        a.output_ids = d_pout;
+        a.sequence_lengths = d_pseq;
+        e->forward(a);  // host synchronous; the engine's buffers keep the request's state: step_ids / parent_ids [n + 1][K], ...
+        // the prompt's pages, shared by every beam
+        std::vector<int> shared;
+        for (int i = 0; i < (n + P - 1) / P; i++) {
+            shared.push_back(take_page());
+        }
+        g.lists.assign(K, shared);
+        for (int pg : shared) {
+            page_ref[pg] = K;
+        }
+        groups[si] = g;
+        BeamGroup& G = groups[si];
+        upload_group_tables(G, st);
+        const size_t row_kv = (size_t)e->nhl * (n + 1) * e->dh;
+        launch_scatter_kv_to_pages(e->k_cache, e->v_cache, kpool, vpool, d_pt + (size_t)si * max_pages, e->L, e->nhl, e->dh, n + 1, n, P,
+                                   pool_layer_elems, st, (size_t)K * row_kv);
+        const size_t reg = (size_t)si * (max_len + 2);
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_bout + reg, e->step_ids, (size_t)(n + 1) * K * 4, hipMemcpyDeviceToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_bpar + reg, e->parent_ids, (size_t)(n + 1) * K * 4, hipMemcpyDeviceToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_bseq + si, e->seq_len, (size_t)K * 4, hipMemcpyDeviceToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_cum + si, e->cum, (size_t)K * 4, hipMemcpyDeviceToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_tok + si, e->step_ids + (size_t)n * K, (size_t)K * 4, hipMemcpyDeviceToDevice, st));
+        // (the engine's own `finished` is all ones by now: its one-token request ran into the length criterion)
+        std::vector<int>     lens(K, n), first(K);
+        std::vector<uint8_t> ones(K, 1), fin(K, 0);
+        FTCF_HIP_CHECK(hipMemcpy(first.data(), e->step_ids + (size_t)n * K, (size_t)K * 4, hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; k++) {
+            fin[k] = first[k] == e->cfg.end_id ? 1 : 0;
+        }
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, fin.data(), (size_t)K, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, lens.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_bin + si, lens.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_isbeam + si, ones.data(), (size_t)K, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_btemp + si, &r.temperature, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_brep + si, &r.repetition_penalty, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_bdiv + si, &r.diversity, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipMemcpyAsync(d_blen + si, &r.len_penalty, 4, hipMemcpyHostToDevice, st));
+        FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        for (int k = 0; k < K; k++) {
+            Slot& s  = slots[si + k];
+            s.active = true;
+            s.group  = si;
+            s.id     = r.id;
+            s.len    = n;
+            s.pages.clear();
+            s.hist.clear();
+            s.stop.clear();
+            s.repetition_penalty = 1.f;  // (the beam kernels apply the request's penalty themselves)
+        }
+        G.generated = 1;
+        bool all_fin = true;
+        for (int k = 0; k < K; k++) {
+            all_fin &= fin[k] != 0;
+        }
+        if (all_fin || G.generated >= G.max_new) {
+            finish_group(si, ev);
+            return;
+        }
+        prepare_append(G, n, fin, st);
+    }
+    // the beam kernels of every running group on this step's logits, BEFORE the sampling kernels (whose end-id mask rewrites the
+    // logits of rows that are finished in their view -- the groups' rows)
+    void enqueue_beam_steps(hipStream_t st)
+    {
+        for (auto& kv : groups) {
+            BeamGroup&   g   = kv.second;
+            const int    si  = g.si, step = g.n + g.generated;
+            const size_t reg = (size_t)si * (max_len + 2);
+            hipLaunchKernelGGL(k_batcher_set_step, dim3(1), dim3(1), 0, st, d_bstate + si, step);
+            BeamParams bp{};
+            bp.logits = logits + (size_t)si * e->V;
+            bp.B = 1;
+            bp.K = g.K;
+            bp.V = e->V;
+            bp.max_input_len = g.n;
+            bp.total_len = max_len + 2;
+            bp.end_id = e->cfg.end_id;
+            bp.s_max = 0;  // (no cache indirection: the page lists are reordered instead)
+            bp.input_lengths = d_bin + si;
+            bp.temperature = d_btemp + si;
+            bp.repetition_penalty = g.penalised ? d_brep + si : nullptr;  // (NULL: no history staging buffer in LDS)
+            bp.diversity_rate = d_bdiv + si;
+            bp.len_penalty = d_blen + si;
+            bp.output_ids = d_bout + reg;
+            bp.parent_ids = d_bpar + reg;
+            bp.finished = d_fin + si;
+            bp.seq_len = d_bseq + si;
+            bp.cum_log_probs = d_cum + si;
+            bp.cache_indir = d_zero;
+            bp.state = d_bstate + si;
+            bp.ws = beam_ws;
+            launch_beam_search(bp, st);
+        }
+    }
+    // ... and behind them (k_batcher_last_token writes every slot's input token): the groups' next input tokens and positions
+    void enqueue_beam_advance(hipStream_t st)
+    {
+        for (auto& kv : groups) {
+            const BeamGroup& g    = kv.second;
+            const int        step = g.n + g.generated;
+            hipLaunchKernelGGL(k_batcher_beam_advance, dim3(1), dim3(64), 0, st, d_tok + g.si, d_len + g.si,
+                               d_bout + (size_t)g.si * (max_len + 2) + (size_t)step * g.K, g.K);
+        }
+    }
+    // after the step's synchronisation: every beam takes over its parent's pages, finished groups leave
+    void advance_groups(std::vector<Event>& ev, const std::vector<uint8_t>& fin_all)
+    {
+        hipStream_t      st = e->stream;
+        std::vector<int> leaders;
+        for (auto& kv : groups) {
+            leaders.push_back(kv.first);
+        }
+        for (const int si : leaders) {
+            BeamGroup&       g = groups.at(si);
+            const int        step = g.n + g.generated;
+            std::vector<int> parent(g.K);
+            FTCF_HIP_CHECK(hipMemcpy(parent.data(), d_bpar + (size_t)si * (max_len + 2) + (size_t)step * g.K, (size_t)g.K * 4,
+                                     hipMemcpyDeviceToHost));
+            std::vector<std::vector<int>> nl(g.K);
+            for (int k = 0; k < g.K; k++) {
+                nl[k] = g.lists[parent[k] % g.K];
+                for (int pg : nl[k]) {
+                    page_ref[pg]++;
+                }
+            }
+            for (int k = 0; k < g.K; k++) {
+                for (int pg : g.lists[k]) {
+                    drop_page(pg);
+                }
+            }
+            g.lists = std::move(nl);
+            g.generated += 1;
+            std::vector<uint8_t> fin(fin_all.begin() + si, fin_all.begin() + si + g.K);
+            bool                 all_fin = true;
+            for (int k = 0; k < g.K; k++) {
+                all_fin &= fin[k] != 0;
+                slots[si + k].len += 1;
+            }
+            if (all_fin || g.generated >= g.max_new) {
+                finish_group(si, ev);
+            }
+            else {
+                prepare_append(g, g.n + g.generated - 1, fin, st);
             }
         }
     }
@@ -544,8 +958,17 @@ struct ftcf_batcher {
         sp.ws = samp_ws;
         sp.max_top_k = host_max_top_k;
         sp.any_top_p = host_any_top_p;
+        if (!groups.empty()) {  // the rows of beam groups are "finished" for the sampling kernels
+            enqueue_beam_steps(st);
+            hipLaunchKernelGGL(k_batcher_sampling_view, dim3(1), dim3(64), 0, st, d_sfin, d_fin, d_isbeam, B, 0);
+            sp.finished = d_sfin;
+        }
         DynamicDecodeLayer{}.forward(sp, st, false);  // (the stop / length criteria are the scheduler's: no finish step)
         hipLaunchKernelGGL(k_batcher_last_token, dim3(1), dim3(64), 0, st, d_tok, d_hist, d_len, B);
+        if (!groups.empty()) {
+            hipLaunchKernelGGL(k_batcher_sampling_view, dim3(1), dim3(64), 0, st, d_sfin, d_fin, d_isbeam, B, 1);
+            enqueue_beam_advance(st);
+        }
         std::vector<int>     tok(B);
         std::vector<uint8_t> fin(B);
         int                  gemm_err = 0;
@@ -566,7 +989,7 @@ struct ftcf_batcher {
         }
         for (int si = 0; si < B; si++) {
             Slot& s = slots[si];
-            if (!s.active) {
+            if (!s.active || s.group >= 0) {
                 continue;
             }
             s.len += 1;
@@ -581,6 +1004,9 @@ struct ftcf_batcher {
                 }
                 release(s);
             }
+        }
+        if (!groups.empty()) {
+            advance_groups(ev, fin);
         }
     }
 
@@ -607,12 +1033,50 @@ struct ftcf_batcher {
         // admissions: as many of the queue's head requests as there are free slots and pages, prefilled as ONE ragged batch
         std::vector<int>     sis;
         std::vector<Request> rs;
-        int                  pages_left = (int)free_pages.size();
+        int                  pages_left = (int)free_pages.size() - reserved_pages();
+        if (!waiting.empty() && waiting.front().beam_width > 1) {
+            // a beam request at the head of the queue: K consecutive free slots and the group's whole page budget, admitted alone
+            const Request& r    = waiting.front();
+            const int      K    = r.beam_width, need = K * (((int)r.prompt.size() + r.max_new + P - 1) / P);
+            int            si0  = -1;
+            for (int si = 0, run = 0; si < max_batch && si0 < 0; si++) {
+                run = slots[si].active ? 0 : run + 1;
+                if (run == K) {
+                    si0 = si - K + 1;
+                }
+            }
+            if (si0 >= 0 && pages_left >= need) {
+                Request rq = std::move(waiting.front());
+                waiting.pop_front();
+                for (int k = 0; k < K; k++) {
+                    slot_topk[si0 + k] = 1;
+                    slot_temp[si0 + k] = 1.f;
+                }
+                const size_t ev0 = ev.size();
+                try {
+                    admit_beam(si0, rq, ev);
+                }
+                catch (...) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipGetLastError();
+                    release_group(si0);
+                    beam_results.erase(rq.id);
+                    waiting.push_front(std::move(rq));
+                    ev.resize(ev0);
+                    throw;
+                }
+            }
+            refresh_host_flags();
+            return;
+        }
         for (int si = 0; si < max_batch && !waiting.empty(); si++) {
             if (slots[si].active) {
                 continue;
             }
             const Request& r    = waiting.front();
+            if (r.beam_width > 1) {
+                break;  // (admitted alone, by the next iteration)
+            }
             const int      need = ((int)r.prompt.size() + r.max_new + P - 1) / P;
             if (pages_left < need) {
                 break;  // FIFO: nobody overtakes the head of the queue
@@ -755,6 +1219,40 @@ extern "C" int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, i
                                 repetition_penalty, stop_words, stop_len);
     });
 }
+extern "C" int ftcf_batcher_submit_beam(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
+                                        float beam_search_diversity_rate, float len_penalty, float temperature,
+                                        float repetition_penalty, long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit_beam(prompt_ids, prompt_len, max_new_tokens, beam_width, beam_search_diversity_rate, len_penalty,
+                                     temperature, repetition_penalty);
+    });
+}
+extern "C" int ftcf_batcher_beam_result(ftcf_batcher_t b, long request_id, int* output_ids, int* sequence_lengths,
+                                        float* cum_log_probs, int capacity, int* beam_width, int* total_len)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && beam_width && total_len, "NULL argument");
+        auto it = b->beam_results.find(request_id);
+        if (it == b->beam_results.end()) {
+            *beam_width = 0;
+            *total_len  = 0;
+            return;
+        }
+        const ftcf_batcher::BeamResult& r = it->second;
+        *beam_width = r.K;
+        *total_len  = r.total;
+        if (!output_ids) {
+            return;  // (a size query)
+        }
+        FTCF_CHECK_ARG(capacity >= r.K * r.total && sequence_lengths && cum_log_probs, "beam result: arrays too small");
+        std::copy(r.ids.begin(), r.ids.end(), output_ids);
+        std::copy(r.lens.begin(), r.lens.end(), sequence_lengths);
+        std::copy(r.cum.begin(), r.cum.end(), cum_log_probs);
+        b->beam_results.erase(it);
+    });
+}
 extern "C" int ftcf_batcher_step(ftcf_batcher_t b, long* request_ids, int* tokens, int* finished, int capacity, int* n_events)
 {
     return guarded([&] {
@@ -822,6 +1320,12 @@ extern "C" int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found
         }
         for (int si = 0; si < b->max_batch && !hit; si++) {
             ftcf_batcher::Slot& s = b->slots[si];
+            if (s.active && s.id == request_id && s.group >= 0) {
+                FTCF_HIP_CHECK(hipSetDevice(b->e->cfg.device));
+                b->release_group(s.group);
+                hit = 1;
+                break;
+            }
             if (s.active && s.id == request_id) {
                 FTCF_HIP_CHECK(hipSetDevice(b->e->cfg.device));
                 const uint8_t one8 = 1;

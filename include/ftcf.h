@@ -237,7 +237,8 @@ int ftcf_gptneox_destroy(ftcf_gptneox_t h);
  * A batcher borrows an engine (which must outlive it and must not run a request of its own while a batcher call is in
  * progress).  K/V live in `num_pages` pages of `page_tokens` tokens shared by all sequences; up to `max_batch` sequences
  * decode together; waiting requests are admitted, in order, as soon as a slot and the pages for prompt + max_new_tokens are
- * free.  fp16 / int8 engines, parallel residual, tensor_para_size 1, beam_width 1; sampling: top_k / top_p / temperature. */
+ * free.  fp16 / int8 engines, parallel residual, any tensor_para_size (one batcher per rank, fed the same requests in the same
+ * order); sampling: top_k / top_p / temperature / repetition penalty / stop words, and beam search (ftcf_batcher_submit_beam). */
 typedef struct ftcf_batcher* ftcf_batcher_t;
 int ftcf_batcher_create(ftcf_gptneox_t engine, int max_batch, int page_tokens, int num_pages, int max_seq_len,
                         ftcf_batcher_t* out);
@@ -252,6 +253,18 @@ int ftcf_batcher_submit(ftcf_batcher_t b, const int* prompt_ids, int prompt_len,
 int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int top_k, float top_p,
                            float temperature, float repetition_penalty, unsigned long long seed, const int* stop_words,
                            int stop_len, long* request_id);
+/* A beam-search request (GptNeoXOp.forward with beam_width > 1: OnlineBeamSearchLayer semantics, the engine's own beam kernels):
+ * it occupies `beam_width` consecutive slots, its beams share the prompt's pages and every page they have in common (copy on
+ * write).  ftcf_batcher_step reports ONE event for it, when it has finished: token = -1, finished = 1; the hypotheses are
+ * then fetched ONCE with ftcf_batcher_beam_result: output_ids [beam_width][total_len] (prompt, then the beam's tokens, end_id
+ * padded: total_len = prompt_len + max_new_tokens), sequence_lengths [beam_width], cum_log_probs [beam_width] -- the arrays
+ * GptNeoXOp.forward returns.  output_ids == NULL: only *beam_width / *total_len are set (0 / 0: unknown id or still running).
+ * 2 <= beam_width <= min(64, max_batch). */
+int ftcf_batcher_submit_beam(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
+                             float beam_search_diversity_rate, float len_penalty, float temperature, float repetition_penalty,
+                             long* request_id);
+int ftcf_batcher_beam_result(ftcf_batcher_t b, long request_id, int* output_ids, int* sequence_lengths, float* cum_log_probs,
+                             int capacity, int* beam_width, int* total_len);
 /* One scheduler iteration: one decode step for the running sequences, then admissions (prefill + first token).  Returns one
  * event per token produced: request id, token, finished (end_id emitted or max_new_tokens reached).  capacity >= 2 * max_batch.
  * With sequences running, a prompt longer than FTCF_BATCHER_PREFILL_CHUNK tokens (default 512; 0 = never) is admitted alone and

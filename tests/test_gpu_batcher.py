@@ -411,3 +411,86 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
             got.setdefault(k, []).append(tok)
     for k in range(len(prompts)):
         assert got[k] == ref[k], (k, got[k], ref[k])
+
+
+def _beam_alone(gh, op, prompt, n_new, V, K, **kw):
+    """What GptNeoXOp.forward returns for this prompt by itself with beam_width K."""
+    r = gh.run_op_beam(op, np.asarray(prompt, np.int32)[None, :], [len(prompt)], n_new, V, K, **kw)
+    return r["output_ids"][0], r["sequence_lengths"][0], r["cum_log_probs"].reshape(-1)
+
+
+@pytest.mark.parametrize("page_tokens", [8, 16])
+def test_beam_requests_share_the_batcher_with_greedy_ones(gh, page_tokens):
+    """Beam search inside the batcher (K consecutive slots, pages shared copy-on-write instead of the reference's cache
+    indirection): every hypothesis, its length and its score are what the engine's own beam search returns for the prompt
+    alone, while greedy requests come and go around it and stay what they are alone; every page comes back."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(5)
+    greedy = [z["prompt"].tolist(), rng.randint(3, V, size=11).tolist(), z["prompt_b"].tolist()]
+    g_new = [10, 7, 9]
+    g_ref = [_alone(gh, op, p, n, V, end_id)[0] for p, n in zip(greedy, g_new)]
+    beams = [(z["prompt"].tolist(), 9, 3, {}), (z["prompt_b"][:6].tolist(), 12, 4, dict(beam_search_diversity_rate=[-0.4])),
+             (rng.randint(3, V, size=17).tolist(), 6, 2, dict(repetition_penalty=[1.3], temperature=[0.8]))]
+    b_ref = [_beam_alone(gh, op, p, n, V, K, **kw) for p, n, K, kw in beams]
+    cb = ContinuousBatcher(op, max_batch=6, page_tokens=page_tokens, num_pages=200 // page_tokens + 8, max_seq_len=48)
+    free0 = cb.status()["free_pages"]
+    ids, bids, got, done = {}, {}, {}, set()
+
+    def scalar(kw, key, default):
+        return float(kw[key][0]) if key in kw else default
+
+    def submit_beam(i):
+        p, n, K, kw = beams[i]
+        bids[cb.submit_beam(p, n, K, scalar(kw, "beam_search_diversity_rate", 0.0), 0.0, scalar(kw, "temperature", 1.0),
+                            scalar(kw, "repetition_penalty", 1.0))] = i
+
+    arrivals = {0: [("g", 0), ("b", 0)], 1: [("g", 1)], 3: [("b", 1)], 4: [("g", 2)], 6: [("b", 2)]}
+    it = 0
+    while arrivals or cb.busy():
+        for kind, i in arrivals.pop(it, []):
+            if kind == "g":
+                ids[cb.submit(greedy[i], g_new[i])] = i
+            else:
+                submit_beam(i)
+        for rid, tok, fin in cb.step():
+            if rid in bids:
+                assert tok == -1 and fin
+                done.add(rid)
+            else:
+                got.setdefault(ids[rid], []).append(tok)
+        it += 1
+        assert it < 2000
+    for i in range(len(greedy)):
+        assert got[i] == g_ref[i], (i, got[i], g_ref[i])
+    assert done == set(bids)
+    for rid, i in bids.items():
+        out, lens, cum = cb.beam_result(rid)
+        ref_out, ref_lens, ref_cum = b_ref[i]
+        assert out.shape == ref_out.shape, (i, out.shape, ref_out.shape)
+        assert np.array_equal(out, ref_out), (i, out, ref_out)
+        assert np.array_equal(lens, ref_lens), (i, lens, ref_lens)
+        np.testing.assert_allclose(cum, ref_cum, rtol=2e-3, atol=2e-3)
+        assert cb.beam_result(rid) is None  # fetched once
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+
+
+def test_a_cancelled_beam_request_returns_its_pages(gh):
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    op = gh.make_op(cfg, w)
+    cb = ContinuousBatcher(op, max_batch=4, page_tokens=8, num_pages=40, max_seq_len=48)
+    free0 = cb.status()["free_pages"]
+    rid = cb.submit_beam(z["prompt"].tolist(), 20, 4)
+    for _ in range(5):
+        assert all(r != rid for r, _, _ in cb.step())
+    assert cb.status()["free_pages"] < free0
+    assert cb.cancel(rid)
+    assert cb.status()["free_pages"] == free0 and cb.beam_result(rid) is None
+    # the slots serve the next request
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    ref = _alone(gh, op, z["prompt_b"].tolist(), 6, V, end_id)[0]
+    got, _ = _drain(cb, {0: [(z["prompt_b"].tolist(), 6)]})
+    assert got[0] == ref
