@@ -371,10 +371,14 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
     new = [8, 6, 11, 9, 5, 7]
     op1 = gh.make_op(cfg, w)
     ref = [_alone(gh, op1, p, n, V, end_id)[0] for p, n in zip(prompts, new)]
+    # with room for it, a beam request of width 3 rides along (its admission is the engine's own tensor-parallel beam request)
+    beam = (prompts[1], 7, 3) if max_batch >= 6 else None
+    beam_ref = _beam_alone(gh, op1, beam[0], beam[1], V, beam[2]) if beam else None
     del op1
     arrivals = {0: [0, 1], 2: [2, 3], 3: [4], 7: [5]}
     group = LocalTensorParallelGroup()
     res, err = [None] * tp, []
+    beams = [None] * tp
     gate = threading.Barrier(tp)
 
     def worker(r):
@@ -386,10 +390,15 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
             while pending or cb.busy():
                 for k in pending.pop(it, []):
                     ids[cb.submit(prompts[k], new[k])] = k
+                if beam and it == 1:
+                    brid = cb.submit_beam(beam[0], beam[1], beam[2])
+                    ids[brid] = "beam"
                 gate.wait(timeout=120)  # (the ranks step together, like the ranks of a serving job)
                 events.append([(ids[rid], tok, fin) for rid, tok, fin in cb.step()])
                 it += 1
                 assert it < 2000
+            if beam:
+                beams[r] = cb.beam_result(brid)
             assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
             res[r] = events
         except BaseException as e:  # noqa: BLE001
@@ -411,6 +420,11 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
             got.setdefault(k, []).append(tok)
     for k in range(len(prompts)):
         assert got[k] == ref[k], (k, got[k], ref[k])
+    if beam:
+        assert got["beam"] == [-1]
+        for r in range(tp):
+            assert np.array_equal(beams[r][0], beam_ref[0]) and np.array_equal(beams[r][1], beam_ref[1]), (r, beams[r], beam_ref)
+            np.testing.assert_allclose(beams[r][2], beam_ref[2], rtol=5e-3, atol=5e-3)
 
 
 def _beam_alone(gh, op, prompt, n_new, V, K, **kw):
