@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict
 // DH: any of the reference's head sizes (a multiple of 16; the d steps of Q K^T are padded with zeros to a multiple of 32).
 // KT: keys per tile, 64, or 32 for the sizes above 128 (LDS: K tile + transposed V tile + P tiles <= 64 KB of static LDS).
 template<int DH, int KT = 64>
-__global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __restrict__ qkv,
+__global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_mfma(const f16* __restrict__ qkv,
                                                                 const int* __restrict__ input_lengths,
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
     __shared__ __attribute__((aligned(16))) f16 sVt[DH * LDV];
     __shared__ __attribute__((aligned(16))) f16 sP[4][16 * LDP];
 
-    const int b = blockIdx.z, h = blockIdx.y, q0 = s_lo + blockIdx.x * 64;  // (s_lo: first query row of a chunked prompt phase)
+    // (s_lo: first query row of a chunked prompt phase; the LAST query block -- the most key tiles -- is dispatched first: the
+    // launch's tail is made of the short ones)
+    const int b = blockIdx.z, h = blockIdx.y, q0 = s_lo + (int)(gridDim.x - 1 - blockIdx.x) * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int hl  = nh * DH;
@@ -435,29 +437,65 @@ __global__ __launch_bounds__(256) void k_context_attention_mfma(const f16* __res
     const int q_last   = min(min(q0 + 63, len - 1), s_hi - 1);  // last query row of the block whose K/V is in the cache
     const int w_last   = q0 + wid * 16 + 15;  // last query row of this wave
     f16*      sPw      = sP[wid];
-    for (int k0 = 0; k0 <= q_last; k0 += KT) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KT * DH / 8; i += 256) {  // K tile, row major
-            const int r = i / (DH / 8), ch = i % (DH / 8);
-            int       kk = k0 + r;
-            // (keys above the block's last query row are masked for every row of the block: they re-read that row instead of
-            // cache lines a chunked prompt phase has not written yet -- a masked P = 0 times a stale NaN / Inf is NaN)
-            kk           = kk < q_last ? kk : q_last;
-            *reinterpret_cast<u32x4*>(&sK[r * LDK + ch * 8]) = *reinterpret_cast<const u32x4*>(kc + (size_t)kk * DH + ch * 8);
-        }
-        for (int i = threadIdx.x; i < (KT / 2) * (DH / 8); i += 256) {  // V tile, transposed: a thread moves 2 keys x 8 dims
-            const int rp = i % (KT / 2), ch = i / (KT / 2);            // (lanes of a wave spread over the banks)
-            int       k1 = k0 + 2 * rp, k2 = k0 + 2 * rp + 1;
-            k1           = k1 < q_last ? k1 : q_last;
-            k2           = k2 < q_last ? k2 : q_last;
-            const f16x8 v1 = *reinterpret_cast<const f16x8*>(vc + (size_t)k1 * DH + ch * 8);
-            const f16x8 v2 = *reinterpret_cast<const f16x8*>(vc + (size_t)k2 * DH + ch * 8);
+    // The K / V rows of a tile travel global memory -> registers -> LDS, and the NEXT tile's rows are requested before this
+    // tile's arithmetic starts (round 4: the single-buffered form exposed a memory round trip per tile -- 16 of them for the last
+    // query block of a 1024-token prompt; 84.8 -> 68.9 us per 13B layer at 1024 tokens).  K tile: row major; V tile: transposed, a thread
+    // moves 2 keys x 8 dims (lanes of a wave spread over the banks).
+    constexpr int NKC = (KT * DH / 8 + 255) / 256, NVC = ((KT / 2) * (DH / 8) + 255) / 256;
+    u32x4         rk[NKC];
+    f16x8         rv[NVC][2];
+    auto fetch = [&](const int k0) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                *reinterpret_cast<f16x2*>(&sVt[(ch * 8 + e) * LDV + 2 * rp]) = f16x2{v1[e], v2[e]};
+        for (int u = 0; u < NKC; u++) {
+            const int i = threadIdx.x + u * 256;
+            if (NKC * 256 == KT * DH / 8 || i < KT * DH / 8) {
+                const int r = i / (DH / 8), ch = i % (DH / 8);
+                int       kk = k0 + r;
+                // (keys above the block's last query row are masked for every row of the block: they re-read that row instead of
+                // cache lines a chunked prompt phase has not written yet -- a masked P = 0 times a stale NaN / Inf is NaN)
+                kk    = kk < q_last ? kk : q_last;
+                rk[u] = *reinterpret_cast<const u32x4*>(kc + (size_t)kk * DH + ch * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVC; u++) {
+            const int i = threadIdx.x + u * 256;
+            if (NVC * 256 == (KT / 2) * (DH / 8) || i < (KT / 2) * (DH / 8)) {
+                const int rp = i % (KT / 2), ch = i / (KT / 2);
+                int       k1 = k0 + 2 * rp, k2 = k0 + 2 * rp + 1;
+                k1           = k1 < q_last ? k1 : q_last;
+                k2           = k2 < q_last ? k2 : q_last;
+                rv[u][0]     = *reinterpret_cast<const f16x8*>(vc + (size_t)k1 * DH + ch * 8);
+                rv[u][1]     = *reinterpret_cast<const f16x8*>(vc + (size_t)k2 * DH + ch * 8);
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 <= q_last; k0 += KT) {
+        __syncthreads();  // every wave is through with the previous tile
+#pragma unroll
+        for (int u = 0; u < NKC; u++) {
+            const int i = threadIdx.x + u * 256;
+            if (NKC * 256 == KT * DH / 8 || i < KT * DH / 8) {
+                const int r = i / (DH / 8), ch = i % (DH / 8);
+                *reinterpret_cast<u32x4*>(&sK[r * LDK + ch * 8]) = rk[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVC; u++) {
+            const int i = threadIdx.x + u * 256;
+            if (NVC * 256 == (KT / 2) * (DH / 8) || i < (KT / 2) * (DH / 8)) {
+                const int rp = i % (KT / 2), ch = i / (KT / 2);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    *reinterpret_cast<f16x2*>(&sVt[(ch * 8 + e) * LDV + 2 * rp]) = f16x2{rv[u][0][e], rv[u][1][e]};
+                }
             }
         }
         __syncthreads();
+        if (k0 + KT <= q_last) {
+            fetch(k0 + KT);  // in flight under this tile's arithmetic
+        }
         if (k0 > w_last) {
             continue;  // above this wave's diagonal (the barriers above are still taken by every wave)
         }
