@@ -1398,7 +1398,7 @@ size_t lm_head_greedy_partial_bytes(int B)
 
 bool lm_head_greedy_ok(const SamplingParams& p, int K)
 {
-    static const int on = getenv("FTCF_LM_GREEDY") ? atoi(getenv("FTCF_LM_GREEDY")) : 1;
+    const int on = getenv("FTCF_LM_GREEDY") ? atoi(getenv("FTCF_LM_GREEDY")) : 1;  // (read per call: the tests switch the forms)
     return on && p.B <= 4 && K % 8 == 0 && dynamic_decode_is_fused(p, true) && p.next_x
            && lm_head_greedy_partial_bytes(p.B) <= sampling_workspace_bytes(p.B, p.V);
 }
@@ -1446,7 +1446,7 @@ size_t sampling_workspace_bytes(int B, int V)
 
 bool dynamic_decode_is_fused(const SamplingParams& p, bool finish)
 {
-    static const int greedy_on = getenv("FTCF_GREEDY_FUSED") ? atoi(getenv("FTCF_GREEDY_FUSED")) : 1;
+    const int greedy_on = getenv("FTCF_GREEDY_FUSED") ? atoi(getenv("FTCF_GREEDY_FUSED")) : 1;  // (read per call: the tests switch the forms)
     return greedy_on && finish && p.max_top_k == 1 && !p.any_top_p && !p.apply_temperature && !p.apply_repetition && !p.optional_last_tokens
            && !p.row_len && p.V <= GREEDY_SLICES * 256 * GREEDY_MAXE && p.B <= 1024 && p.rot / 2 <= 256
            && (size_t)p.B * GREEDY_SLICES * 16 <= sampling_workspace_bytes(p.B, p.V);

@@ -612,3 +612,89 @@ def test_multi_token_graphs_equal_single_token_graphs(gh, tiny, monkeypatch, dec
     torch.cuda.synchronize()
     assert out_ids[:, 0].cpu().numpy().tolist() == res[1][0] and seq[:, 0].cpu().numpy().tolist() == res[1][1]
     assert total_done == res[1][3]
+
+
+def _forward_capi(op, ids_np, S, out, V, min_length=None, stop_words=None):
+    """A request through the C ABI's argument block (min_length is not reachable through GptNeoXOp.forward)."""
+    import ctypes as C
+    import torch
+    from fastertransformer4codefuse_amd import capi
+    B = ids_np.shape[0]
+    ids = torch.from_numpy(np.ascontiguousarray(ids_np, dtype=np.int32)).cuda()
+    lens = torch.full((B,), S, dtype=torch.int32, device="cuda")
+    out_ids = torch.zeros((B, 1, S + out), dtype=torch.int32, device="cuda")
+    seq = torch.zeros((B, 1), dtype=torch.int32, device="cuda")
+    cum = torch.zeros((B, 1), dtype=torch.float32, device="cuda")
+    top_k = np.array([1], np.int32)
+    fa = capi.ForwardArgs()
+    fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+    fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = B, S, out, 1
+    fa.top_k, fa.n_top_k = top_k.ctypes.data, 1
+    if min_length is not None:
+        ml = np.ascontiguousarray(min_length, dtype=np.int32)
+        fa.min_length, fa.n_min_length = ml.ctypes.data, ml.size
+    if stop_words is not None:
+        sw = torch.from_numpy(np.ascontiguousarray(stop_words, dtype=np.int32)).cuda()
+        fa.stop_words_list, fa.stop_words_len = sw.data_ptr(), stop_words.shape[2]
+    fa.return_cum_log_probs = 1
+    fa.output_ids, fa.sequence_lengths, fa.cum_log_probs = out_ids.data_ptr(), seq.data_ptr(), cum.data_ptr()
+    capi.check(capi.lib().ftcf_gptneox_forward(op._h, C.byref(fa)))
+    torch.cuda.synchronize()
+    return out_ids[:, 0].cpu().numpy(), seq[:, 0].cpu().numpy(), cum[:, 0].cpu().numpy(), op.stats()["decode_steps"]
+
+
+GREEDY_FORMS = {"lm-head launch": ("1", "1"), "one launch": ("0", "1"), "four launches": ("0", "0")}
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+def test_the_three_forms_of_an_all_greedy_step_agree_and_follow_the_oracle(gh, tiny, monkeypatch, B):
+    """An all-greedy step runs (a) inside the LM head launch (k_lm_head_greedy: <= 4 rows on one GPU), (b) as one launch behind
+    k_lm_head (k_greedy_decode), (c) as the general four launches.  Same tokens, lengths and loop count from all three, scores to
+    1e-4 -- on a request whose rows end on end_id at different steps, with min_length holding the end token back (the mask of
+    sampling_penalty_kernels.cu:485-520, which the bench's request uses and GptNeoXOp.forward cannot reach) and with stop
+    words -- and all of it what the oracle generates."""
+    from oracle import oracle as orc
+    cfg, w, layers, glob, z = tiny
+    V, S, out = cfg["vocab_size"], 16, 14
+    # rows whose free-running greedy tokens the engine and the oracle agree on (the tiny model's logits are flat: a near tie may
+    # fall either way in fp16, and everything behind a flipped token differs): the golden prompt first, then candidates
+    rng = np.random.RandomState(12)
+    pool = [z["prompt"], z["prompt"][::-1], np.roll(z["prompt"], 5), np.roll(z["prompt"][::-1], 3)]
+    pool += [rng.randint(3, V, size=S) for _ in range(8)]
+    pool = np.stack([np.asarray(r, np.int32)[:S] for r in pool])
+    n = len(pool)
+    eng_free = gh.run_op(gh.make_op(cfg, w), pool, [S] * n, out, V, top_k=1, return_logits=False)["output_ids"]
+    orc_free = orc.Model(dict(cfg, fp16=1), layers, glob).generate(pool, [S] * n, out, orc.Sampling(n, top_k=1))["output_ids"]
+    keep = [i for i in range(n) if np.array_equal(eng_free[i], orc_free[i])]
+    assert keep and keep[0] == 0 and len(keep) >= B, keep
+    ids_np = pool[keep[:B]]
+    free = eng_free[keep[:B]]
+    cfg2 = dict(cfg, end_id=int(free[0, S + 3]))  # row 0 emits it as its 4th new token
+    model = orc.Model(dict(cfg2, fp16=1), layers, glob)
+    stop = np.full((B, 2, 4), -1, np.int32)
+    stop[:, 0, :] = 0
+    for b in range(B):  # every row stops on ITS 6th and 7th free-running tokens
+        stop[b, 0, :2] = free[b, S + 5:S + 7]
+        stop[b, 1, 0] = 2
+    cases = {"end_id": {}, "min_length": dict(min_length=[9] * B), "stop_words": dict(stop_words=stop, min_length=[20] * B)}
+    for name, kw in cases.items():
+        ref = model.generate(ids_np, [S] * B, out, orc.Sampling(B, top_k=1, **kw))
+        got = {}
+        for form, (lm, fused) in GREEDY_FORMS.items():
+            monkeypatch.setenv("FTCF_LM_GREEDY", lm)
+            monkeypatch.setenv("FTCF_GREEDY_FUSED", fused)
+            got[form] = _forward_capi(gh.make_op(cfg2, w), ids_np, S, out, V, **kw)
+        base = got["four launches"]
+        for form, g in got.items():
+            assert np.array_equal(g[0], base[0]) and np.array_equal(g[1], base[1]) and g[3] == base[3], (name, form, g, base)
+            np.testing.assert_allclose(g[2], base[2], rtol=1e-4, atol=1e-4, err_msg=f"{name} {form}")
+        assert np.array_equal(base[0], ref["output_ids"]), (name, base[0], ref["output_ids"])
+        assert np.array_equal(base[1], ref["sequence_lengths"]), (name, base[1], ref["sequence_lengths"])
+        # (scores end to end: sums of up to 14 log-probabilities of fp16 logits computed in two summation orders)
+        np.testing.assert_allclose(base[2], ref["cum_log_probs"], rtol=2e-2, atol=5e-2, err_msg=name)
+        assert base[3] == ref["steps"], (name, base[3], ref["steps"])
+        if name == "min_length":
+            assert (base[1] - S >= 9).all()  # nobody ended before its ninth new token ...
+            assert not np.array_equal(base[0], got_end[0])  # ... where the unmasked request did
+        if name == "end_id":
+            got_end = base
