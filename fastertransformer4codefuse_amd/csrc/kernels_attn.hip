@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
     f16*      sPw      = sP[wid];
     // The K / V rows of a tile travel global memory -> registers -> LDS, and the NEXT tile's rows are requested before this
     // tile's arithmetic starts (round 4: the single-buffered form exposed a memory round trip per tile -- 16 of them for the last
-    // query block of a 1024-token prompt; 84.8 -> 68.9 us per 13B layer at 1024 tokens).  K tile: row major; V tile: transposed, a thread
+    // query block of a 1024-token prompt; 84.8 -> 68.9 us per 13B layer at 1024 tokens; 57.8 with the rows' reductions on DPP).  K tile: row major; V tile: transposed, a thread
     // moves 2 keys x 8 dims (lanes of a wave spread over the banks).
     constexpr int NKC = (KT * DH / 8 + 255) / 256, NVC = ((KT / 2) * (DH / 8) + 255) / 256;
     u32x4         rk[NKC];
@@ -523,10 +523,12 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
                 sv[kg]           = valid ? qk_scale * sc[kg][j] : -INFINITY;
                 mt               = fmaxf(mt, sv[kg]);
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                mt = fmaxf(mt, __shfl_xor(mt, off, 64));
-            }
+            // (a row's 16 lanes are one DPP row: no LDS crossbar round trips -- __shfl_xor is a ds_bpermute, eight of them per
+            // row and tile in a dependent chain)
+            mt = fmaxf(mt, dpp_read<0xB1>(mt));
+            mt = fmaxf(mt, dpp_read<0x4E>(mt));
+            mt = fmaxf(mt, dpp_read<0x141>(mt));
+            mt = fmaxf(mt, dpp_read<0x140>(mt));
             const float mn = fmaxf(m_run[j], mt);
             const float al = (m_run[j] == -INFINITY) ? 0.f : __expf(m_run[j] - mn);
             float       ls = 0.f;
@@ -536,10 +538,7 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
                 ls += e;
                 sPw[(g * 4 + j) * LDP + kg * 16 + c] = (f16)e;
             }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                ls += __shfl_xor(ls, off, 64);
-            }
+            ls = group_sum_dpp<16>(ls);
             l_run[j] = l_run[j] * al + ls;
             m_run[j] = mn;
 #pragma unroll
