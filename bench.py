@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-e2e", action="store_true")
     p.add_argument("--profile-steps", type=int, default=48)
+    p.add_argument("--no-pmc", action="store_true",
+                   help="do not measure the layer kernel's HBM traffic with a `rocprofv3 --pmc` pass of a child process (N = 1)")
     p.add_argument("--fake-tp", type=int, default=0,
                    help="timing aid: run rank 0's shard of a TP=N model in ONE process over a 1-rank communicator "
                         "(no peers: outputs are meaningless, the JSON line is marked invalid)")
@@ -158,6 +160,53 @@ def cpu_baseline(a, budget_s=25.0, max_steps=8):
             "sample": f"{reps} whole decode steps (all {Lc} layers of the {'int8' if int8 else 'fp16'} model + final LN + "
                       f"{V}x{H} LM head + arg-max) at KV length {t + 1}..{t + reps}, bs=1, after one warm-up step; "
                       f"oracle/ftcf_oracle.c", "s_per_step": dt}
+
+
+def live_traffic(a):
+    """HBM bytes of one k_decode_persistent launch from the PMC counters, measured by THIS invocation: a child process runs the very
+    same request (all 512 tokens: the launches' mean KV length is the request's) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace`
+    -- its own pass, no other trace domain, as MI355X_MICROARCH.md's HBM section prescribes -- and the per-dispatch counter is
+    averaged over the launches that ran the layers (the two table-building launches over no layers are short).  FETCH_SIZE counts
+    KiB and is half the bytes on gfx950 (the guide's correction): bytes = value * 1024 * 2.  Returns (bytes, launches, avg us) or
+    None (no rocprofv3, a nested profiler, a failed pass)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ftcf_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+           "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-e2e", "--no-cpu-baseline", "--profile-steps", "0", "--no-pmc",
+           "--dtype", a.dtype, "--prompt-len", str(a.prompt_len), "--output-len", str(a.output_len), "--batch", str(a.batch),
+           "--layers", str(a.layers), "--heads", str(a.heads), "--head-dim", str(a.head_dim), "--inter", str(a.inter),
+           "--vocab", str(a.vocab), "--rotary", str(a.rotary)]
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        dbs = glob.glob(os.path.join(tmp, "**", "*results.db"), recursive=True)
+        c = sqlite3.connect(dbs[0])
+        tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+        T = lambda pre: [t for t in tabs if t.startswith(pre)][0]  # noqa: E731
+        disp, sym, pmc, info = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
+        scols = [r[1] for r in c.execute(f"pragma table_info({sym})")]
+        name_col = "kernel_name" if "kernel_name" in scols else "display_name"
+        q = (f"select count(*), avg(e.value), avg(d.end - d.start) from {pmc} e join {disp} d on e.event_id = d.event_id "
+             f"join {sym} s on d.kernel_id = s.id join {info} i on e.pmc_id = i.id "
+             f"where i.name = 'FETCH_SIZE' and s.{name_col} like '%k_decode_persistent%' and (d.end - d.start) > 200000")
+        n, kb, dur = c.execute(q).fetchone()
+        c.close()
+        if not n or not kb:
+            return None
+        return float(kb) * 1024.0 * 2.0, int(n), float(dur) / 1e3
+    except Exception:  # noqa: BLE001  (the bench line falls back to the committed pass and says so)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -327,6 +376,9 @@ def main():
             # HBM traffic of that kernel from the PMC pass recorded under profiles/ (collected in its own rocprofv3 run, as
             # the counters cannot ride along with this timing run); only quoted when it was measured on this very config
             traffic = traffic_source = None
+            live = None
+            if (world == 1 and a.fake_tp <= 1 and not a.no_pmc and ps["gemv_kind"] == 4 and a.batch == 1):
+                live = live_traffic(a)
             try:
                 import glob
                 pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1]))
@@ -337,8 +389,13 @@ def main():
                     traffic_source = ("profiles/" + os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1])
                                       + ": FETCH_SIZE x 2 (gfx950 correction) from a separate `rocprofv3 --pmc` pass over this very "
                                         "command, NOT measured in this run")
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
+            if live is not None:
+                traffic = live[0]
+                traffic_source = (f"measured by this invocation: a child process ran the same request under `rocprofv3 --pmc FETCH_SIZE "
+                                  f"--kernel-trace` (its own pass); FETCH_SIZE x 1024 x 2 (gfx950 correction) averaged over {live[1]} "
+                                  f"launches of the kernel ({live[2]:.1f} us each under the counters)")
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": traffic, "traffic_source": traffic_source, "kernel": KIND_NAMES.get(ps["gemv_kind"], "?"), "bytes_per_launch": per_launch_bytes, "avg_launch_us": avg_ms * 1e3,
                     "launches": ps["gemv_launches"],
