@@ -508,3 +508,47 @@ def test_a_cancelled_beam_request_returns_its_pages(gh):
     ref = _alone(gh, op, z["prompt_b"].tolist(), 6, V, end_id)[0]
     got, _ = _drain(cb, {0: [(z["prompt_b"].tolist(), 6)]})
     assert got[0] == ref
+
+
+@pytest.mark.parametrize("int8_mode", [0, 1])
+def test_beams_that_finish_on_end_id_inside_the_batcher(gh, int8_mode):
+    """Beams end on end_id at different steps (a finished beam appends nothing, keeps the pages it shares and offers only its end
+    token), the group leaves when all of them have or at max_new_tokens -- on the 512-hidden model, fp16 and int8, next to sampling
+    neighbours: the hypotheses are the engine's own."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg = dict(MID)
+    w = random_model(cfg, seed=21)
+    V = cfg["vocab_size"]
+    rng = np.random.RandomState(9)
+    prompts = [rng.randint(3, V, size=n).tolist() for n in (19, 7, 33)]
+    K, n_new = 4, 16
+    free = _beam_alone(gh, gh.make_op(cfg, w, int8_mode=int8_mode), prompts[0], n_new, V, K)
+    # a token the best hypothesis emits mid-way becomes the end token: beams finish during the search
+    cfg2 = dict(cfg, end_id=int(free[0][0, len(prompts[0]) + 5]))
+    op = gh.make_op(cfg2, w, int8_mode=int8_mode)
+    refs = [_beam_alone(gh, op, p, n_new, V, K) for p in prompts]
+    assert any((r[1] < len(p) + n_new).any() for r, p in zip(refs, prompts))  # the case really finishes beams early
+    cb = ContinuousBatcher(op, max_batch=10, page_tokens=8, num_pages=120, max_seq_len=64)
+    free0 = cb.status()["free_pages"]
+    bids = {}
+    arrivals = {0: [0], 2: [1], 3: [2]}
+    it, done = 0, set()
+    noise = 0
+    while arrivals or cb.busy():
+        for i in arrivals.pop(it, []):
+            bids[cb.submit_beam(prompts[i], n_new, K)] = i
+        if it in (1, 4):  # sampled neighbours in the slots around the groups
+            cb.submit(rng.randint(3, V, size=11).tolist(), 9, top_k=4, top_p=0.9, temperature=0.7, seed=it)
+            noise += 1
+        for rid, tok, fin in cb.step():
+            if rid in bids and fin:
+                done.add(rid)
+        it += 1
+        assert it < 2000
+    assert done == set(bids)
+    for rid, i in bids.items():
+        out, lens, cum = cb.beam_result(rid)
+        assert np.array_equal(out, refs[i][0]), (i, out, refs[i][0])
+        assert np.array_equal(lens, refs[i][1]), (i, lens, refs[i][1])
+        np.testing.assert_allclose(cum, refs[i][2], rtol=5e-3, atol=5e-3)
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
