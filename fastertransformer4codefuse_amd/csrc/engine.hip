@@ -423,7 +423,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         in_len = tiled_len;
     }
     launch_decode_init(finished, seq_len, cum, pad_count, masked, draws, in_len, state, B, S, s_max, stream, K);
-    if (B <= 4 && !fp32) {  // the tagged partials of k_lm_head_greedy: a tag is the step, and steps repeat from request to request
+    if (B <= 2 && !fp32) {  // the tagged partials of k_lm_head_greedy: a tag is the step, and steps repeat from request to request
         FTCF_HIP_CHECK(hipMemsetAsync(samp_ws, 0, lm_head_greedy_partial_bytes(B), stream));
     }
     if (S > 1 && K > 1 && fp32) {
@@ -584,7 +584,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
                 lm_head_dispatch(nrm, Wrows, out, B, rows, H, ld, stream);
             }
         };
-        // one GPU, <= 4 rows, an all-greedy step: the LM head launch picks the tokens, closes the step and prepares the next
+        // one GPU, <= 2 rows, an all-greedy step: the LM head launch picks the tokens, closes the step and prepares the next
         // token's input itself (k_lm_head_greedy) -- nothing is launched behind it
         const bool lm_greedy = !lm_done && tp == 1 && fuse_ln && ses.K == 1 && lm_head_greedy_ok(ses.sp, H);
         if (lm_done) {

@@ -388,7 +388,7 @@ void   launch_gather_tree_beam(int* output_ids, int* sequence_lengths, const int
 size_t sampling_workspace_bytes(int B, int V);
 void   launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish = true);
 // LM head (final LayerNorm fused, as launch_lm_head with gamma) + the all-greedy dynamic decode of the token + the next token's
-// prologue in ONE launch (k_lm_head_greedy): one GPU, <= 4 rows, a step launch_dynamic_decode would run as k_greedy_decode.
+// prologue in ONE launch (k_lm_head_greedy): one GPU, <= 2 rows, a step launch_dynamic_decode would run as k_greedy_decode.
 // The workgroups' partials are tagged with the step: the first lm_head_greedy_partial_bytes(B) bytes of the sampling workspace
 // must be zero at the start of a request.
 bool   lm_head_greedy_ok(const SamplingParams& p, int K);

@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_greedy_decode(const SamplingParams p, f
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LM head + the all-greedy dynamic decode of the token in ONE launch (one GPU, <= 4 rows: the headline's token).  The wave
+// LM head + the all-greedy dynamic decode of the token in ONE launch (one GPU, one or two rows: the headline's token).  The wave
 // that produces a logit keeps the arg max and the soft-max statistics of its vocabulary rows as it goes (wave-uniform
 // registers: the logits never come back from memory), the workgroup publishes ONE partial per row as granules {step tag,
 // value}, and the workgroup dispatched LAST runs greedy_finish on them, re-reading until every tag is this token's.  Against
@@ -1399,7 +1399,9 @@ size_t lm_head_greedy_partial_bytes(int B)
 bool lm_head_greedy_ok(const SamplingParams& p, int K)
 {
     const int on = getenv("FTCF_LM_GREEDY") ? atoi(getenv("FTCF_LM_GREEDY")) : 1;  // (read per call: the tests switch the forms)
-    return on && p.B <= 4 && K % 8 == 0 && dynamic_decode_is_fused(p, true) && p.next_x
+    // (one or two rows -- the persistent kernel's batch sizes: the kernel is held to 64 VGPRs for eight waves per SIMD, and the
+    // LM head's own loop needs 68 / 76 at three / four rows)
+    return on && p.B <= 2 && K % 8 == 0 && dynamic_decode_is_fused(p, true) && p.next_x
            && lm_head_greedy_partial_bytes(p.B) <= sampling_workspace_bytes(p.B, p.V);
 }
 
@@ -1415,11 +1417,11 @@ void launch_lm_head_greedy(const f16* x, const f16* W, float* logits, int K, con
     unsigned long long* part = reinterpret_cast<unsigned long long*>(p.ws);
 #define FTCF_LMG(MM)                                                                                                   \
     hipLaunchKernelGGL((k_lm_head_greedy<MM>), dim3(grid), dim3(256), smem, s, x, W, logits, K, gamma, beta, eps, p, part)
-    switch (p.B) {
-        case 1: FTCF_LMG(1); break;
-        case 2: FTCF_LMG(2); break;
-        case 3: FTCF_LMG(3); break;
-        default: FTCF_LMG(4); break;
+    if (p.B == 1) {
+        FTCF_LMG(1);
+    }
+    else {
+        FTCF_LMG(2);
     }
 #undef FTCF_LMG
     FTCF_HIP_CHECK(hipGetLastError());

@@ -648,7 +648,7 @@ GREEDY_FORMS = {"lm-head launch": ("1", "1"), "one launch": ("0", "1"), "four la
 
 @pytest.mark.parametrize("B", [1, 2, 3, 4])
 def test_the_three_forms_of_an_all_greedy_step_agree_and_follow_the_oracle(gh, tiny, monkeypatch, B):
-    """An all-greedy step runs (a) inside the LM head launch (k_lm_head_greedy: <= 4 rows on one GPU), (b) as one launch behind
+    """An all-greedy step runs (a) inside the LM head launch (k_lm_head_greedy: <= 2 rows on one GPU; three and four rows take form (b)), (b) as one launch behind
     k_lm_head (k_greedy_decode), (c) as the general four launches.  Same tokens, lengths and loop count from all three, scores to
     1e-4 -- on a request whose rows end on end_id at different steps, with min_length holding the end token back (the mask of
     sampling_penalty_kernels.cu:485-520, which the bench's request uses and GptNeoXOp.forward cannot reach) and with stop
