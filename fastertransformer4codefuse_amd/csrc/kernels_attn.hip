@@ -17,6 +17,9 @@
 // consecutive keys.  Roofline: HBM (decode: 4*t*dh*nh bytes per layer per row).
 #include "attn_device.hip.h"
 
+#include <map>
+#include <mutex>
+
 namespace ftcf {
 
 template<int DH, bool BEAMS>
@@ -367,6 +370,15 @@ __global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict
     }
 }
 
+// a * x + b * y with both products rounded on their own (no fused multiply-add): the same value whichever operand pair comes first
+__device__ __forceinline__ float sym_mad2(const float a, const float x, const float b, const float y)
+{
+#pragma clang fp contract(off)
+    const float p = a * x;
+    const float q = b * y;
+    return p + q;
+}
+
 // MFMA form of the causal prefill attention: one workgroup = 64 query rows of one (row, head), a wave = 16 of them.
 // Per 64-key tile: S = Q K^T on mfma_f32_16x16x32_f16 (K rows are d-contiguous = the B-operand order), online softmax in
 // the accumulator layout (a row lives in 16 lanes x 4 key groups), P rounded to half (the reference's softmax output
@@ -380,7 +392,8 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
                                                                 const f16* __restrict__ k_cache,
                                                                 const f16* __restrict__ v_cache, int S, int nh, int s_max,
                                                                 f16* __restrict__ ctx, float qk_scale, int crm, int s_lo,
-                                                                int s_hi)
+                                                                int s_hi, int nsplit2 = 0, float* __restrict__ split_ws = nullptr,
+                                                                unsigned* __restrict__ split_tk = nullptr)
 {
     static_assert(DH % 16 == 0 && (KT == 32 || KT == 64), "head size: a multiple of 16");
     constexpr int ND  = (DH + 31) / 32;  // d steps of Q K^T
@@ -396,7 +409,14 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
 
     // (s_lo: first query row of a chunked prompt phase; the LAST query block -- the most key tiles -- is dispatched first: the
     // launch's tail is made of the short ones)
-    const int b = blockIdx.z, h = blockIdx.y, q0 = s_lo + (int)(gridDim.x - 1 - blockIdx.x) * 64;
+    // nsplit2 > 0: the launch's time is the CHAIN of key tiles of its last query block (16 dependent tiles at 1024 tokens, each
+    // ~3.6 us with three workgroups per CU) while the chip as a whole has room: the nsplit2 heaviest query blocks are cut in two along
+    // their keys -- two workgroups, half the chain each -- and the one that finishes second merges the two partial soft-maxes
+    // (deterministic: the merge is symmetric in its operands)
+    const int nqb  = (int)gridDim.x - nsplit2;  // query blocks of the launch
+    const int qbi  = (int)blockIdx.x < 2 * nsplit2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x - nsplit2;  // 0 = the last block
+    const int half = (int)blockIdx.x < 2 * nsplit2 ? (int)(blockIdx.x & 1) : -1;                      // -1: not split
+    const int b = blockIdx.z, h = blockIdx.y, q0 = s_lo + (nqb - 1 - qbi) * 64;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int hl  = nh * DH;
@@ -470,8 +490,14 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
             }
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 <= q_last; k0 += KT) {
+    int k_begin = 0, k_end = q_last + 1;  // keys [k_begin, k_end) in whole tiles
+    if (half >= 0) {
+        const int tiles = q_last / KT + 1, cut = (tiles / 2) * KT;
+        k_begin = half ? cut : 0;
+        k_end   = half ? q_last + 1 : cut;
+    }
+    fetch(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
         __syncthreads();  // every wave is through with the previous tile
 #pragma unroll
         for (int u = 0; u < NKC; u++) {
@@ -493,7 +519,7 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
             }
         }
         __syncthreads();
-        if (k0 + KT <= q_last) {
+        if (k0 + KT < k_end) {
             fetch(k0 + KT);  // in flight under this tile's arithmetic
         }
         if (k0 > w_last) {
@@ -558,6 +584,54 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
             }
         }
     }
+    if (half >= 0) {
+        // this half's partial {o (relative to m), m, l} -> workspace in the accumulator layout (write-through: the other workgroup
+        // may sit on another XCD), then a ticket; the second arrival adds the first one's partial to its registers
+        __shared__ int s_second;
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        constexpr size_t PW   = (size_t)64 * DH + 128;  // floats per partial
+        const size_t     item = ((size_t)b * gridDim.y + h) * nsplit2 + qbi;
+        gu32*            mine = (gu32*)(split_ws + (item * 2 + half) * PW);
+        const gu32*      othr = (const gu32*)(split_ws + (item * 2 + (1 - half)) * PW);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = wid * 16 + g * 4 + j;
+#pragma unroll
+            for (int n = 0; n < NO; n++) {
+                __hip_atomic_store(mine + (size_t)row * DH + n * 16 + c, __float_as_uint(o[n][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (c == 0) {
+                __hip_atomic_store(mine + (size_t)64 * DH + row * 2, __float_as_uint(m_run[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + (size_t)64 * DH + row * 2 + 1, __float_as_uint(l_run[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_second = __hip_atomic_fetch_add(split_tk + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_second) {
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int   row = wid * 16 + g * 4 + j;
+            const float m2  = __uint_as_float(__hip_atomic_load(othr + (size_t)64 * DH + row * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float l2  = __uint_as_float(__hip_atomic_load(othr + (size_t)64 * DH + row * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float mn  = fmaxf(m_run[j], m2);
+            const float a1  = (m_run[j] == -INFINITY) ? 0.f : __expf(m_run[j] - mn);
+            const float a2  = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+            // (products rounded on their own: a fused multiply-add would make the sum depend on which half merges)
+            l_run[j]        = sym_mad2(l_run[j], a1, l2, a2);
+            m_run[j]        = mn;
+#pragma unroll
+            for (int n = 0; n < NO; n++) {
+                const float o2 = __uint_as_float(__hip_atomic_load(othr + (size_t)row * DH + n * 16 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                o[n][j]        = sym_mad2(o[n][j], a1, o2, a2);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int qi = q0 + wid * 16 + g * 4 + j;
@@ -569,6 +643,23 @@ __global__ __launch_bounds__(256, (DH > 192 ? 2 : 3)) void k_context_attention_m
             }
         }
     }
+}
+
+// workspace of the key-split prompt attention: one per (device, stream), kept for the life of the process (as the split-K GEMM's)
+constexpr size_t CTX_SPLIT_WS = (size_t)96 << 20;
+constexpr size_t CTX_SPLIT_TK = 64 * 1024;  // tickets (unsigned)
+static float* ctx_split_workspace(hipStream_t s)
+{
+    static std::mutex                                    mu;
+    static std::map<std::pair<int, hipStream_t>, float*> ws;
+    int                                                  dev = 0;
+    FTCF_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    float*&                     p = ws[{dev, s}];
+    if (!p) {
+        FTCF_HIP_CHECK(hipMalloc(&p, CTX_SPLIT_WS + CTX_SPLIT_TK * sizeof(unsigned)));
+    }
+    return p;
 }
 
 void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* input_lengths, f16* k_cache,
@@ -607,11 +698,41 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
         }
     }
     else {
-        dim3 grid((ns + 63) / 64, nh, B);
+        // key split of the heaviest query blocks (see the kernel): those whose chain is longer than half the longest one, when the
+        // launch is long enough to care (>= 8 key tiles), the partials fit the workspace and nobody is capturing a graph (the
+        // workspace is allocated on first use).  FTCF_CTX_SPLIT=0 switches it off.
+        const int nqb = (ns + 63) / 64;
+        int       nsplit2 = 0;
+        float*    sws = nullptr;
+        unsigned* stk = nullptr;
+        {
+            const char* e    = getenv("FTCF_CTX_SPLIT");
+            const int   KTl  = dh > 128 ? 32 : 64;
+            const int   tmax = (s_hi - 1) / KTl + 1;  // key tiles of the last query block
+            if ((!e || atoi(e) != 0) && tmax >= 8) {
+                // query block qbi (0 = last) sees keys up to s_hi - 1 - 64 * qbi: split while its tiles exceed tmax / 2
+                int n2 = 0;
+                while (n2 < nqb && (s_hi - 1 - 64 * n2) / KTl + 1 > tmax / 2) {
+                    n2++;
+                }
+                const size_t need = (size_t)B * nh * n2 * 2 * ((size_t)64 * dh + 128) * sizeof(float);
+                if (n2 > 0 && need <= CTX_SPLIT_WS && (size_t)B * nh * n2 <= CTX_SPLIT_TK) {
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    (void)hipStreamIsCapturing(s, &cs);
+                    if (cs == hipStreamCaptureStatusNone) {
+                        sws     = ctx_split_workspace(s);
+                        stk     = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sws) + CTX_SPLIT_WS);
+                        nsplit2 = n2;
+                        FTCF_HIP_CHECK(hipMemsetAsync(stk, 0, (size_t)B * nh * n2 * sizeof(unsigned), s));
+                    }
+                }
+            }
+        }
+        dim3 grid(nqb + nsplit2, nh, B);
 #define X(D)                                                                                                           \
     if (dh == D) {                                                                                                     \
         hipLaunchKernelGGL((k_context_attention_mfma<D, (D > 128 ? 32 : 64)>), grid, dim3(256), 0, s, qkv, input_lengths,\
-                           k_cache, v_cache, S, nh, s_max, ctx, qk_scale, cache_row_mult, s_lo, s_hi);                 \
+                           k_cache, v_cache, S, nh, s_max, ctx, qk_scale, cache_row_mult, s_lo, s_hi, nsplit2, sws, stk);  \
     }
         FTCF_HEAD_SIZES(X)
 #undef X

@@ -269,6 +269,41 @@ def test_context_attention_matches_oracle(dh, nh, rot):
     np.testing.assert_array_equal(Vc.cpu().float().numpy()[:, :, :S], vc_o[:, :, :S])
 
 
+@pytest.mark.parametrize("dh,nh", [(128, 3), (64, 2)])
+def test_context_attention_key_split_matches_oracle_and_the_unsplit_form(dh, nh, monkeypatch):
+    """Prompts of >= 8 key tiles: the heaviest query blocks are cut in two along their keys and merged inside the launch
+    (FTCF_CTX_SPLIT, default on).  Ragged rows (one shorter than the split blocks' start, one ending inside a split block, one full)
+    against the oracle, the split and the unsplit form against each other, and the split form bit-identical on repeats (whichever
+    half arrives second merges: the merge is symmetric)."""
+    rng = np.random.RandomState(5)
+    B, S, s_max, rot = 3, 600, 640, 32
+    hl = nh * dh
+    lens = np.array([600, 130, 421], dtype=np.int32)
+    qkv = orc.round_half(rng.randn(B * S, 3 * hl).astype(np.float32))
+    bias = orc.round_half(0.1 * rng.randn(3 * hl).astype(np.float32))
+    kc_o = np.zeros((B, nh, s_max, dh), dtype=np.float32)
+    vc_o = np.zeros_like(kc_o)
+    ref = orc.context_attention(qkv, bias, lens, kc_o, vc_o, B, S, nh, dh, rot, fp16=True).reshape(B, S, hl)
+    t = lambda a, dt=torch.float16: D(torch.from_numpy(a).to(dt))
+
+    def run(split):
+        monkeypatch.setenv("FTCF_CTX_SPLIT", split)
+        Kc = torch.zeros((B, nh, s_max, dh), dtype=torch.float16, device="cuda")
+        Vc = torch.zeros_like(Kc)
+        ctx = torch.zeros((B * S, hl), dtype=torch.float16, device="cuda")
+        capi.check(capi.lib().ftcf_context_attention(capi.vp(t(qkv)), capi.vp(t(bias)), capi.vp(t(lens, torch.int32)),
+                                                     capi.vp(Kc), capi.vp(Vc), B, S, nh, dh, rot, s_max, capi.vp(ctx), sp()))
+        torch.cuda.synchronize()
+        return ctx.cpu().float().numpy().reshape(B, S, hl)
+
+    on, on2, off = run("1"), run("1"), run("0")
+    for b in range(B):
+        np.testing.assert_allclose(on[b, :lens[b]], ref[b, :lens[b]], rtol=1e-2, atol=2e-3)
+        np.testing.assert_allclose(on[b, :lens[b]], off[b, :lens[b]], rtol=2e-3, atol=1e-3)
+        np.testing.assert_array_equal(on[b, :lens[b]], on2[b, :lens[b]])
+    assert not np.array_equal(on[0], off[0])  # (the split really ran: a different association of the same sums)
+
+
 def test_gemv_and_mfma_paths_agree_at_codefuse_13b_shapes():
     """Full BASELINE sizes (H=5120, I=20480): the m<=4 VALU GEMV and the m>4 MFMA GEMM read the same tiled image;
     they must agree with each other and with an fp32 torch reference of the dequantised weights on the device."""
