@@ -383,7 +383,7 @@ def main():
                 import glob
                 pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1]))
                 c = pm["config"]
-                if (ps["gemv_kind"] == 4 and a.dtype == c["dtype"] and world == c["tensor_parallel"] and a.layers == c["layers"]
+                if (ps["gemv_kind"] == 4 and a.fake_tp <= 1 and a.dtype == c["dtype"] and world == c["tensor_parallel"] and a.layers == c["layers"]
                         and H == c["hidden"] and a.inter == c["inter"] and a.batch == 1):
                     traffic = pm["traffic_bytes_per_launch"]
                     traffic_source = ("profiles/" + os.path.basename(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_int8_tp1.json")))[-1])
