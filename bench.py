@@ -187,7 +187,7 @@ def live_traffic(a):
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
-        subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         dbs = glob.glob(os.path.join(tmp, "**", "*results.db"), recursive=True)
         c = sqlite3.connect(dbs[0])
         tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
