@@ -28,3 +28,20 @@ if (e > 0).all():
     print("kernel entry -> first layer top (preamble), us: median %.2f max %.2f ; entry skew across workgroups %.2f" % (
         np.median(ts[:, 0, :, 0] - e), (ts[:, 0, :, 0] - e).max(), e.max() - e.min()))
     print("kernel entry (first wg) -> last layer's x' merged (last wg): %.2f us" % (ts[:, L - 1, :, 12].max() - e.min()))
+# per XCD (workgroup b runs on XCD b % 8): are the late workgroups always the same ones?  Mean over layers 4 .. L-2 of the
+# workgroup's stamp relative to the layer's first wave, median over the XCD's workgroups, for the streams' ends
+if len(sys.argv) > 3 and sys.argv[3] == "xcd":
+    sub = ts[:, 4:L - 1]
+    rel = sub - sub[:, :, :, 0].min(axis=(0, 2))[None, :, None, None]
+    for k, w in ((3, 2), (3, 7), (4, 2), (6, 2), (7, 2), (10, 2), (10, 7), (10, 0), (12, 2)):
+        v = rel[:, :, w, k].mean(axis=1)  # [NB]
+        print(f"{names[k]:<34} wave {w}: " + " ".join("xcd%d %5.1f" % (x, np.median(v[x::8])) for x in range(8))
+              + "   | slowest wgs: " + " ".join(str(i) for i in np.argsort(v)[-6:]))
+    # is a workgroup's lateness persistent across layers?  correlation of its P3-run-end offset between even and odd layers
+    a = rel[:, 0::2, 2, 10].mean(axis=1)
+    b = rel[:, 1::2, 2, 10].mean(axis=1)
+    print("correlation of a workgroup's P3 run end (wave 2) between even and odd layers: %.2f; spread (p95 - p5) %.2f us" % (
+        np.corrcoef(a, b)[0, 1], np.percentile(a, 95) - np.percentile(a, 5)))
+    a = rel[:, 0::2, 2, 3].mean(axis=1)
+    b = rel[:, 1::2, 2, 3].mean(axis=1)
+    print("the same for the P1 run end: %.2f; spread %.2f us" % (np.corrcoef(a, b)[0, 1], np.percentile(a, 95) - np.percentile(a, 5)))
