@@ -552,3 +552,56 @@ def test_beams_that_finish_on_end_id_inside_the_batcher(gh, int8_mode):
         assert np.array_equal(lens, refs[i][1]), (i, lens, refs[i][1])
         np.testing.assert_allclose(cum, refs[i][2], rtol=5e-3, atol=5e-3)
     assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_mix_of_beam_and_greedy_requests_in_a_tight_pool(gh, seed):
+    """Stress of the page accounting: beam groups (their budgets, shared prompt pages, copy-on-write) and greedy requests arrive at
+    random into a pool too small for all of them -- admissions wait for pages and for K consecutive slots -- and every request still
+    is what the engine produces for it alone; the pool ends full."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(100 + seed)
+    reqs = []
+    for i in range(14):
+        n = int(rng.randint(2, 20))
+        prompt = rng.randint(3, V, size=n).tolist()
+        new = int(rng.randint(2, 11))
+        K = int(rng.choice([1, 1, 2, 3, 4]))
+        reqs.append((prompt, new, K))
+    refs = []
+    for prompt, new, K in reqs:
+        refs.append(_alone(gh, op, prompt, new, V, end_id)[0] if K == 1 else _beam_alone(gh, op, prompt, new, V, K))
+    cb = ContinuousBatcher(op, max_batch=6, page_tokens=8, num_pages=26, max_seq_len=32)
+    free0 = cb.status()["free_pages"]
+    arrive = sorted((int(rng.randint(0, 25)), i) for i in range(len(reqs)))
+    ids, got, done, it = {}, {}, set(), 0
+    while arrive or cb.busy():
+        while arrive and arrive[0][0] <= it:
+            _, i = arrive.pop(0)
+            prompt, new, K = reqs[i]
+            ids[cb.submit(prompt, new) if K == 1 else cb.submit_beam(prompt, new, K)] = i
+        for rid, tok, fin in cb.step():
+            i = ids[rid]
+            if reqs[i][2] == 1:
+                got.setdefault(i, []).append(tok)
+            else:
+                assert tok == -1 and fin
+                done.add(i)
+        st = cb.status()
+        assert 0 <= st["free_pages"] <= free0
+        it += 1
+        assert it < 5000
+    for i, (prompt, new, K) in enumerate(reqs):
+        if K == 1:
+            assert got[i] == refs[i], (i, got[i], refs[i])
+        else:
+            assert i in done
+            rid = [r for r, j in ids.items() if j == i][0]
+            out, lens, cum = cb.beam_result(rid)
+            assert np.array_equal(out, refs[i][0]) and np.array_equal(lens, refs[i][1]), (i, out, refs[i][0])
+            # (scores: the engine ran the K rows alone, the batcher among six -- other GEMM forms, other summation orders)
+            np.testing.assert_allclose(cum, refs[i][2], rtol=1e-2, atol=1e-2)
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
