@@ -60,15 +60,24 @@ class ContinuousBatcher:
         return int(rid.value)
 
     def submit_beam(self, prompt_ids, max_new_tokens, beam_width, beam_search_diversity_rate=0.0, len_penalty=0.0, temperature=1.0,
-                    repetition_penalty=1.0):
+                    repetition_penalty=1.0, min_length=0, stop_words=None):
         """A beam-search request (GptNeoXOp.forward with beam_width > 1).  step() reports one event for it, (request_id, -1, True),
         when it has finished; beam_result(request_id) then returns what forward returns for one prompt."""
         ids = np.ascontiguousarray(prompt_ids, dtype=np.int32).reshape(-1)
         rid = C.c_long(0)
-        capi.check(capi.lib().ftcf_batcher_submit_beam(
+        sw, sw_len = None, 0
+        if stop_words:
+            flat = [t for w in stop_words for t in w]
+            sw_len = len(flat)
+            arr = np.zeros((2, sw_len), dtype=np.int32)  # to_word_list_format (codefuse_example.py:26-53)
+            arr[0] = flat
+            arr[1] = -1
+            arr[1, :len(stop_words)] = np.cumsum([len(w) for w in stop_words])
+            sw = np.ascontiguousarray(arr)
+        capi.check(capi.lib().ftcf_batcher_submit_beam_ex(
             self._h, ids.ctypes.data_as(C.POINTER(C.c_int)), int(ids.size), int(max_new_tokens), int(beam_width),
             C.c_float(beam_search_diversity_rate), C.c_float(len_penalty), C.c_float(temperature), C.c_float(repetition_penalty),
-            C.byref(rid)))
+            int(min_length), sw.ctypes.data_as(C.POINTER(C.c_int)) if sw is not None else None, int(sw_len), C.byref(rid)))
         return int(rid.value)
 
     def beam_result(self, request_id):

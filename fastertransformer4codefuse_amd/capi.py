@@ -74,7 +74,7 @@ EXPORTED = [
     "ftcf_comm_allgather", "ftcf_gptneox_create", "ftcf_gptneox_forward", "ftcf_gptneox_begin", "ftcf_gptneox_step", "ftcf_gptneox_finish",
     "ftcf_gptneox_get_stats",
     "ftcf_gptneox_set_profiling", "ftcf_gptneox_destroy",
-    "ftcf_batcher_create", "ftcf_batcher_submit", "ftcf_batcher_submit_ex", "ftcf_batcher_submit_beam", "ftcf_batcher_beam_result", "ftcf_batcher_step", "ftcf_batcher_set_token_callback", "ftcf_batcher_status", "ftcf_batcher_cancel", "ftcf_batcher_destroy"]
+    "ftcf_batcher_create", "ftcf_batcher_submit", "ftcf_batcher_submit_ex", "ftcf_batcher_submit_beam", "ftcf_batcher_submit_beam_ex", "ftcf_batcher_beam_result", "ftcf_batcher_step", "ftcf_batcher_set_token_callback", "ftcf_batcher_status", "ftcf_batcher_cancel", "ftcf_batcher_destroy"]
 
 _lib = None
 

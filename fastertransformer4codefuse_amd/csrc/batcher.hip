@@ -92,6 +92,7 @@ struct ftcf_batcher {
         std::vector<std::vector<int>> stop;  // stop sequences (token ids)
         int              beam_width = 1;     // > 1: a beam group (submit_beam)
         float            diversity = 0.f, len_penalty = 0.f;
+        int              min_length = 0;     // beam requests: the end token is held back for this many new tokens
     };
     struct Slot {
         bool             active = false;
@@ -118,6 +119,7 @@ struct ftcf_batcher {
         long id = 0;
         int  si = 0, K = 0, n = 0, max_new = 0, generated = 0, budget = 0;
         bool penalised = false;  // repetition_penalty != 1
+        bool has_stop = false, has_min = false;
         std::vector<std::vector<int>> lists;  // page list of every beam
     };
     struct BeamResult {
@@ -144,6 +146,7 @@ struct ftcf_batcher {
     int *        d_bout = nullptr, *d_bpar = nullptr, *d_bseq = nullptr, *d_bin = nullptr, *d_pairs = nullptr, *d_bres = nullptr,
         *d_bres_len = nullptr;
     float *      d_btemp = nullptr, *d_brep = nullptr, *d_bdiv = nullptr, *d_blen = nullptr;
+    int *        d_bsw = nullptr, *d_bmin = nullptr;  // a group's stop words ([2][STOP_LW], the reference's layout) and min_length
     DecodeState* d_bstate = nullptr;
     void*        beam_ws = nullptr;
     float *      d_ptopk = nullptr, *d_ptopp = nullptr, *d_temp = nullptr, *d_cum = nullptr, *d_rep = nullptr;
@@ -239,6 +242,8 @@ struct ftcf_batcher {
         d_brep = dmalloc<float>(B);
         d_bdiv = dmalloc<float>(B);
         d_blen = dmalloc<float>(B);
+        d_bsw = dmalloc<int>(B * 2 * STOP_LW);
+        d_bmin = dmalloc<int>(B);
         d_bstate = dmalloc<DecodeState>(B);
         beam_ws = dmalloc<char>(beam_workspace_bytes(1, std::min(max_batch, BEAM_MAX_K)));
         d_ptopk = dmalloc<float>(B);
@@ -350,8 +355,10 @@ struct ftcf_batcher {
     // a beam-search request (GptNeoXOp.forward with beam_width > 1: OnlineBeamSearchLayer): K consecutive slots; one event when
     // it has finished (token = -1), the K hypotheses through beam_result()
     long submit_beam(const int* ids, int n, int max_new, int beam_width, float diversity, float len_penalty, float temperature,
-                     float repetition_penalty)
+                     float repetition_penalty, int min_length = 0, const int* stop_words = nullptr, int stop_len = 0)
     {
+        FTCF_CHECK_ARG(min_length >= 0, "min_length must not be negative");
+        FTCF_CHECK_ARG(stop_len >= 0 && stop_len <= STOP_LW && (stop_len == 0 || stop_words), "bad stop word list");
         FTCF_CHECK_ARG(beam_width >= 2 && beam_width <= BEAM_MAX_K && beam_width <= max_batch,
                        "beam_width must be in [2, 64] and fit the batcher's slots");
         FTCF_CHECK_ARG(repetition_penalty > 0.f && temperature > 0.f, "repetition_penalty and temperature must be positive");
@@ -375,6 +382,16 @@ struct ftcf_batcher {
         r.beam_width = beam_width;
         r.diversity = diversity;
         r.len_penalty = len_penalty;
+        r.min_length = min_length;
+        for (int i = 0, start = 0; i < stop_len; i++) {  // to_word_list_format (codefuse_example.py:26-53), as submit()
+            const int end = stop_words[stop_len + i];
+            if (end < 0) {
+                break;
+            }
+            FTCF_CHECK_ARG(end > start && end <= stop_len, "bad stop word offsets");
+            r.stop.emplace_back(stop_words + start, stop_words + end);
+            start = end;
+        }
         waiting.push_back(std::move(r));
         return waiting.back().id;
     }
@@ -668,6 +685,26 @@ struct ftcf_batcher {
         a.n_len_penalty = 1;
         a.output_ids = d_pout;
         a.sequence_lengths = d_pseq;
+        g.has_min  = r.min_length > 0;
+        g.has_stop = !r.stop.empty();
+        if (g.has_min) {
+            a.min_length = &r.min_length;
+            a.n_min_length = 1;
+            FTCF_HIP_CHECK(hipMemcpy(d_bmin + si, &r.min_length, 4, hipMemcpyHostToDevice));
+        }
+        if (g.has_stop) {  // the group's stop words stay on the device for its beam steps (checked along the parent chain there)
+            std::vector<int> sw(2 * STOP_LW, 0);
+            std::fill(sw.begin() + STOP_LW, sw.end(), -1);
+            int pos = 0, k = 0;
+            for (const auto& wd : r.stop) {
+                std::copy(wd.begin(), wd.end(), sw.begin() + pos);
+                pos += (int)wd.size();
+                sw[STOP_LW + k++] = pos;
+            }
+            FTCF_HIP_CHECK(hipMemcpy(d_bsw + (size_t)si * 2 * STOP_LW, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+            a.stop_words_list = d_bsw + (size_t)si * 2 * STOP_LW;
+            a.stop_words_len = STOP_LW;
+        }
         e->forward(a);  // host synchronous; the engine's buffers keep the request's state: step_ids / parent_ids [n + 1][K], ...
         // the prompt's pages, shared by every beam
         std::vector<int> shared;
@@ -696,6 +733,12 @@ struct ftcf_batcher {
         FTCF_HIP_CHECK(hipMemcpy(first.data(), e->step_ids + (size_t)n * K, (size_t)K * 4, hipMemcpyDeviceToHost));
         for (int k = 0; k < K; k++) {
             fin[k] = first[k] == e->cfg.end_id ? 1 : 0;
+            for (const auto& wd : r.stop) {  // (stop_criteria_kernels.cu:24-83 on prompt + first token: every beam's parent is the prompt)
+                if (!wd.empty() && (int)wd.size() <= n + 1 && wd.back() == first[k]
+                    && std::equal(wd.begin(), wd.end() - 1, r.prompt.end() - (wd.size() - 1))) {
+                    fin[k] = 1;
+                }
+            }
         }
         FTCF_HIP_CHECK(hipMemcpyAsync(d_fin + si, fin.data(), (size_t)K, hipMemcpyHostToDevice, st));
         FTCF_HIP_CHECK(hipMemcpyAsync(d_len + si, lens.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
@@ -751,6 +794,9 @@ struct ftcf_batcher {
             bp.repetition_penalty = g.penalised ? d_brep + si : nullptr;  // (NULL: no history staging buffer in LDS)
             bp.diversity_rate = d_bdiv + si;
             bp.len_penalty = d_blen + si;
+            bp.min_length = g.has_min ? d_bmin + si : nullptr;
+            bp.stop_words = g.has_stop ? d_bsw + (size_t)si * 2 * STOP_LW : nullptr;
+            bp.stop_len = STOP_LW;
             bp.output_ids = d_bout + reg;
             bp.parent_ids = d_bpar + reg;
             bp.finished = d_fin + si;
@@ -1227,6 +1273,17 @@ extern "C" int ftcf_batcher_submit_beam(ftcf_batcher_t b, const int* prompt_ids,
         FTCF_CHECK_ARG(b && request_id, "NULL argument");
         *request_id = b->submit_beam(prompt_ids, prompt_len, max_new_tokens, beam_width, beam_search_diversity_rate, len_penalty,
                                      temperature, repetition_penalty);
+    });
+}
+extern "C" int ftcf_batcher_submit_beam_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
+                                           float beam_search_diversity_rate, float len_penalty, float temperature,
+                                           float repetition_penalty, int min_length, const int* stop_words, int stop_len,
+                                           long* request_id)
+{
+    return guarded([&] {
+        FTCF_CHECK_ARG(b && request_id, "NULL argument");
+        *request_id = b->submit_beam(prompt_ids, prompt_len, max_new_tokens, beam_width, beam_search_diversity_rate, len_penalty,
+                                     temperature, repetition_penalty, min_length, stop_words, stop_len);
     });
 }
 extern "C" int ftcf_batcher_beam_result(ftcf_batcher_t b, long request_id, int* output_ids, int* sequence_lengths,

@@ -263,6 +263,12 @@ int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_l
 int ftcf_batcher_submit_beam(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
                              float beam_search_diversity_rate, float len_penalty, float temperature, float repetition_penalty,
                              long* request_id);
+/* The same with min_length (the end token is held back for that many new tokens: beam_search_penalty_kernels.cu:155-169; 0 = none)
+ * and stop words in the layout of ftcf_batcher_submit_ex (checked along a beam's parent chain: a beam that has emitted a stop
+ * sequence is finished). */
+int ftcf_batcher_submit_beam_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
+                                float beam_search_diversity_rate, float len_penalty, float temperature, float repetition_penalty,
+                                int min_length, const int* stop_words, int stop_len, long* request_id);
 int ftcf_batcher_beam_result(ftcf_batcher_t b, long request_id, int* output_ids, int* sequence_lengths, float* cum_log_probs,
                              int capacity, int* beam_width, int* total_len);
 /* One scheduler iteration: one decode step for the running sequences, then admissions (prefill + first token).  Returns one

@@ -605,3 +605,73 @@ def test_random_mix_of_beam_and_greedy_requests_in_a_tight_pool(gh, seed):
             # (scores: the engine ran the K rows alone, the batcher among six -- other GEMM forms, other summation orders)
             np.testing.assert_allclose(cum, refs[i][2], rtol=1e-2, atol=1e-2)
     assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+
+
+def _beam_capi(op, prompt, n_new, K, min_length=None, stop_words=None):
+    """The engine's beam search through the C ABI's argument block (min_length is not reachable through GptNeoXOp.forward)."""
+    import ctypes as C
+    from fastertransformer4codefuse_amd import capi
+    S = len(prompt)
+    ids = torch.tensor([prompt], dtype=torch.int32, device="cuda")
+    lens = torch.tensor([S], dtype=torch.int32, device="cuda")
+    out_ids = torch.zeros((1, K, S + n_new), dtype=torch.int32, device="cuda")
+    seq = torch.zeros((1, K), dtype=torch.int32, device="cuda")
+    cum = torch.zeros((1, K), dtype=torch.float32, device="cuda")
+    fa = capi.ForwardArgs()
+    fa.input_ids, fa.input_lengths = ids.data_ptr(), lens.data_ptr()
+    fa.batch_size, fa.max_input_len, fa.output_len, fa.beam_width = 1, S, n_new, K
+    keep = []
+    if min_length is not None:
+        ml = np.array([min_length], dtype=np.int32)
+        keep.append(ml)
+        fa.min_length, fa.n_min_length = ml.ctypes.data, 1
+    if stop_words is not None:
+        sw = torch.from_numpy(np.ascontiguousarray(stop_words, dtype=np.int32)).cuda()
+        keep.append(sw)
+        fa.stop_words_list, fa.stop_words_len = sw.data_ptr(), stop_words.shape[2]
+    fa.return_cum_log_probs = 1
+    fa.output_ids, fa.sequence_lengths, fa.cum_log_probs = out_ids.data_ptr(), seq.data_ptr(), cum.data_ptr()
+    capi.check(capi.lib().ftcf_gptneox_forward(op._h, C.byref(fa)))
+    torch.cuda.synchronize()
+    return out_ids[0].cpu().numpy(), seq[0].cpu().numpy(), cum[0].cpu().numpy()
+
+
+def test_beam_requests_with_stop_words_and_min_length_in_the_batcher(gh):
+    """ftcf_batcher_submit_beam_ex: min_length holds the end token back, stop words finish a beam along its parent chain -- the
+    hypotheses are what the engine's own beam search returns for the same arguments."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    cfg, w, z = load_tiny()
+    V = cfg["vocab_size"]
+    prompt, K, n_new = z["prompt"].tolist(), 3, 12
+    free = _beam_capi(gh.make_op(cfg, w), prompt, n_new, K)
+    S = len(prompt)
+    # the best hypothesis' 4th new token becomes the end token; its 7th and 8th new tokens a stop sequence
+    cfg2 = dict(cfg, end_id=int(free[0][0, S + 3]))
+    op = gh.make_op(cfg2, w)
+    base = _beam_capi(op, prompt, n_new, K)
+    stop_list = [[int(base[0][1, S + 1]), int(base[0][1, S + 2])]]
+    sw = np.full((1, 2, 2), -1, np.int32)
+    sw[0, 0, :] = stop_list[0]
+    sw[0, 1, 0] = 2
+    cases = {"plain": {}, "min_length": dict(min_length=8), "stop": dict(stop_words=sw), "both": dict(min_length=6, stop_words=sw)}
+    refs = {k: _beam_capi(op, prompt, n_new, K, **kw) for k, kw in cases.items()}
+    assert not np.array_equal(refs["plain"][0], refs["min_length"][0])  # the arguments matter on this prompt ...
+    assert not np.array_equal(refs["plain"][1], refs["stop"][1]) or not np.array_equal(refs["plain"][0], refs["stop"][0])
+    cb = ContinuousBatcher(op, max_batch=7, page_tokens=8, num_pages=80, max_seq_len=48)
+    free0 = cb.status()["free_pages"]
+    rids = {}
+    for name, kw in cases.items():
+        rids[cb.submit_beam(prompt, n_new, K, min_length=kw.get("min_length", 0),
+                            stop_words=stop_list if "stop_words" in kw else None)] = name
+    cb.submit(z["prompt_b"].tolist(), 9)  # a greedy neighbour
+    it = 0
+    while cb.busy():
+        cb.step()
+        it += 1
+        assert it < 2000
+    for rid, name in rids.items():
+        out, lens, cum = cb.beam_result(rid)
+        assert np.array_equal(out, refs[name][0]), (name, out, refs[name][0])
+        assert np.array_equal(lens, refs[name][1]), (name, lens, refs[name][1])
+        np.testing.assert_allclose(cum, refs[name][2], rtol=1e-2, atol=1e-2)
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
