@@ -1128,10 +1128,109 @@ __global__ __launch_bounds__(64 * WPB) void k_gemm_nk_f32out(const f16* __restri
     }
 }
 
+// The same product with the weight rows read as WHOLE 512-byte pieces (round 4).  The form above asks the memory for 64-byte
+// pieces of sixteen rows per wave-load -- the B-fragment order taken straight from the row-major [V, H] image -- and reaches
+// 3.6 TB/s on the 100864 x 5120 head; here a wave-load is two rows' 256 halves (lanes along k, as the GEMV LM head reads), the
+// 16 x 256 tile goes through a wave-private LDS tile and comes back in fragment order, and the 16 x 256 tile of x is staged once
+// per workgroup and chunk (double buffered, one barrier per chunk) instead of once per wave from the L2.  Every wave of a
+// workgroup makes the same number of trips (16 vocabulary rows each); the next chunk's rows are requested before the current
+// chunk's MFMAs.
+constexpr int NKT_KC = 256;
+template<int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gemm_nk_f32out_tr(const f16* __restrict__ A, const f16* __restrict__ W,
+                                                                 float* __restrict__ C, int m, int n, int k, int ldc, int trips)
+{
+    constexpr int KC = NKT_KC, LDT = KC + 8, NTHR = 64 * WAVES;
+    constexpr int XP = 16 * KC / 8 / NTHR;  // 16-byte pieces of the x tile per thread
+    static_assert(16 * KC / 8 % NTHR == 0, "x tile pieces per thread");
+    __shared__ __attribute__((aligned(16))) f16 xt[2][16 * LDT];
+    __shared__ __attribute__((aligned(16))) f16 wt[WAVES][16 * LDT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.y * 16;
+    const int NRG = (n + 15) / 16, nkc = k / KC;
+    const int total = trips * nkc;
+    f16*      wtw   = wt[wid];
+    u32x4     wr[8], xr[XP];
+    auto fetch = [&](const int it) {
+        const int t = it / nkc, kc = it % nkc;
+        int       rg = (t * (int)gridDim.x + (int)blockIdx.x) * WAVES + wid;
+        rg           = rg < NRG ? rg : NRG - 1;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int row = rg * 16 + 2 * u + (lane >> 5);
+            row     = row < n ? row : n - 1;
+            wr[u]   = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)row * k + (size_t)kc * KC + (lane & 31) * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < XP; u++) {
+            const int idx = threadIdx.x + u * NTHR;
+            int       row = m0 + idx / (KC / 8);
+            row           = row < m ? row : m - 1;
+            xr[u]         = *reinterpret_cast<const u32x4*>(A + (size_t)row * k + (size_t)kc * KC + (idx % (KC / 8)) * 8);
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int it = 0; it < total; it++) {
+        const int buf = it & 1;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            *reinterpret_cast<u32x4*>(&wtw[(2 * u + (lane >> 5)) * LDT + (lane & 31) * 8]) = wr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < XP; u++) {
+            const int idx = threadIdx.x + u * NTHR;
+            *reinterpret_cast<u32x4*>(&xt[buf][(idx / (KC / 8)) * LDT + (idx % (KC / 8)) * 8]) = xr[u];
+        }
+        __syncthreads();  // the x tile of this chunk (the readers of this buffer two chunks ago passed the previous barrier)
+        if (it + 1 < total) {
+            fetch(it + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ks++) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(&xt[buf][c * LDT + ks * 32 + g * 8]);
+            const f16x8 b = *reinterpret_cast<const f16x8*>(&wtw[c * LDT + ks * 32 + g * 8]);
+            acc           = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+        }
+        if (it % nkc == nkc - 1) {  // the trip's last chunk: 16 rows of x by 16 vocabulary rows
+            const int rg = ((it / nkc) * (int)gridDim.x + (int)blockIdx.x) * WAVES + wid;
+            if (rg < NRG) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = m0 + g * 4 + q;
+                    if (row < m && rg * 16 + c < n) {
+                        C[(size_t)row * ldc + rg * 16 + c] = acc[q];
+                    }
+                }
+            }
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n, int k, int ldc, hipStream_t s)
 {
     FTCF_CHECK_ARG(k % 32 == 0, "k must be a multiple of 32");
-    // (NGR, waves per workgroup, 32-k steps per trip) = (8, 2, 2): 289 us on the 100864 x 5120 head at 16 rows (3.6 TB/s);
+    {
+        const char* e = getenv("FTCF_LMHEAD_TR");  // (0: the fragment-order form below)
+        if ((!e || atoi(e) != 0) && k % NKT_KC == 0 && n >= 16) {
+            constexpr int WAVES = 4;
+            const int     NRG = (n + 15) / 16;
+            // 100864 x 5120 at 16 rows, us per launch by trips per wave: 1 (1576 workgroups): 171.0, 2: 190.9, 3 (526 workgroups = 2.05 per
+            // CU): 213.2, 4: 172.2, 6: 221.7 -- the fragment-order form: 283.7
+            int           trips = 1;
+            if (const char* t = getenv("FTCF_LMHEAD_TRIPS")) {
+                trips = std::max(1, atoi(t));
+            }
+            const int     gx    = (NRG + WAVES * trips - 1) / (WAVES * trips);
+            dim3          grid(gx, (m + 15) / 16);
+            hipLaunchKernelGGL((k_gemm_nk_f32out_tr<WAVES>), grid, dim3(64 * WAVES), 0, s, A, W_nk, C, m, n, k, ldc, trips);
+            FTCF_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
+    // (fallback for k % 256 != 0; NGR, waves per workgroup, 32-k steps per trip) = (8, 2, 2): 289 us on the 100864 x 5120 head at 16 rows (3.6 TB/s);
     // (2, 4, 8) 353, (4, 4, 4) 328, (8, 2, 4) 320, (16, 2, 1) 307.  More fragments in flight do not help: the row-major
     // [V, H] image (the caller's buffer, not re-tiled) is read in 64-byte pieces of 16 rows per wave-load.
     constexpr int NGR = 8, WPB = 2;

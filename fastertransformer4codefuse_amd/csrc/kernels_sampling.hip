@@ -1020,7 +1020,66 @@ __device__ __forceinline__ void greedy_finish(const SamplingParams& p, const flo
         steps_done = p.state->steps_done;
     }
     int picked = 0;
-    for (int row = 0; row < p.B; row++) {
+    // batches of more than four rows (k_greedy_decode's 32 slices per row): ONE WAVE per row, four rows at a time -- no workgroup
+    // barrier per row (16 rows took 70 us one after the other; the same picks, the same arithmetic per row)
+    const bool by_wave = !TAGGED && nsl <= 64 && p.B > 4;
+    if (by_wave) {
+        for (int row = wid; row < p.B; row += 4) {
+            int* out_id = p.output_ids + (size_t)step * p.B + row;
+            if (p.finished[row]) {
+                if (lane == 0) {
+                    *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242
+                    if (row < 8) {
+                        s_ids[row] = p.end_id;
+                    }
+                }
+                continue;
+            }
+            uint64_t draws = 0;
+            float    cum   = 0.f;
+            int      slen  = 0;
+            if (lane == 0) {
+                draws = p.draw_counter[row];
+                slen  = p.seq_len[row];
+                if (p.return_cum_log_probs && p.cum_log_probs) {
+                    cum = p.cum_log_probs[row];
+                }
+            }
+            const gu32* q = (const gu32*)(part + (size_t)row * nsl * 4);
+            VI          cand{-INFINITY, 0x7fffffff};
+            float       mq = -FLT_MAX, sq = 0.f;
+            if (lane < nsl) {
+                cand.v = __uint_as_float(__hip_atomic_load(q + (size_t)lane * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                cand.i = (int)__hip_atomic_load(q + (size_t)lane * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mq     = __uint_as_float(__hip_atomic_load(q + (size_t)lane * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                sq     = __uint_as_float(__hip_atomic_load(q + (size_t)lane * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            const VI    r       = wave_best(cand);
+            const float row_max = wave_max(mq);
+            const float tot     = wave_sum(sq * __expf(mq - row_max));  // (lanes without a slice add 0 * exp(.) = 0)
+            if (lane == 0) {
+                float prob = 1.f;
+                if (p.return_cum_log_probs) {
+                    prob = __expf(r.v - row_max) / (tot + 1e-6f);
+                }
+                p.draw_counter[row] = draws + 1;
+                int id = r.i;
+                if (id == 0x7fffffff || id < 0) {
+                    id = 0;
+                }
+                *out_id = id;
+                if (p.return_cum_log_probs && p.cum_log_probs) {
+                    p.cum_log_probs[row] = cum + logf(prob);
+                }
+                p.seq_len[row]  = slen + 1;
+                p.finished[row] = (id == p.end_id);
+                if (row < 8) {
+                    s_ids[row] = id;
+                }
+            }
+        }
+    }
+    for (int row = 0; row < (by_wave ? 0 : p.B); row++) {
         int* out_id = p.output_ids + (size_t)step * p.B + row;
         if (p.finished[row]) {
             if (threadIdx.x == 0) {
