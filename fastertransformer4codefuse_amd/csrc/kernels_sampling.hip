@@ -1211,7 +1211,32 @@ __device__ __forceinline__ void greedy_finish(const SamplingParams& p, const flo
         }
     }
     __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
-    if (p.next_x) {
+    if (p.next_x && by_wave) {
+        // (many rows: one wave per row, a row's pieces requested together -- sixteen rows copied one after the other by the whole
+        // workgroup were sixteen dependent memory round trips, 30 us of this tail)
+        constexpr int NP = 8;  // 16-byte pieces per lane and pass: 8 KiB of a row
+        for (int row = wid; row < p.B; row += 4) {
+            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
+            const f16* src = p.wte + (size_t)id * p.H;
+            f16*       dst = p.next_x + (size_t)row * p.H;
+            for (int i0 = 0; i0 < p.H; i0 += 64 * 8 * NP) {
+                u32x4 v[NP];
+#pragma unroll
+                for (int u = 0; u < NP; u++) {
+                    const int i = i0 + (u * 64 + lane) * 8;
+                    v[u]        = i < p.H ? *reinterpret_cast<const u32x4*>(src + i) : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < NP; u++) {
+                    const int i = i0 + (u * 64 + lane) * 8;
+                    if (i < p.H) {
+                        *reinterpret_cast<u32x4*>(dst + i) = v[u];
+                    }
+                }
+            }
+        }
+    }
+    else if (p.next_x) {
         // the next token's embedding rows: requested now, under the bookkeeping below
         for (int row = 0; row < p.B; row++) {
             const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
