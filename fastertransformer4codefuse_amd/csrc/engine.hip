@@ -370,7 +370,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
         // granules of the batched-decode GEMMs' in-launch reduction: their tags repeat from request to request
         FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), stream));
     }
-    if (pplan.ok) {
+    if (pplan.ok || rplan.ok) {
         const size_t cache_l = (size_t)B * nhl * s_max * dh;
         std::vector<PersistLayer> pl(L);
         for (int l = 0; l < L; l++) {
@@ -395,10 +395,15 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
             r.v_cache = v_cache + l * cache_l;
         }
         FTCF_HIP_CHECK(hipMemcpyAsync(d_players, pl.data(), sizeof(PersistLayer) * L, hipMemcpyHostToDevice, stream));
-        FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
+        if (rplan.ok) {  // the rows kernel's flags are monotone tags of (step, layer): steps repeat from request to request
+            FTCF_HIP_CHECK(hipMemsetAsync(rows_ws, 0, rows_flag_bytes(rplan, B, nhl), stream));
+        }
+        if (pplan.ok) {
+            FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
+        }
         ps_tab_ready = false;
         static const int tab_env = getenv("FTCF_PERSIST_TABLES") ? atoi(getenv("FTCF_PERSIST_TABLES")) : 1;
-        if (tab_env && ps_tab && !(cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->local)) {
+        if (pplan.ok && tab_env && ps_tab && !(cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->local)) {
             // the run / tile tables of this plan: one launch over no layers builds and stores them, every token's launch
             // loads them (17 us of table building per launch otherwise)
             PersistParams pp = persist_params(B, s_max);
@@ -765,6 +770,10 @@ void ftcf_gptneox::finish()
         FTCF_HIP_CHECK(hipMemcpyAsync(&smallm_error, reinterpret_cast<char*>(smallm_ws) + smallm_partial, sizeof(int),
                                       hipMemcpyDeviceToHost, stream));
     }
+    int rows_error = 0;
+    if (rplan.ok) {
+        FTCF_HIP_CHECK(hipMemcpyAsync(&rows_error, rows_ws, sizeof(int), hipMemcpyDeviceToHost, stream));
+    }
     comm_stream_sync(cfg.comm, stream);
     float ms = 0.f;
     FTCF_HIP_CHECK(hipEventElapsedTime(&ms, ses.e0, ses.e1));
@@ -805,6 +814,27 @@ void ftcf_gptneox::finish()
             fclose(f);
         }
     }
+    if (rplan.ok && rows_ts) {
+        std::vector<long long> h((size_t)rplan.NB * L * 128);
+        FTCF_HIP_CHECK(hipMemcpy(h.data(), rows_ts, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(ps_ts_file.c_str(), "wb")) {
+            const int hdr[4] = {rplan.NB, L, 8, 16};
+            fwrite(hdr, 4, 4, f);
+            fwrite(h.data(), 8, h.size(), f);
+            fclose(f);
+        }
+    }
+    if (rplan.ok && persist_fail_once) {  // the same test hook for the rows kernel
+        persist_fail_once = 0;
+        rows_error        = 99;
+    }
+    if (rplan.ok && cfg.tensor_para_size > 1) {
+        if (!tp_scratch) {
+            FTCF_HIP_CHECK(hipMalloc((void**)&tp_scratch, 256));
+            FTCF_HIP_CHECK(hipMemsetAsync(tp_scratch, 0, 256, stream));
+        }
+        rows_error = comm_max(cfg.comm, rows_error, stream, tp_scratch);
+    }
     if (pplan.ok && persist_fail_once) {  // test hook (FTCF_PERSIST_FAIL_ONCE=1): pretend the kernel gave up once
         persist_fail_once = 0;
         ps_error          = 99;
@@ -833,6 +863,12 @@ void ftcf_gptneox::finish()
     }
     if (smallm_error != 0) {
         throw Error(-2, "batched decode GEMM: a split-K reducer gave up waiting for its sibling workgroups' partial sums");
+    }
+    if (rows_error != 0) {
+        persist_failed = true;
+        rows           = 0;  // the next request (and the replay of this one) is planned on the general path
+        throw Error(-2, "rows decode kernel gave up waiting for a hand-off (code " + std::to_string(rows_error)
+                            + "): not every workgroup was resident");
     }
     if (ps_error != 0) {
         persist_failed = true;
@@ -1006,6 +1042,15 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_PERSIST")) {
             e->persist = atoi(m);
         }
+        if (const char* m = getenv("FTCF_ROWS")) {
+            e->rows = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_ROWS_NB")) {
+            e->rows_nb = atoi(m);
+        }
+        if (const char* m = getenv("FTCF_ROWS_MIN_ROWS")) {
+            e->rows_min = std::max(1, atoi(m));
+        }
         if (const char* m = getenv("FTCF_PERSIST_FAIL_ONCE")) {
             e->persist_fail_once = atoi(m);
         }
@@ -1034,6 +1079,12 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         }
         if (const char* m = getenv("FTCF_USE_GRAPH")) {
             e->use_graph = atoi(m) != 0;
+        }
+        if (cfg->tensor_para_size > 1) {
+            // scratch word of the communicator helpers (comm_barrier / comm_max / comm_agree): every path of a tensor-parallel
+            // engine may reach them (the prompt-phase overlap's trials, the kernels' error words), whatever it planned
+            FTCF_HIP_CHECK(hipMalloc((void**)&e->tp_scratch, 256));
+            FTCF_HIP_CHECK(hipMemsetAsync(e->tp_scratch, 0, 256, e->stream));
         }
         FTCF_HIP_CHECK(hipHostMalloc((void**)&e->h_flags, 64, hipHostMallocDefault));
         e->h_flags[0] = e->h_flags[1] = e->h_flags[2] = 0;

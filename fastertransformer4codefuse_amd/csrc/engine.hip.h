@@ -124,6 +124,11 @@ struct ftcf_gptneox {
     int*                ps_err = nullptr;
     int*                tp_scratch = nullptr;  // device int for the barrier all-reduce of the tensor-parallel windows
     long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
+    // persistent decode layers for 3..16 rows (kernels_rows.hip): on whenever the shape is eligible (FTCF_ROWS=0: general path)
+    int                 rows = 1, rows_nb = 0, rows_min = 3;
+    RowsPlan            rplan{};
+    char*               rows_ws = nullptr;
+    long long*          rows_ts = nullptr;
     std::string         ps_ts_file;
 
     // profiling
@@ -296,6 +301,29 @@ struct ftcf_gptneox {
                 static const int lm_env = persist_lm_tail_built() && getenv("FTCF_PERSIST_LM") ? atoi(getenv("FTCF_PERSIST_LM")) : 0;
                 ps_lm_fused = lm_env != 0 && tpn == 1 && H % 512 == 0;
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
+            }
+            // 3..16 rows (and what the one- / two-row kernel does not take): the rows kernel, one launch per token; with tensor
+            // parallelism one launch per layer, the all-reduce of x' between them
+            rplan = RowsPlan{};
+            rows_ws = nullptr;
+            rows_ts = nullptr;
+            if (rows && !pplan.ok && !fp32 && K == 1 && B >= rows_min && B <= 16 && cfg.use_gptj_residual && L <= 255) {
+                // (ranks that share ONE device -- a local group's threads, the two-process tests -- must be resident together)
+                int nb = rows_nb > 0 ? rows_nb : persist_nb;
+                if (tp_local) {
+                    nb = std::max(1, (nb > 0 ? nb : num_cu) / tpn);
+                }
+                rplan = rows_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb);
+                if (rplan.ok && !rows_resident(rplan, int8, dh, num_cu)) {
+                    rplan = RowsPlan{};
+                }
+                if (rplan.ok) {
+                    rows_ws = c.take<char>(rows_workspace_bytes(rplan, B, H, hl, il, nhl, dh));
+                    if (!d_players || !pplan.ok) {
+                        d_players = c.take<PersistLayer>(L);
+                    }
+                    rows_ts = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)rplan.NB * L * 128);
+                }
             }
             // (the four GEMMs of a layer may be in flight together: one region each)
             // (17..SMALLM_MAX_ROWS rows run the same kernel in chunks of 16 rows: sized for one chunk)
@@ -785,6 +813,39 @@ struct ftcf_gptneox {
         return pp;
     }
 
+    RowsParams rows_params(int B, int s_max)
+    {
+        RowsParams rp{};
+        rp.layers = d_players;
+        rp.L = L;
+        rp.l_begin = 0;
+        rp.l_end = L;
+        rp.x_in = x;
+        rp.x_out = x;
+        rp.M = B;
+        rp.H = H;
+        rp.Hl = hl;
+        rp.Il = il;
+        rp.nh = nhl;
+        rp.dh = dh;
+        rp.rot = cfg.rotary_embedding_dim;
+        rp.s_max = s_max;
+        rp.tp = cfg.tensor_para_size;
+        rp.plan = rplan;
+        rows_carve(rp, rows_ws);
+        rp.d_step = &state->step;
+        rp.d_stop = &state->all_finished;
+        rp.seq_len = seq_len;
+        rp.pad_count = pad_count;
+        rp.input_lengths = ses.sp.input_lengths;
+        rp.max_input_len = ses.S;
+        rp.finished = finished;
+        rp.rot_table = rot_table;
+        rp.eps = 1e-5f;
+        rp.ts = rows_ts;
+        return rp;
+    }
+
     // GptNeoXDecoder::forward (GptNeoXDecoder.cc:245-384)
     void decoder(int B, int s_max)
     {
@@ -799,7 +860,8 @@ struct ftcf_gptneox {
             FT_LOG_DEBUG(cfg.device, "decoder of this request: %s (rows %d, context %d%s)",
                          pplan.ok ? (pplan.a4 ? "persistent layers, second form (attention branch on the control waves)"
                                               : "persistent layers")
-                                  : (staged ? "per-stage launches" : "general path (batched GEMMs)"),
+                                  : (rplan.ok ? "persistent layers for up to 16 rows"
+                                              : (staged ? "per-stage launches" : "general path (batched GEMMs)")),
                          B, s_max, pplan.ok ? (pplan.uk == 16 ? ", 512 keys per KV split" : ", 256 keys per KV split") : "");
         }
         if (pplan.ok) {
@@ -832,6 +894,25 @@ struct ftcf_gptneox {
                 return;
             }
             timed(KIND_PERSIST, layer_bytes * L + (ps_lm_fused ? 2.0 * V * H : 0.0), [&] { launch_decode_persistent(pp, int8, stream); });
+            return;
+        }
+        if (rplan.ok) {
+            // every stage of every layer inside ONE launch for up to 16 rows (kernels_rows.hip); with tensor parallelism one
+            // launch per layer and the all-reduce of its output between them (GptNeoXDecoder.cc:357-359)
+            RowsParams   rp          = rows_params(B, s_max);
+            const double layer_bytes = wbytes * ((double)H * 3 * hl + (double)H * il + (double)hl * H + (double)il * H)
+                                       + 4.0 * ses.next_step * hl * B;
+            stats.decode_path = 3;
+            if (cfg.tensor_para_size == 1) {
+                timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_rows(rp, int8, stream); });
+                return;
+            }
+            for (int l = 0; l < L; l++) {
+                rp.l_begin = l;
+                rp.l_end   = l + 1;
+                timed(KIND_PERSIST, layer_bytes, [&] { launch_decode_rows(rp, int8, stream); });
+                allreduce(x, (size_t)B * H);
+            }
             return;
         }
         for (int l = 0; l < L; l++) {
@@ -1175,8 +1256,7 @@ struct ftcf_gptneox {
             // a sticky error word instead of hanging the GPU; the request is then replayed from the start on the
             // per-stage / general path (tensor parallel: every rank takes this branch -- finish() agrees on the error
             // word across the ranks) and the engine stays off the persistent path.
-            persist_failed = false;
-            persist        = 0;
+            persist_failed = false;  // (finish() has switched off the kernel that gave up: `persist` or `rows`)
             FT_LOG_WARNING(cfg.device, "persistent decode kernel gave up on a hand-off: replaying the request on the per-stage "
                                        "path (this engine stays there)");
             begin(a);

@@ -276,6 +276,59 @@ const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
 PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8);
 const void* persist4_kernel(bool int8, int dh, bool tp, bool group);
 
+// ---- persistent decode layers for 3..16 rows : kernels_rows.hip ----
+// One launch runs layers [l_begin, l_end) of the batched decode step (GptNeoXDecoder.cc:245-384, any B <= 16) on one resident
+// 8-wave workgroup per CU.  A layer is five chip-wide streams -- QKV, FFN1, the K/V rows of the attention, FFN2, out-proj --
+// in that order, so that every hand-off but the layer boundary travels under the stream that follows its producer.  Weight
+// tiles are walked k-major over up to five 16-column groups per workgroup with the rows' MFMA A fragments fetched per k-step
+// from L2 (sc1 loads of the producers' write-through stores); hand-offs are flags behind drained write-through stores.
+struct RowsPlan {
+    int    ok;
+    int    NB;            // workgroups (<= CUs)
+    int    g1;            // kernel instantiation: column groups per k-step of the QKV pass (4 or 5)
+    int    CB, KP2, KP3;  // row-parallel GEMMs: column blocks of RW_G groups, K pieces of FFN2 / out-proj
+    int    nc1, nc2, nc3; // k-steps the control wave streams itself (column-parallel passes, FFN2 piece, out-proj piece)
+    int    nsplit;        // KV splits per (row, head)
+    size_t smem;
+};
+struct RowsParams {
+    const PersistLayer* layers;  // device array [L] (k_cache / v_cache: this layer's [B][nh][s_max][dh])
+    int                 L, l_begin, l_end;
+    const f16*          x_in;   // [M][H] input of layer l_begin (plain memory)
+    f16*                x_out;  // [M][H] output of layer l_end - 1
+    f16*                xb[2];  // layer inputs handed over inside the launch (layer l reads xb[l & 1])
+    unsigned long long* stats;  // [2][M][CB] {sum, sum of squares} of a row over one column block, as two floats
+    f16 *               qkv, *mid, *ctx;  // [M][3 Hl], [M][Il], [M][Hl]
+    float *             p2, *p3;          // fp32 partial sums of FFN2 / out-proj: [KP][M][H]
+    float*              pa;               // attention partials [M][nh][nsplit][dh + 2]
+    unsigned *          fq, *fm, *f2, *f3, *fx;  // [NB] flags: qkv / mid / FFN2 piece / out-proj piece / x' of a workgroup
+    unsigned *          fa, *fc;                 // [M * nh * nsplit], [M * nh]: attention partial / merged ctx
+    int*                err;
+    int                 M, H, Hl, Il, nh, dh, rot, s_max, tp;
+    RowsPlan            plan;
+    const int*          d_step;
+    const int*          d_stop;
+    const int*          seq_len;
+    const int*          pad_count;
+    const int*          input_lengths;  // keys [input_lengths[b], max_input_len) of row b are padding (never attended)
+    int                 max_input_len;
+    const uint8_t*      finished;
+    const float*        rot_table;
+    float               eps;
+    long long*          ts;  // optional [NB][L][8][16] stamps
+    // paged K/V (continuous batching): page_table != NULL -> row b's key t lives in page page_table[b * max_pages + t / P] of
+    // the layer's pool [num_pages][nh][P][dh] (k_cache / v_cache of the layer table point at the pools)
+    const int*          page_table;
+    int                 page_tokens, max_pages;
+};
+RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb);
+bool     rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu);
+// bytes of the hand-off region (flags first: rows_flag_bytes() of it must be zero when a request begins) and its carve
+size_t   rows_workspace_bytes(const RowsPlan& pl, int M, int H, int Hl, int Il, int nh, int dh);
+size_t   rows_flag_bytes(const RowsPlan& pl, int M, int nh);
+void     rows_carve(RowsParams& p, void* workspace);  // fills the buffer pointers of p (M, H, ..., plan set)
+void     launch_decode_rows(const RowsParams& p, bool int8, hipStream_t s);
+
 // ---- fp32 instantiation (FTGptNeoX<float>, GptNeoXOp.cc:56-70) : kernels_fp32.hip ----
 struct Mmha32Params {
     const float*   qkv;       // [B, 3*Hl]
