@@ -287,8 +287,8 @@ struct RowsPlan {
     int    NB;            // workgroups (<= CUs)
     int    g1;            // kernel instantiation: column groups per k-step of the QKV pass (4 or 5)
     int    CB, KP2, KP3;  // row-parallel GEMMs: column blocks of RW_G groups, K pieces of FFN2 / out-proj
-    int    nc1, nc2, nc3; // k-steps the control wave streams itself (column-parallel passes, FFN2 piece, out-proj piece)
-    int    nsplit;        // KV splits per (row, head)
+    int    U;             // (row, head) pairs of a workgroup at most (pair = workgroup + u * NB)
+    int    CR, cw;        // the layer boundary: column ranges per row (merger = row * CR + range), columns per range
     size_t smem;
 };
 struct RowsParams {
@@ -296,14 +296,15 @@ struct RowsParams {
     int                 L, l_begin, l_end;
     const f16*          x_in;   // [M][H] input of layer l_begin (plain memory)
     f16*                x_out;  // [M][H] output of layer l_end - 1
-    f16*                xb[2];  // layer inputs handed over inside the launch (layer l reads xb[l & 1])
-    unsigned long long* stats;  // [2][M][CB] {sum, sum of squares} of a row over one column block, as two floats
-    f16 *               qkv, *mid, *ctx;  // [M][3 Hl], [M][Il], [M][Hl]
-    float *             p2, *p3;          // fp32 partial sums of FFN2 / out-proj: [KP][M][H]
-    float*              pa;               // attention partials [M][nh][nsplit][dh + 2]
-    unsigned *          fq, *fm, *f2, *f3, *fx;  // [NB] flags: qkv / mid / FFN2 piece / out-proj piece / x' of a workgroup
-    unsigned *          fa, *fc;                 // [M * nh * nsplit], [M * nh]: attention partial / merged ctx
-    int*                err;
+    // the hand-off region: ONE buffer (one descriptor inside the kernel), byte offsets of its parts
+    char*               ws;
+    unsigned            ws_bytes;
+    unsigned            o_fq, o_fm, o_fc, o_f2, o_f3;  // [NB] flags: q|k|v / mid / ctx / FFN2 piece / out-proj piece of a workgroup
+    unsigned            o_xs;     // [2][M * CR] 16-byte granules {tag, sum, sum of squares, 0} of a merger's piece of x'
+    unsigned            o_xb[2];  // layer inputs handed over inside the launch (layer l reads xb[l & 1]): [M][H] halves
+    unsigned            o_qkv, o_mid, o_ctx;  // [M][3 Hl], [M][Il], [M][Hl] halves
+    unsigned            o_p2, o_p3;           // fp32 partial sums of FFN2 / out-proj: [KP][M][H]
+    int*                err;                  // (= ws)
     int                 M, H, Hl, Il, nh, dh, rot, s_max, tp;
     RowsPlan            plan;
     const int*          d_step;

@@ -5,19 +5,9 @@
 
 namespace ftcf {
 
-// k-steps the control wave streams itself out of the n of a workgroup's piece: what seven equal shares leave over, unless that is
-// more than about half a streamer wave's share (the control wave starts its stream behind its polls)
-static int rows_control_share(const int n)
-{
-    const int c = n % RW_NS;
-    return (c <= n / RW_NS / 2 + 1) ? c : 0;
-}
-
 RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb)
 {
     RowsPlan pl{};
-    (void)s_max;
-    const int KS = int8 ? TILE_K_I8 : TILE_K_F16;
     if (M < 1 || M > 16 || (dh != 64 && dh != 128) || nh * dh != Hl || H % 64 != 0 || Hl % 64 != 0 || Il % 64 != 0 || H > 8192) {
         return pl;
     }
@@ -35,29 +25,39 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
     if (pl.CB > NB) {
         return pl;
     }
-    const int KT1 = H / KS, KT2 = Il / KS, KT3 = Hl / KS;
+    const int KS  = int8 ? TILE_K_I8 : TILE_K_F16;
+    const int KT2 = Il / KS, KT3 = Hl / KS;
     pl.KP2 = std::max(1, std::min(NB / pl.CB, KT2 / 8));
     pl.KP3 = std::max(1, std::min(std::min(NB / pl.CB, KT3 / 8), 16));
-    // attention: one wave per (row, head, split); the splits fill the streamer waves
-    const int pairs = M * nh;
-    if (pairs > NB * RW_NS) {
+    // (32-bit byte offsets behind the kernel's descriptors: a weight matrix, a layer's K cache)
+    if ((size_t)H * std::max(3 * Hl, Il) * 2 >= ((size_t)1 << 31) || (size_t)M * nh * (size_t)s_max * dh * 2 >= ((size_t)1 << 31)) {
         return pl;
     }
-    pl.nsplit = std::max(1, std::min(RW_MAXSPLIT, NB * RW_NS / pairs));
-    static const int ns_env = getenv("FTCF_ROWS_NSPLIT") ? atoi(getenv("FTCF_ROWS_NSPLIT")) : 0;
-    if (ns_env > 0 && ns_env <= RW_MAXSPLIT && pairs * ns_env <= NB * RW_NS) {
-        pl.nsplit = ns_env;
-    }
-    static const int nc_env = getenv("FTCF_ROWS_NC") ? atoi(getenv("FTCF_ROWS_NC")) : -1;
-    pl.nc1 = nc_env >= 0 ? nc_env : rows_control_share(KT1);
-    pl.nc2 = nc_env >= 0 ? nc_env : rows_control_share((KT2 + pl.KP2 - 1) / pl.KP2);
-    pl.nc3 = nc_env >= 0 ? nc_env : rows_control_share((KT3 + pl.KP3 - 1) / pl.KP3);
-    // the merger's scratch: (rows of a merger) x (octets of a column block) items
-    if (((M + pl.KP3 - 1) / pl.KP3) * RW_G * 2 > 256) {
+    // attention: the (row, head) pairs are dealt round robin, a pair stays inside its workgroup
+    pl.U = (M * nh + NB - 1) / NB;
+    if (pl.U > RW_UMAX) {
         return pl;
     }
-    pl.NB   = NB;
-    pl.smem = (size_t)4 * H * 2 + (size_t)2 * RW_NW * RW_G * 256 * 4 + 32 * 4 + 512 * 4 + (size_t)RW_NW * 3 * dh * 2 + 64;
+    // the layer boundary: merger (row, column range); a range is a whole number of 8-column pieces
+    if (M > NB) {
+        return pl;
+    }
+    pl.CR = std::max(1, std::min(NB / M, H / 64));
+    while (H % pl.CR != 0 || (H / pl.CR) % 8 != 0) {
+        pl.CR--;
+    }
+    pl.cw = H / pl.CR;
+    if (M * pl.CR > 256) {
+        pl.CR = 256 / M;  // (the control wave sweeps at most 256 granules)
+        while (H % pl.CR != 0 || (H / pl.CR) % 8 != 0) {
+            pl.CR--;
+        }
+        pl.cw = H / pl.CR;
+    }
+    pl.NB = NB;
+    const int Hp = (H + 511) & ~511;
+    pl.smem      = (size_t)4 * Hp * 2 + (size_t)2 * RW_NS * RW_G * 256 * 4 + (size_t)RW_UMAX * RW_NS * (dh + RW_PA) * 4
+              + (size_t)RW_NW * RW_UMAX * 2 * dh * 2 + 32 * 4 + 512 * 4 + RW_UMAX * 8 * 4 + 64;
     if (pl.smem > 160 * 1024) {
         return pl;
     }
@@ -71,50 +71,48 @@ static size_t al256(size_t v)
 }
 size_t rows_flag_bytes(const RowsPlan& pl, int M, int nh)
 {
-    // err | fq fm f2 f3 fx [NB each] | fa [M nh nsplit] | fc [M nh]
-    return al256(256 + (size_t)(5 * pl.NB + M * nh * pl.nsplit + M * nh) * 4);
+    (void)nh;
+    // err | fq fm fc f2 f3 [NB each] | x' granules [2][M * CR] of 16 bytes
+    return al256(256 + (size_t)5 * pl.NB * 4) + al256((size_t)2 * M * pl.CR * 16);
 }
 size_t rows_workspace_bytes(const RowsPlan& pl, int M, int H, int Hl, int Il, int nh, int dh)
 {
+    (void)dh;
     size_t b = rows_flag_bytes(pl, M, nh);
-    b += al256((size_t)2 * M * pl.CB * 8);                          // stats
-    b += 2 * al256((size_t)M * H * 2);                              // xb
+    b += 2 * al256((size_t)M * H * 2);                                                            // xb
     b += al256((size_t)M * 3 * Hl * 2) + al256((size_t)M * Il * 2) + al256((size_t)M * Hl * 2);  // qkv, mid, ctx
     b += al256((size_t)pl.KP2 * M * H * 4) + al256((size_t)pl.KP3 * M * H * 4);                   // p2, p3
-    b += al256((size_t)M * nh * pl.nsplit * (dh + RW_PA_PAD) * 4);                                // pa
     return b;
 }
 void rows_carve(RowsParams& p, void* workspace)
 {
     const RowsPlan& pl = p.plan;
-    char*           q  = static_cast<char*>(workspace);
-    p.err              = reinterpret_cast<int*>(q);
-    unsigned* f        = reinterpret_cast<unsigned*>(q + 256);
-    p.fq               = f;
-    p.fm               = f + pl.NB;
-    p.f2               = f + 2 * pl.NB;
-    p.f3               = f + 3 * pl.NB;
-    p.fx               = f + 4 * pl.NB;
-    p.fa               = f + 5 * pl.NB;
-    p.fc               = p.fa + (size_t)p.M * p.nh * pl.nsplit;
-    q += rows_flag_bytes(pl, p.M, p.nh);
-    p.stats = reinterpret_cast<unsigned long long*>(q);
-    q += al256((size_t)2 * p.M * pl.CB * 8);
-    p.xb[0] = reinterpret_cast<f16*>(q);
-    q += al256((size_t)p.M * p.H * 2);
-    p.xb[1] = reinterpret_cast<f16*>(q);
-    q += al256((size_t)p.M * p.H * 2);
-    p.qkv = reinterpret_cast<f16*>(q);
-    q += al256((size_t)p.M * 3 * p.Hl * 2);
-    p.mid = reinterpret_cast<f16*>(q);
-    q += al256((size_t)p.M * p.Il * 2);
-    p.ctx = reinterpret_cast<f16*>(q);
-    q += al256((size_t)p.M * p.Hl * 2);
-    p.p2 = reinterpret_cast<float*>(q);
-    q += al256((size_t)pl.KP2 * p.M * p.H * 4);
-    p.p3 = reinterpret_cast<float*>(q);
-    q += al256((size_t)pl.KP3 * p.M * p.H * 4);
-    p.pa = reinterpret_cast<float*>(q);
+    p.ws               = static_cast<char*>(workspace);
+    p.err              = reinterpret_cast<int*>(workspace);
+    size_t o           = 256;
+    p.o_fq             = (unsigned)o;
+    p.o_fm             = (unsigned)(o + (size_t)pl.NB * 4);
+    p.o_fc             = (unsigned)(o + (size_t)2 * pl.NB * 4);
+    p.o_f2             = (unsigned)(o + (size_t)3 * pl.NB * 4);
+    p.o_f3             = (unsigned)(o + (size_t)4 * pl.NB * 4);
+    o                  = al256(256 + (size_t)5 * pl.NB * 4);
+    p.o_xs             = (unsigned)o;
+    o += al256((size_t)2 * p.M * pl.CR * 16);
+    p.o_xb[0] = (unsigned)o;
+    o += al256((size_t)p.M * p.H * 2);
+    p.o_xb[1] = (unsigned)o;
+    o += al256((size_t)p.M * p.H * 2);
+    p.o_qkv = (unsigned)o;
+    o += al256((size_t)p.M * 3 * p.Hl * 2);
+    p.o_mid = (unsigned)o;
+    o += al256((size_t)p.M * p.Il * 2);
+    p.o_ctx = (unsigned)o;
+    o += al256((size_t)p.M * p.Hl * 2);
+    p.o_p2 = (unsigned)o;
+    o += al256((size_t)pl.KP2 * p.M * p.H * 4);
+    p.o_p3 = (unsigned)o;
+    o += al256((size_t)pl.KP3 * p.M * p.H * 4);
+    p.ws_bytes = (unsigned)o;
 }
 
 template<bool INT8, int DH, int G1, bool PAGED>
@@ -137,14 +135,6 @@ static const void* rw_kernel_for(bool int8, int dh, int g1, bool paged)
     RW_SEL(false, 128, 5, false)
     RW_SEL(false, 64, 4, false)
     RW_SEL(false, 64, 5, false)
-    RW_SEL(true, 128, 4, true)
-    RW_SEL(true, 128, 5, true)
-    RW_SEL(true, 64, 4, true)
-    RW_SEL(true, 64, 5, true)
-    RW_SEL(false, 128, 4, true)
-    RW_SEL(false, 128, 5, true)
-    RW_SEL(false, 64, 4, true)
-    RW_SEL(false, 64, 5, true)
 #endif
 #undef RW_SEL
     return nullptr;
@@ -156,7 +146,7 @@ bool rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu)
     if (!pl.ok) {
         return false;
     }
-    for (int paged = 0; paged < 2; paged++) {
+    for (int paged = 0; paged < 1; paged++) {  // (the paged form is instantiated when the batcher takes this kernel)
         const void* k = rw_kernel_for(int8, dh, pl.g1, paged != 0);
         if (!k) {
             return false;
