@@ -287,8 +287,11 @@ struct RowsPlan {
     int    NB;            // workgroups (<= CUs)
     int    g1;            // kernel instantiation: column groups per k-step of the QKV pass (4 or 5)
     int    CB, KP2, KP3;  // row-parallel GEMMs: column blocks of RW_G groups, K pieces of FFN2 / out-proj
-    int    U;             // (row, head) pairs of a workgroup at most (pair = workgroup + u * NB)
+    int    U;             // attention units of a workgroup at most: whole (row, head) pairs (pair = workgroup + u * NB) + one part
+    int    FX;            // ... of a leftover pair: each of the M nh % NB leftover pairs is shared by FX workgroups
     int    CR, cw;        // the layer boundary: column ranges per row (merger = row * CR + range), columns per range
+    int    wcum[8];       // K shares of the seven streamer waves: wave s streams [n wcum[s] / wcum[7], n wcum[s + 1] / wcum[7]) of a
+                          // workgroup's n k-steps (the younger wave of a SIMD's pair issues behind the older one: FTCF_ROWS_WS)
     size_t smem;
 };
 struct RowsParams {
@@ -304,6 +307,7 @@ struct RowsParams {
     unsigned            o_xb[2];  // layer inputs handed over inside the launch (layer l reads xb[l & 1]): [M][H] halves
     unsigned            o_qkv, o_mid, o_ctx;  // [M][3 Hl], [M][Il], [M][Hl] halves
     unsigned            o_p2, o_p3;           // fp32 partial sums of FFN2 / out-proj: [KP][M][H]
+    unsigned            o_fa, o_pa;           // shared pairs: [NB] flags, [NB][dh + 4] {out, max, sum} of a part
     int*                err;                  // (= ws)
     int                 M, H, Hl, Il, nh, dh, rot, s_max, tp;
     RowsPlan            plan;

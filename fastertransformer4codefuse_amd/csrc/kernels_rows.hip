@@ -1,6 +1,7 @@
 // Host side of the persistent decode layers for 3..16 rows (rows_device.hip.h): the static plan, the hand-off region, the launch.
 #include "rows_device.hip.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ftcf {
@@ -34,7 +35,15 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
         return pl;
     }
     // attention: the (row, head) pairs are dealt round robin, a pair stays inside its workgroup
-    pl.U = (M * nh + NB - 1) / NB;
+    {
+        const int full = M * nh / NB, rem = M * nh % NB;
+        pl.FX = rem > 0 ? std::max(1, std::min(NB / rem, 8)) : 1;
+        static const int fx_env = getenv("FTCF_ROWS_FX") ? atoi(getenv("FTCF_ROWS_FX")) : 0;
+        if (fx_env >= 1 && rem > 0 && rem * fx_env <= NB) {
+            pl.FX = fx_env;
+        }
+        pl.U = full + (rem > 0 ? 1 : 0);
+    }
     if (pl.U > RW_UMAX) {
         return pl;
     }
@@ -54,6 +63,29 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
         }
         pl.cw = H / pl.CR;
     }
+    // K shares of the streamer waves (FTCF_ROWS_WS=a,b,c,d,e,f,g: relative weights)
+    {
+        int         w[RW_NS] = {16, 16, 16, 16, 16, 16, 16};
+        const char* e        = getenv("FTCF_ROWS_WS");
+        if (e) {
+            int v[RW_NS];
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == RW_NS) {
+                bool good = true;
+                for (int i = 0; i < RW_NS; i++) {
+                    good = good && v[i] >= 1 && v[i] <= 1024;
+                }
+                if (good) {
+                    for (int i = 0; i < RW_NS; i++) {
+                        w[i] = v[i];
+                    }
+                }
+            }
+        }
+        pl.wcum[0] = 0;
+        for (int i = 0; i < RW_NS; i++) {
+            pl.wcum[i + 1] = pl.wcum[i] + w[i];
+        }
+    }
     pl.NB = NB;
     const int Hp = (H + 511) & ~511;
     pl.smem      = (size_t)4 * Hp * 2 + (size_t)2 * RW_NS * RW_G * 256 * 4 + (size_t)RW_UMAX * RW_NS * (dh + RW_PA) * 4
@@ -72,13 +104,13 @@ static size_t al256(size_t v)
 size_t rows_flag_bytes(const RowsPlan& pl, int M, int nh)
 {
     (void)nh;
-    // err | fq fm fc f2 f3 [NB each] | x' granules [2][M * CR] of 16 bytes
-    return al256(256 + (size_t)5 * pl.NB * 4) + al256((size_t)2 * M * pl.CR * 16);
+    // err | fq fm fc f2 f3 fa [NB each] | x' granules [2][M * CR] of 16 bytes
+    return al256(256 + (size_t)6 * pl.NB * 4) + al256((size_t)2 * M * pl.CR * 16);
 }
 size_t rows_workspace_bytes(const RowsPlan& pl, int M, int H, int Hl, int Il, int nh, int dh)
 {
-    (void)dh;
     size_t b = rows_flag_bytes(pl, M, nh);
+    b += al256((size_t)pl.NB * (dh + RW_PA) * 4);  // pa
     b += 2 * al256((size_t)M * H * 2);                                                            // xb
     b += al256((size_t)M * 3 * Hl * 2) + al256((size_t)M * Il * 2) + al256((size_t)M * Hl * 2);  // qkv, mid, ctx
     b += al256((size_t)pl.KP2 * M * H * 4) + al256((size_t)pl.KP3 * M * H * 4);                   // p2, p3
@@ -95,7 +127,8 @@ void rows_carve(RowsParams& p, void* workspace)
     p.o_fc             = (unsigned)(o + (size_t)2 * pl.NB * 4);
     p.o_f2             = (unsigned)(o + (size_t)3 * pl.NB * 4);
     p.o_f3             = (unsigned)(o + (size_t)4 * pl.NB * 4);
-    o                  = al256(256 + (size_t)5 * pl.NB * 4);
+    p.o_fa             = (unsigned)(o + (size_t)5 * pl.NB * 4);
+    o                  = al256(256 + (size_t)6 * pl.NB * 4);
     p.o_xs             = (unsigned)o;
     o += al256((size_t)2 * p.M * pl.CR * 16);
     p.o_xb[0] = (unsigned)o;
@@ -112,6 +145,8 @@ void rows_carve(RowsParams& p, void* workspace)
     o += al256((size_t)pl.KP2 * p.M * p.H * 4);
     p.o_p3 = (unsigned)o;
     o += al256((size_t)pl.KP3 * p.M * p.H * 4);
+    p.o_pa = (unsigned)o;
+    o += al256((size_t)pl.NB * (p.dh + RW_PA) * 4);
     p.ws_bytes = (unsigned)o;
 }
 

@@ -43,6 +43,22 @@ constexpr int RW_G      = 5;          // 16-column groups per k-step (compile-ti
 #define RW_KVR_ 4
 #endif
 constexpr int RW_R      = RW_R_;      // ring slots of a weight pass (three k-steps in flight while one is consumed)
+// ring slots of the QKV pass: its weights are requested at the layer boundary, while the pieces of x' travel and the HBM has nothing
+// else to do -- deep enough to take most of the wave's share (G1 = 4: 8 x 24 registers; G1 = 5: 6 x 28)
+#ifndef RW_RQ4_
+#define RW_RQ4_ 4
+#endif
+#ifndef RW_RQ5_
+#define RW_RQ5_ 4
+#endif
+#ifndef RW_RQA_
+#define RW_RQA_ 1
+#endif
+template<int G1>
+struct RwQ {
+    static constexpr int R  = G1 <= 4 ? RW_RQ4_ : RW_RQ5_;
+    static constexpr int RA = R / RW_RQA_;
+};
 constexpr int RW_KVB    = 4;          // K (and V) wave-loads per ring slot of the attention stream
 constexpr int RW_KVR    = RW_KVR_;    // its ring slots
 constexpr int RW_UMAX   = 4;          // (row, head) pairs of a workgroup at most
@@ -174,12 +190,12 @@ __host__ __device__ inline int rw_group_begin(const int w, const int NG, const i
 {
     return (int)((long)w * NG / NB);
 }
-// k-steps [kb, ke) of streamer wave s (0 .. RW_NS - 1) when a workgroup streams k-steps [K0, K1): contiguous shares
-__host__ __device__ inline void rw_wave_ksteps(const int K0, const int K1, const int s, int& kb, int& ke)
+// k-steps [kb, ke) of streamer wave s (0 .. RW_NS - 1) when a workgroup streams k-steps [K0, K1): contiguous shares, weighted
+__host__ __device__ inline void rw_wave_ksteps(const int K0, const int K1, const int s, const int (&wcum)[8], int& kb, int& ke)
 {
     const int n = K1 - K0;
-    kb          = K0 + (int)((long)n * s / RW_NS);
-    ke          = K0 + (int)((long)n * (s + 1) / RW_NS);
+    kb          = K0 + (int)(((long)n * wcum[s] + wcum[RW_NS] / 2) / wcum[RW_NS]);
+    ke          = K0 + (int)(((long)n * wcum[s + 1] + wcum[RW_NS] / 2) / wcum[RW_NS]);
 }
 __device__ __forceinline__ int rw_sel4(const int (&a)[RW_UMAX], const int i)
 {
@@ -239,12 +255,14 @@ struct RwSmem {
     int*   sync;   // [0] go, [1..2] partial sums written (per buffer), [3] attention partials written
 };
 
-// the ring of a weight pass: RW_R k-steps of up to RW_G weight tiles + the rows' A fragment (shared by the passes of a wave: a
+// the ring of a weight pass: R k-steps of G weight tiles + the rows' A fragment (shared by the passes of a wave: a
 // pass's first ring is requested while the previous pass's sums are still on their way out)
-template<bool INT8>
+// (RA <= R slots of A fragments: they come from L2 and are requested RA k-steps ahead, the weight tiles R k-steps ahead)
+template<bool INT8, int R, int RA, int G>
 struct RwRing {
-    u32x4 w[RW_R][RW_G];
-    u32x4 a[RW_R][RwK<INT8>::AV];
+    static_assert(R % RA == 0, "the A slots cycle inside the weight slots");
+    u32x4 w[R][G];
+    u32x4 a[RA][RwK<INT8>::AV];
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -253,11 +271,10 @@ struct RwRing {
 // [M][lda] halves at byte offset asoff behind `ar`.  LN: normalised on the fly with the row's statistics and gamma / beta from LDS.
 // bind_w / prime_w need nothing but the weights: they run BEFORE the wait for the pass's input.
 // ---------------------------------------------------------------------------------------------------------------
-template<bool INT8, int G, bool LN>
+template<bool INT8, int G, bool LN, int R = RW_R, int RA = R>
 struct RwPass {
     static constexpr int KS = RwK<INT8>::KS;
     static constexpr int AV = RwK<INT8>::AV;
-    using Ring              = RwRing<INT8>;
     f32x4                  acc[G];
     f16x2                  sc2[G];
     __amdgpu_buffer_rsrc_t wr;       // weight image (a descriptor: the per-lane part of an address is ONE 32-bit register per group)
@@ -302,6 +319,7 @@ struct RwPass {
             lb = beta + (lane >> 4) * (KS / 4);
         }
     }
+    template<class Ring>
     __device__ __forceinline__ void load_w(Ring& q, const int r, const int k)
     {
 #pragma unroll
@@ -309,6 +327,7 @@ struct RwPass {
             q.w[r][g] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)woff[g], k * TILE_BYTES, 2);  // (aux 2 = nt)
         }
     }
+    template<class Ring>
     __device__ __forceinline__ void load_a(Ring& q, const int r, const int k)
     {
 #pragma unroll
@@ -316,6 +335,7 @@ struct RwPass {
             q.a[r][v] = rw_ld16(ar, aoff + v * 16, asoff + k * KS * 2);
         }
     }
+    template<class Ring>
     __device__ __forceinline__ void kill_w(Ring& q, const int r)
     {
 #pragma unroll
@@ -323,6 +343,7 @@ struct RwPass {
             rw_kill(q.w[r][g]);
         }
     }
+    template<class Ring>
     __device__ __forceinline__ void kill_a(Ring& q, const int r)
     {
 #pragma unroll
@@ -330,10 +351,11 @@ struct RwPass {
             rw_kill(q.a[r][v]);
         }
     }
+    template<class Ring>
     __device__ __forceinline__ void consume(const Ring& q, const int r, const int k)
     {
-        f16x8 a0 = __builtin_bit_cast(f16x8, q.a[r][0]);
-        f16x8 a1 = __builtin_bit_cast(f16x8, q.a[r][AV - 1]);
+        f16x8 a0 = __builtin_bit_cast(f16x8, q.a[r % RA][0]);
+        f16x8 a1 = __builtin_bit_cast(f16x8, q.a[r % RA][AV - 1]);
         if constexpr (LN) {
             const f16x8* gp = reinterpret_cast<const f16x8*>(lg + k * KS);
             const f16x8* bp = reinterpret_cast<const f16x8*>(lb + k * KS);
@@ -345,14 +367,18 @@ struct RwPass {
 #pragma unroll
         for (int g = 0; g < G; g++) {
             rw_tile<INT8>(q.w[r][g], a0, a1, sc2[g], acc[g]);
+#ifdef RW_TILE_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
     // the weight tiles of the first ring.  A load is never a duplicate: the ring's conditions are uniform, and only the first ring
     // and the last two rotations of a pass carry them (inside the steady rotations the compiler counts vmcnt exactly)
+    template<class Ring>
     __device__ __forceinline__ void prime_w(Ring& q)
     {
 #pragma unroll
-        for (int r = 0; r < RW_R; r++) {
+        for (int r = 0; r < R; r++) {
             if (r < n) {
                 load_w(q, r, kb + r);
             }
@@ -362,10 +388,11 @@ struct RwPass {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    template<class Ring>
     __device__ __forceinline__ void prime_a(Ring& q)
     {
 #pragma unroll
-        for (int r = 0; r < RW_R; r++) {
+        for (int r = 0; r < RA; r++) {
             if (r < n) {
                 load_a(q, r, kb + r);
             }
@@ -376,45 +403,60 @@ struct RwPass {
         __builtin_amdgcn_sched_barrier(0);
     }
     // streams the pass (its first ring has been requested): a slot is re-requested as soon as it has been consumed
+    template<class Ring>
     __device__ __forceinline__ void run(Ring& q)
     {
         if (n <= 0) {
             return;
         }
-        const int nrot = (n + RW_R - 1) / RW_R;
+        const int nrot = (n + R - 1) / R;
         for (int it = 0; it < nrot - 2; it++) {  // every re-request of these rotations is a k-step of the pass
 #pragma unroll
-            for (int r = 0; r < RW_R; r++) {
-                const int i = it * RW_R + r;
+            for (int r = 0; r < R; r++) {
+                const int i = it * R + r;
                 consume(q, r, kb + i);
                 __builtin_amdgcn_sched_barrier(0);
-                load_w(q, r, kb + i + RW_R);
-                load_a(q, r, kb + i + RW_R);
+                load_w(q, r, kb + i + R);
+                load_a(q, r % RA, kb + i + RA);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (nrot >= 2) {
 #pragma unroll
-            for (int r = 0; r < RW_R; r++) {
-                const int i = (nrot - 2) * RW_R + r;
+            for (int r = 0; r < R; r++) {
+                const int i = (nrot - 2) * R + r;
                 consume(q, r, kb + i);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i + RW_R < n) {
-                    load_w(q, r, kb + i + RW_R);
-                    load_a(q, r, kb + i + RW_R);
+                if (i + R < n) {
+                    load_w(q, r, kb + i + R);
                 }
                 else {
                     kill_w(q, r);
-                    kill_a(q, r);
+                }
+                if (i + RA < n) {
+                    load_a(q, r % RA, kb + i + RA);
+                }
+                else {
+                    kill_a(q, r % RA);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const int last = (nrot - 1) * RW_R;
+        const int last = (nrot - 1) * R;
 #pragma unroll
-        for (int r = 0; r < RW_R; r++) {
+        for (int r = 0; r < R; r++) {
             if (last + r < n) {
                 consume(q, r, kb + last + r);
+            }
+            if constexpr (RA < R) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (last + r + RA < n) {
+                    load_a(q, r % RA, kb + last + r + RA);
+                }
+                else {
+                    kill_a(q, r % RA);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -490,7 +532,7 @@ struct RwAt {
     int  nst[RW_UMAX];  // blocks of this wave per unit
     int  U, T;          // units of the workgroup, blocks of this wave over all of them
     int  lu, ls;        // loader cursor (unit, block of the unit)
-    int  l_tl, l_b, l_h;
+    int  l_tl, l_b, l_h, l_X, l_x;
     int  s, sub, grp;
     __amdgpu_buffer_rsrc_t rk, rv;  // the layer's K / V cache (non-paged)
 
@@ -512,9 +554,13 @@ struct RwAt {
         T = 0;
 #pragma unroll
         for (int u = 0; u < RW_UMAX; u++) {
+            // part x of X of the unit's blocks (blocks j = x, x + X, ...), dealt round robin to the streamer waves
             const int tl   = u < U ? rw_rfl(unit[u * 8]) : 0;
+            const int X    = u < U ? rw_rfl(unit[u * 8 + 5]) : 1;
+            const int x    = u < U ? rw_rfl(unit[u * 8 + 6]) : 0;
             const int nblk = tl > 0 ? (tl + KB - 1) / KB : 0;
-            nst[u]         = nblk > s ? (nblk - s + RW_NS - 1) / RW_NS : 0;
+            const int nbp  = nblk > x ? (nblk - x + X - 1) / X : 0;
+            nst[u]         = nbp > s ? (nbp - s + RW_NS - 1) / RW_NS : 0;
             T += nst[u];
         }
     }
@@ -523,12 +569,14 @@ struct RwAt {
         l_tl = rw_rfl(unit[lu * 8]);
         l_b  = rw_rfl(unit[lu * 8 + 1]);
         l_h  = rw_rfl(unit[lu * 8 + 2]);
+        l_X  = rw_rfl(unit[lu * 8 + 5]);
+        l_x  = rw_rfl(unit[lu * 8 + 6]);
     }
     // (non-paged: the layer's caches behind two descriptors, a unit's rows at a uniform byte offset; rows_plan() keeps a layer's
     //  cache below 4 GB)
     __device__ __forceinline__ void load(const RowsParams& p, const PersistLayer& lw, Slot& q)
     {
-        const int j = s + RW_NS * ls;
+        const int j = l_x + l_X * (s + RW_NS * ls);
         if constexpr (PAGED) {
 #pragma unroll
             for (int i = 0; i < RW_KVB; i++) {
@@ -692,7 +740,7 @@ struct RwAt {
         for (int e = 0; e < 8; e++) {
             o[e] = 0.f;
         }
-        int cu = 0, cs = 0, c_tl = 0, c_in = 0;
+        int cu = 0, cs = 0, c_tl = 0, c_in = 0, c_X = 1, c_x = 0;
         auto qk = [&](const f16x8 q8, const f16x8 kv) {
             float a = 0.f;
             a       = dot2(f16x2{q8[0], q8[1]}, f16x2{kv[0], kv[1]}, a);
@@ -704,6 +752,8 @@ struct RwAt {
         auto enter = [&]() {  // the consumer's unit -> its parameters
             c_tl = rw_rfl(unit[cu * 8]);
             c_in = rw_rfl(unit[cu * 8 + 3]);
+            c_X  = rw_rfl(unit[cu * 8 + 5]);
+            c_x  = rw_rfl(unit[cu * 8 + 6]);
         };
         // closes unit cu: the new token (first streamer, from LDS; :1407-1437), the key groups merged, the partial out
         auto finish = [&]() {
@@ -752,7 +802,7 @@ struct RwAt {
         };
         auto use = [&](const Slot& q) {
             const f16x8 q8 = *reinterpret_cast<const f16x8*>(aw + cu * 2 * DH + sub * 8);
-            const int   j  = s + RW_NS * cs;
+            const int   j  = c_x + c_X * (s + RW_NS * cs);
             float       sc[RW_KVB];
             float       mx = m;
 #pragma unroll
@@ -902,9 +952,13 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
     const int  k2a = (int)((long)KT2 * kp2 / KP2), k2b = has2 ? (int)((long)KT2 * (kp2 + 1) / KP2) : k2a;
     const int  k3a = (int)((long)KT3 * kp3 / KP3), k3b = has3 ? (int)((long)KT3 * (kp3 + 1) / KP3) : k3a;
     // attention: the (row, head) pairs wg, wg + NB, ... of this workgroup
-    const int npairs = M * p.nh;
-    const int U      = wg < npairs ? (npairs - wg + NB - 1) / NB : 0;
-    const int npw    = npairs < NB ? npairs : NB;  // workgroups that own pairs
+    // attention: `ufull` whole (row, head) pairs per workgroup (pair = wg + u * NB); each of the `rem` leftover pairs is shared by FX
+    // workgroups (part x takes its key blocks x, x + FX, ...; part 0 merges the parts and owns the pair's context)
+    const int  npairs = M * p.nh;
+    const int  ufull = npairs / NB, rem = npairs - ufull * NB, FX = p.plan.FX;
+    const bool has_frac = wg < rem * FX;
+    const int  U   = ufull + (has_frac ? 1 : 0);
+    const int  npw = ufull > 0 ? NB : rem * FX;  // workgroups that own units
 
     const __amdgpu_buffer_rsrc_t r_ws = rw_rsrc(p.ws, p.ws_bytes), r_xin = rw_rsrc(p.x_in, (size_t)M * H * 2);
 
@@ -937,15 +991,21 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             }
         }
         if (tx < RW_UMAX) {
-            const int  pair = wg + tx * NB;
+            // units of this workgroup: `ufull` whole pairs (pair = wg + u * NB), then -- on the first rem * X workgroups -- part
+            // wg % X of leftover pair ufull * NB + wg / X
+            const bool frac = tx == ufull && has_frac;
             const bool on   = tx < U;
+            const int  pair = frac ? ufull * NB + wg / FX : wg + tx * NB;
             const int  b = on ? pair / p.nh : 0, h = on ? pair - b * p.nh : 0;
-            const bool fin    = p.finished && p.finished[b];
+            const bool fin = p.finished && p.finished[b];
+            const int  X = frac ? FX : 1, x = frac ? wg % FX : 0;
             s.unit[tx * 8]     = on ? (fin ? 0 : p.seq_len[b]) : -1;  // cached keys; the new token goes to index seq_len
             s.unit[tx * 8 + 1] = b;
             s.unit[tx * 8 + 2] = h;
             s.unit[tx * 8 + 3] = p.input_lengths ? p.input_lengths[b] : 0x7fffffff;
-            s.unit[tx * 8 + 4] = (on && !fin) ? 1 : 0;
+            s.unit[tx * 8 + 4] = (on && !fin && x == 0) ? 1 : 0;  // the new token: part 0
+            s.unit[tx * 8 + 5] = X;
+            s.unit[tx * 8 + 6] = x;
         }
         if (tx >= 64 && tx < 72) {
             s.sync[tx - 64] = 0;
@@ -958,15 +1018,17 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
         // =========================================== streamer waves ===========================================
         const int sw = wid - 1;
         int       kb1, ke1, kb2, ke2, kb3, ke3;
-        rw_wave_ksteps(0, KT1, sw, kb1, ke1);
-        rw_wave_ksteps(k2a, k2b, sw, kb2, ke2);
-        rw_wave_ksteps(k3a, k3b, sw, kb3, ke3);
-        RwRing<INT8>      ring;
+        rw_wave_ksteps(0, KT1, sw, p.plan.wcum, kb1, ke1);
+        rw_wave_ksteps(k2a, k2b, sw, p.plan.wcum, kb2, ke2);
+        rw_wave_ksteps(k3a, k3b, sw, p.plan.wcum, kb3, ke3);
+        // ONE ring object for every pass of the wave (the QKV pass uses RwQ<G1>::R slots of G1 tiles, the others RW_R slots of
+        // RW_G; what a pass does not use is never defined and costs no register)
+        RwRing<INT8, (RwQ<G1>::R > RW_R ? RwQ<G1>::R : RW_R), RW_R, RW_G> ring;
         RwAt<DH, PAGED>   at;
         f16*              aw = s.att + (size_t)wid * RW_UMAX * 2 * DH;
         f16*              vw = s.att;  // (wave 0 does not stream: its region holds v of the first streamer)
         at.setup(s.unit, U, sw);
-        RwPass<INT8, G1, true> pq;
+        RwPass<INT8, G1, true, RwQ<G1>::R, RwQ<G1>::RA> pq;
         {
             const PersistLayer& lw = p.layers[p.l_begin];
             pq.bind_w(lw.w_qkv, KT1, NGq, q0, nq, lw.s_qkv, lane, kb1, ke1);
@@ -1178,17 +1240,18 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
         if (U > 0) {
             constexpr int LPK = DH / 8;
             const int     u = lane / LPK, sub = lane % LPK;
-            if (u < U) {
+            const bool    mine = u < U;
+            const bool    fr = mine && has_frac && u == ufull;  // the lanes of the shared pair's part
+            float         mx = -INFINITY, L = 0.f, o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                o[e] = 0.f;
+            }
+            if (mine) {
                 const float* pa = s.apart + (size_t)u * RW_NS * (DH + RW_PA);
-                float        mx = -INFINITY;
 #pragma unroll
                 for (int w = 0; w < RW_NS; w++) {
                     mx = fmaxf(mx, pa[w * (DH + RW_PA) + DH]);
-                }
-                float L = 0.f, o[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    o[e] = 0.f;
                 }
 #pragma unroll
                 for (int w = 0; w < RW_NS; w++) {
@@ -1203,6 +1266,48 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
                         o[4 + e] += ww * c[e];
                     }
                 }
+            }
+            const int  fslot = wg;  // (has_frac: leftover pair wg / FX, part wg % FX -- the slots of one pair are neighbours)
+            const int  po    = fslot * (DH + RW_PA) * 4;
+            const bool guest = has_frac && FX > 1 && wg % FX != 0;  // a part that is not the pair's owner
+            const bool owner = has_frac && FX > 1 && wg % FX == 0;
+            if (guest) {
+                // its merged {out, max, sum} travels to part 0
+                if (fr) {
+                    rw_st16(__builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]}), r_ws, po + sub * 32, (int)p.o_pa);
+                    rw_st16(__builtin_bit_cast(u32x4, f32x4{o[4], o[5], o[6], o[7]}), r_ws, po + sub * 32 + 16, (int)p.o_pa);
+                    if (sub == 0) {
+                        rw_st16(__builtin_bit_cast(u32x4, f32x4{mx, L, 0.f, 0.f}), r_ws, po + DH * 4, (int)p.o_pa);
+                    }
+                }
+                rw_drain();
+                if (lane == 0) {
+                    rw_st4(tag, r_ws, fslot * 4, (int)p.o_fa);
+                }
+            }
+            if (owner) {
+                // the other parts in part order (they publish without waiting for anybody)
+                rw_poll(r_ws, (int)p.o_fa + (fslot + 1) * 4, FX - 1, tag, lane, p.err, 4);
+                for (int x = 1; x < FX; x++) {
+                    const int   qo = (fslot + x) * (DH + RW_PA) * 4;
+                    const f32x4 a  = __builtin_bit_cast(f32x4, rw_ld16(r_ws, qo + sub * 32, (int)p.o_pa));
+                    const f32x4 c  = __builtin_bit_cast(f32x4, rw_ld16(r_ws, qo + sub * 32 + 16, (int)p.o_pa));
+                    const f32x4 ml = __builtin_bit_cast(f32x4, rw_ld16(r_ws, qo + DH * 4, (int)p.o_pa));
+                    if (fr) {
+                        const float mn = fmaxf(mx, ml[0]);
+                        const float wa = (mx == -INFINITY) ? 0.f : __expf(mx - mn);
+                        const float wb = (ml[0] == -INFINITY) ? 0.f : __expf(ml[0] - mn);
+                        L              = wa * L + wb * ml[1];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            o[e]     = wa * o[e] + wb * a[e];
+                            o[4 + e] = wa * o[4 + e] + wb * c[e];
+                        }
+                        mx = mn;
+                    }
+                }
+            }
+            if (mine && !(fr && guest)) {
                 const float inv = 1.f / (L + 1.e-6f);
                 f16         hv[8];
 #pragma unroll

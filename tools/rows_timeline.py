@@ -46,3 +46,22 @@ if L > 1:
     first[first <= 0] = np.inf
     tops = first.min(axis=(0, 2))
     print("layer period (first wave in to first wave in), us: median %.2f" % np.median(np.diff(tops)))
+# ---- who is late?  stamps relative to the layer's first wave, mean over layers 4..L-1 ----
+if L > 6:
+    sub = ts[:, 4:, :, :]
+    first = sub[:, :, :, 0].copy()
+    first[first <= 0] = np.inf
+    rel = sub - first.min(axis=(0, 2))[None, :, None, None]
+    print("streamer stamps by wave index (mean over workgroups and layers): " + " | ".join(
+        S[k] + " " + " ".join(f"{rel[:, :, w, k].mean():.1f}" for w in range(1, W)) for k in (2, 3, 5, 7, 9)))
+    for k in (2, 3, 5, 7, 9):
+        v = rel[:, :, 1:, k].max(axis=2).mean(axis=1)  # [NB]: the workgroup's last wave, mean over layers
+        a = rel[:, 0::2, 1:, k].max(axis=2).mean(axis=1)
+        b = rel[:, 1::2, 1:, k].max(axis=2).mean(axis=1)
+        print(f"{S[k]:<14} (wg's last wave): " + " ".join("xcd%d %5.1f" % (x, np.median(v[x::8])) for x in range(8))
+              + f" | p5 {np.percentile(v, 5):.1f} p95 {np.percentile(v, 95):.1f} | persistence {np.corrcoef(a, b)[0, 1]:.2f}"
+              + " | slowest wgs: " + " ".join(str(i) for i in np.argsort(v)[-8:]))
+    # per layer: the slowest workgroup's stamp minus the median workgroup's (what every hand-off waits for)
+    for k in (2, 3, 5, 7, 9):
+        m = rel[:, :, 1:, k].max(axis=2)  # [NB][layers]
+        print(f"{S[k]:<14} slowest wg - median wg per layer: mean {np.mean(m.max(axis=0) - np.median(m, axis=0)):.1f} us")

@@ -11,4 +11,4 @@ for v in ${VARIANTS:-1 0}; do
 done
 FTCF_PERSIST_TS=$O/rows_ts.bin timeout 300 python bench.py --batch 16 --prompt-len 256 --output-len 64 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-pmc > $O/bench_ts.json 2> $O/bench_ts.err
 python tools/rows_timeline.py $O/rows_ts.bin 20 | tee $O/timeline.txt
-rm -f $O/rows_ts.bin
+
