@@ -1024,7 +1024,24 @@ struct ftcf_batcher {
             FTCF_HIP_CHECK(hipMemcpyAsync(&gemm_err, reinterpret_cast<char*>(smallm_ws) + smallm_partial, sizeof(int),
                                           hipMemcpyDeviceToHost, st));
         }
+        // tensor parallel: the window all-reduce's sticky give-up word of this step's 2 L all-reduces (a peer that never arrived:
+        // x is partly reduced and the step's tokens are not to be trusted either), read with the same copies
+        int        ar_err  = 0;
+        const bool ar_live = e->cfg.tensor_para_size > 1 && e->cfg.comm && e->cfg.comm->ar_sync && e->cfg.comm->ar_seq > 0
+                             && !e->cfg.comm->ar_failed;
+        if (ar_live) {
+            FTCF_HIP_CHECK(hipMemcpyAsync(&ar_err, e->cfg.comm->ar_sync + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+        }
         FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        if (ar_live && e->tp_scratch) {
+            // (collective: every rank's batcher runs the same step and has called the window all-reduce as often; all of them learn
+            //  of any rank's failure and drop the step)
+            ar_err = comm_max(e->cfg.comm, ar_err, st, e->tp_scratch);
+            if (ar_err != 0) {
+                e->cfg.comm->ar_failed = true;  // this communicator keeps RCCL (or the emulation) from now on
+                throw Error(-2, "batcher decode: the exchange-window all-reduce gave up waiting for a peer; the step's tokens are dropped");
+            }
+        }
         if (gemm_err != 0) {
             // the tokens of this step are not to be trusted: nothing is reported, the slots keep their state (lengths and
             // draw counters advanced on the device: the requests cannot be resumed exactly), the flag is cleared for the caller's

@@ -1045,6 +1045,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_ROWS")) {
             e->rows = atoi(m);
         }
+        if (const char* m = getenv("FTCF_ROWS_TP")) {
+            e->rows_tp = atoi(m);
+        }
         if (const char* m = getenv("FTCF_ROWS_NB")) {
             e->rows_nb = atoi(m);
         }

@@ -125,7 +125,7 @@ struct ftcf_gptneox {
     int*                tp_scratch = nullptr;  // device int for the barrier all-reduce of the tensor-parallel windows
     long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
     // persistent decode layers for 3..16 rows (kernels_rows.hip): on whenever the shape is eligible (FTCF_ROWS=0: general path)
-    int                 rows = 1, rows_nb = 0, rows_min = 3;
+    int                 rows = 1, rows_nb = 0, rows_min = 3, rows_tp = 0;
     RowsPlan            rplan{};
     char*               rows_ws = nullptr;
     long long*          rows_ts = nullptr;
@@ -302,12 +302,15 @@ struct ftcf_gptneox {
                 ps_lm_fused = lm_env != 0 && tpn == 1 && H % 512 == 0;
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
-            // 3..16 rows (and what the one- / two-row kernel does not take): the rows kernel, one launch per token; with tensor
-            // parallelism one launch per layer, the all-reduce of x' between them
+            // 3..16 rows (and what the one- / two-row kernel does not take): the rows kernel, one launch per token.  With tensor
+            // parallelism it would be one launch per layer and the all-reduce of x' between them: a rank's shard of a layer is a few
+            // microseconds of HBM time behind five in-kernel hand-offs, and the paired launches of the general path are faster
+            // (one rank's shard of TP 8 at bs 16: 2.67 against 1.69 ms per step) -- so only with FTCF_ROWS_TP=1
             rplan = RowsPlan{};
             rows_ws = nullptr;
             rows_ts = nullptr;
-            if (rows && !pplan.ok && !fp32 && K == 1 && B >= rows_min && B <= 16 && cfg.use_gptj_residual && L <= 255) {
+            if (rows && (cfg.tensor_para_size == 1 || rows_tp) && !pplan.ok && !fp32 && K == 1 && B >= rows_min && B <= 16
+                && cfg.use_gptj_residual && L <= 255) {
                 // (ranks that share ONE device -- a local group's threads, the two-process tests -- must be resident together)
                 int nb = rows_nb > 0 ? rows_nb : persist_nb;
                 if (tp_local) {

@@ -37,7 +37,12 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
     // attention: the (row, head) pairs are dealt round robin, a pair stays inside its workgroup
     {
         const int full = M * nh / NB, rem = M * nh % NB;
-        pl.FX = rem > 0 ? std::max(1, std::min(NB / rem, 8)) : 1;
+        // a leftover pair is shared by FX workgroups only when EVERY pair is a leftover pair (fewer pairs than workgroups: small
+        // batches, tensor-parallel shards): then all pairs have the same reduction tree.  With whole pairs next to shared ones
+        // (bs 16 at 40 heads: 2.5 pairs per workgroup) the shared pairs' tree would differ from the whole pairs' and identical
+        // rows of a batch would stop being bit-identical; sharing them anyway (FTCF_ROWS_FX=2) balances the attention stream
+        // and was measured neutral on the step
+        pl.FX = (rem > 0 && full == 0) ? std::max(1, std::min(NB / rem, 8)) : 1;
         static const int fx_env = getenv("FTCF_ROWS_FX") ? atoi(getenv("FTCF_ROWS_FX")) : 0;
         if (fx_env >= 1 && rem > 0 && rem * fx_env <= NB) {
             pl.FX = fx_env;

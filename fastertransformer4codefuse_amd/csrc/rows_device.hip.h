@@ -59,14 +59,6 @@ struct RwQ {
     static constexpr int R  = G1 <= 4 ? RW_RQ4_ : RW_RQ5_;
     static constexpr int RA = R / RW_RQA_;
 };
-// k-steps of the QKV pass a streamer wave stages in LDS at the layer boundary (LDS-DMA into its own slices of the partial-sum
-// buffers and its q | k staging area, all idle then): together with the ring they hold most of the wave's share before x' is complete
-template<int G1, int DH>
-struct RwStage {
-    static constexpr int NL    = (G1 <= 4 && DH >= 128) ? 3 : 2;
-    static constexpr int TILES = NL * G1;
-    static_assert(TILES <= 2 * RW_G + (DH >= 128 ? 2 : 1), "staged tiles of a wave: two partial-sum slices + its q | k area");
-};
 constexpr int RW_KVB    = 4;          // K (and V) wave-loads per ring slot of the attention stream
 constexpr int RW_KVR    = RW_KVR_;    // its ring slots
 constexpr int RW_UMAX   = 4;          // (row, head) pairs of a workgroup at most
@@ -260,7 +252,7 @@ struct RwSmem {
     float* stat;   // [16][2] mean, rstd of the layer input's rows
     float* scr;    // [512] scratch of the control wave
     int*   unit;   // [UMAX][8] {cached keys (-1: no such pair), row, head, input length, current token attended, -, -, -}
-    int*   sync;   // [0] go, [1..2] partial sums written (per buffer), [3] attention partials written, [4] ... read out (FFN2, OUT)
+    int*   sync;   // [0] go, [1..2] partial sums written (per buffer), [3] attention partials written
 };
 
 // the ring of a weight pass: R k-steps of G weight tiles + the rows' A fragment (shared by the passes of a wave: a
@@ -286,7 +278,6 @@ struct RwPass {
     f32x4                  acc[G];
     f16x2                  sc2[G];
     __amdgpu_buffer_rsrc_t wr;       // weight image (a descriptor: the per-lane part of an address is ONE 32-bit register per group)
-    const char*            wbase;    // ... and as a pointer (LDS-DMA requests)
     unsigned               woff[G];  // byte offset of this lane's 16 bytes of group g's tile at k-step 0
     __amdgpu_buffer_rsrc_t ar;
     int                    aoff;   // byte offset of this lane's fragment at k-step 0
@@ -298,9 +289,8 @@ struct RwPass {
     __device__ __forceinline__ void bind_w(const void* w, const int KT, const int NG, const int g0, const int ng, const f16* scale,
                                            const int lane, const int kb_, const int ke_)
     {
-        wr    = rw_rsrc(w, (size_t)NG * KT * TILE_BYTES);
-        wbase = reinterpret_cast<const char*>(w);
-        kb    = kb_;
+        wr = rw_rsrc(w, (size_t)NG * KT * TILE_BYTES);
+        kb = kb_;
         n  = ng > 0 ? ke_ - kb_ : 0;
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -471,96 +461,6 @@ struct RwPass {
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- the pass with NL k-steps staged in LDS (the QKV pass): steps [0, R) come from the ring (requested at the boundary),
-    //      steps [R, R + nl) from LDS, the rest streams through the ring.  st(q): LDS address of staged tile q = step * G + group. ----
-    __device__ __forceinline__ int staged(const int NL) const
-    {
-        const int m = n - R;
-        return m < 0 ? 0 : (m < NL ? m : NL);
-    }
-    // requests the staged tiles (no registers; counts on vmcnt; the compiler does not know)
-    template<int NL, class ST>
-    __device__ __forceinline__ void stage_w(ST&& st)
-    {
-        const int nl = staged(NL);
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            if (j < nl) {
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    rw_lds_dma16(wbase + woff[g] + (size_t)(kb + R + j) * TILE_BYTES,
-                                 (unsigned)rw_rfl((int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)st(j * G + g)));
-                }
-            }
-        }
-    }
-    template<int NL, class Ring, class ST>
-    __device__ __forceinline__ void run_staged(Ring& q, ST&& st, const int lane, const bool on)
-    {
-        if (n <= 0) {
-            return;
-        }
-        const int nl = on ? staged(NL) : 0;  // (the first layer of a launch has nothing staged)
-        // A fragments of the staged steps (the ring's A slots belong to the streamed steps)
-        u32x4 as[NL][AV];
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-#pragma unroll
-            for (int v = 0; v < AV; v++) {
-                if (j < nl) {
-                    as[j][v] = rw_ld16(ar, aoff + v * 16, asoff + (kb + R + j) * KS * 2);
-                }
-                else {
-                    rw_kill(as[j][v]);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the ring's steps; a slot is re-requested with the step behind the staged ones
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (r < n) {
-                consume(q, r, kb + r);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (R + nl + r < n) {
-                load_w(q, r, kb + R + nl + r);
-                load_a(q, r % RA, kb + R + nl + r);
-            }
-            else {
-                kill_w(q, r);
-                kill_a(q, r % RA);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // (the first consume above waited for this wave's oldest loads: its LDS-DMA requests, older still, have landed)
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            if (j < nl) {
-                f16x8 a0 = __builtin_bit_cast(f16x8, as[j][0]);
-                f16x8 a1 = __builtin_bit_cast(f16x8, as[j][AV - 1]);
-                if constexpr (LN) {
-                    const f16x8* gp = reinterpret_cast<const f16x8*>(lg + (kb + R + j) * KS);
-                    const f16x8* bp = reinterpret_cast<const f16x8*>(lb + (kb + R + j) * KS);
-                    a0              = rw_ln8(a0, mh, rh, gp[0], bp[0]);
-                    if constexpr (AV == 2) {
-                        a1 = rw_ln8(a1, mh, rh, gp[1], bp[1]);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const u32x4 w = *reinterpret_cast<const u32x4*>(st(j * G + g) + lane * 16);
-                    rw_tile<INT8>(w, a0, a1, sc2[g], acc[g]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the rest is a pass of its own whose first ring has been requested
-        kb += R + nl;
-        n = n - R - nl;
-        run(q);
-    }
     // the wave's partial sums -> part[s][g][j][lane] (j = accumulator register: row 4 (lane >> 4) + j, column lane & 15)
     __device__ __forceinline__ void dump(float* part, const int s, const int lane) const
     {
@@ -646,7 +546,10 @@ struct RwAt {
             rv                 = rw_rsrc(lw.v_cache, bytes);
         }
     }
-    // per kernel: the wave's share of every unit (the unit table is complete)
+    // per kernel: the wave's share of every unit (the unit table is complete).  Block i of a unit's part goes to wave i % NS whatever
+    // the unit's place in the workgroup: the reduction tree of a (row, head) pair -- blocks in order inside a wave, waves in order,
+    // parts in order -- does not depend on where the pair lands, so identical rows of a batch give bit-identical results (dealing
+    // the workgroup's blocks as one round-robin sequence balances the waves a little better and was measured neutral)
     __device__ __forceinline__ void setup(const int* unit, const int U_, const int s_)
     {
         U = U_;
@@ -654,7 +557,7 @@ struct RwAt {
         T = 0;
 #pragma unroll
         for (int u = 0; u < RW_UMAX; u++) {
-            // part x of X of the unit's blocks (blocks j = x, x + X, ...), dealt round robin to the streamer waves
+            // part x of X of the unit's blocks (blocks j = x, x + X, ...)
             const int tl   = u < U ? rw_rfl(unit[u * 8]) : 0;
             const int X    = u < U ? rw_rfl(unit[u * 8 + 5]) : 1;
             const int x    = u < U ? rw_rfl(unit[u * 8 + 6]) : 0;
@@ -1128,13 +1031,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
         f16*              aw = s.att + (size_t)wid * RW_UMAX * 2 * DH;
         f16*              vw = s.att;  // (wave 0 does not stream: its region holds v of the first streamer)
         at.setup(s.unit, U, sw);
-        // LDS byte address of staged tile q of this wave: its slice of partial-sum buffer 0, then of buffer 1, then its q | k area
-        char* const st0 = reinterpret_cast<char*>(part_of(0) + (size_t)sw * RW_G * 256);
-        char* const st1 = reinterpret_cast<char*>(part_of(1) + (size_t)sw * RW_G * 256);
-        char* const st2 = reinterpret_cast<char*>(aw);
-        auto st_addr = [&](const int q) -> char* {
-            return q < RW_G ? st0 + q * 1024 : (q < 2 * RW_G ? st1 + (q - RW_G) * 1024 : st2 + (q - 2 * RW_G) * 1024);
-        };
         RwPass<INT8, G1, true, RwQ<G1>::R, RwQ<G1>::RA> pq;
         {
             const PersistLayer& lw = p.layers[p.l_begin];
@@ -1158,7 +1054,7 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             // ---- QKV ----
             pq.bind_a(r_x, xso, H * 2, M, ln, s.stat, s.gb, s.gb + Hp);
             pq.prime_a(ring);
-            pq.template run_staged<RwStage<G1, DH>::NL>(ring, st_addr, ln, li > 0);
+            pq.run(ring);
             RwPass<INT8, RW_G, true> pf;
             pf.bind_w(lw.w_ffn1, KT1, NGf, f0, nf, lw.s_ffn1, ln, kb1, ke1);
             pf.prime_w(ring);
@@ -1214,12 +1110,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             p3.dump(part_of(1), sw, ln);
             rw_lds_bump(&s.sync[2], ln);
             stamp(l, 9);
-            if (!last) {
-                // the next QKV pass's staged k-steps: into this wave's own slices of the partial-sum buffers and its q | k area,
-                // once the control wave has read this layer's sums out of them
-                rw_lds_wait(&s.sync[4], 2 * li + 2, p.err, 14);
-                pq.template stage_w<RwStage<G1, DH>::NL>(st_addr);
-            }
         }
         return;
     }
@@ -1449,7 +1339,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
                 rw_st16(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), r_ws, o + 16, (int)p.o_p2);
             });
         }
-        rw_lds_bump(&s.sync[4], lane);  // (buffer 0 has been read out: the streamers may stage the next QKV pass's tiles in it)
         if (has2) {
             rw_drain();
             if (lane == 0) {
@@ -1466,7 +1355,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
                 rw_st16(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), r_ws, o + 16, (int)p.o_p3);
             });
         }
-        rw_lds_bump(&s.sync[4], lane);  // (... and buffer 1)
         if (has3) {
             rw_drain();
             if (lane == 0) {

@@ -187,6 +187,7 @@ public:
                     "sequences)");
         const int  beam_width = beam_width_opt.has_value() ? (int)beam_width_opt.value() : 1;
         const int  B = (int)input_ids.size(0), S = (int)input_ids.size(1);
+        TORCH_CHECK(input_lengths.numel() == B, "input_lengths must hold one length per row of input_ids");
         const auto i32 = th::dtype(th::kInt32).device(input_ids.device()).requires_grad(false);
         th::Tensor output_ids       = th::empty({B, beam_width, S + output_len}, i32);
         th::Tensor sequence_lengths = th::empty({B, beam_width}, i32);
@@ -227,11 +228,16 @@ public:
         a.random_seed = static_cast<const uint64_t*>(p);
         if (stop_words_list_opt.has_value()) {
             check_input(stop_words_list_opt.value(), "stop_words_list", at::kInt);
+            TORCH_CHECK(stop_words_list_opt.value().dim() == 3 && stop_words_list_opt.value().size(0) == B
+                            && stop_words_list_opt.value().size(1) == 2,
+                        "stop_words_list must have shape [batch_size, 2, stop_words_length]");
             a.stop_words_list = stop_words_list_opt.value().data_ptr<int>();
             a.stop_words_len  = (int)stop_words_list_opt.value().size(2);
         }
         if (optional_last_tokens_opt.has_value()) {
             check_input(optional_last_tokens_opt.value(), "optional_last_tokens", at::kInt);
+            TORCH_CHECK(optional_last_tokens_opt.value().dim() == 2 && optional_last_tokens_opt.value().size(0) == B,
+                        "optional_last_tokens must have shape [batch_size, count]");
             a.optional_last_tokens       = optional_last_tokens_opt.value().data_ptr<int>();
             a.optional_last_tokens_count = (int)optional_last_tokens_opt.value().size(1);
         }

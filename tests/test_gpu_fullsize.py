@@ -158,19 +158,23 @@ def test_full_size_fp16_properties(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# BASELINE config 5's single-GPU regime: int8, bs=16, 256-in (general path: burst GEMMs, batched attention / LM head)
+# BASELINE config 5's single-GPU regime: int8, bs=16, 256-in -- the rows kernel (persistent layers for 3..16 rows, one launch per
+# token) and, with FTCF_ROWS=0, the general path (burst GEMMs, batched attention / LM head)
 # ---------------------------------------------------------------------------------------------------------------------
-def test_full_size_bs16_properties(full):
+@pytest.mark.parametrize("path", ["rows", "general"])
+def test_full_size_bs16_properties(full, monkeypatch, path):
     a = full[0]
     V, S, out = a.vocab, 256, 4
     g = torch.Generator().manual_seed(44)
     ids = torch.randint(3, V, (4, S), generator=g, dtype=torch.int32)
     ids16 = ids.repeat(4, 1).contiguous().cuda()  # rows r and r + 4k hold the same prompt
+    if path == "general":
+        monkeypatch.setenv("FTCF_ROWS", "0")
     op = _op(full)
     tb, lb = _run(op, ids16, out, V)
-    assert op.stats()["decode_path"] == 2
+    assert op.stats()["decode_path"] == (3 if path == "rows" else 2)
     tb2, lb2 = _run(op, ids16, out, V)
-    assert np.array_equal(tb, tb2) and np.array_equal(lb, lb2)  # deterministic (in-launch split-K merge is ordered)
+    assert np.array_equal(tb, tb2) and np.array_equal(lb, lb2)  # deterministic (every in-launch merge is ordered)
     for r in range(4):
         for k in range(1, 4):  # identical rows of one batch: bit-identical results
             assert np.array_equal(tb[r], tb[r + 4 * k]) and np.array_equal(lb[:, r], lb[:, r + 4 * k])
@@ -298,10 +302,17 @@ def test_13b_layer_shape_against_oracle(dtype, monkeypatch):
     assert op.stats()["decode_path"] == (1 if dtype == "int8" else 2)
     check(t2, l2, [0, 1], "two rows")
     ids16 = ids.repeat(8, 1).contiguous().cuda()
-    t16, l16 = _run(op, ids16, out, V)  # general path: burst GEMMs at m = 16
-    assert op.stats()["decode_path"] == 2
-    check(t16[:2], l16[:, :2], [0, 1], "general m=16")
+    t16, l16 = _run(op, ids16, out, V)  # the rows kernel at m = 16
+    assert op.stats()["decode_path"] == 3
+    check(t16[:2], l16[:, :2], [0, 1], "rows kernel m=16")
     del op
+    monkeypatch.setenv("FTCF_ROWS", "0")
+    opg = mk()
+    t16, l16 = _run(opg, ids16, out, V)  # general path: burst GEMMs at m = 16
+    assert opg.stats()["decode_path"] == 2
+    check(t16[:2], l16[:, :2], [0, 1], "general m=16")
+    del opg
+    monkeypatch.delenv("FTCF_ROWS")
     monkeypatch.setenv("FTCF_PERSIST", "0")
     op0 = mk()
     t0, l0 = _run(op0, ids[:1].cuda(), out, V)  # per-stage launches (the TP > 1 single-row path)
