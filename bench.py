@@ -369,6 +369,8 @@ def main():
         capi.check(L.ftcf_gptneox_finish(op._h))
         ps = op.stats()
         op.set_profiling(False)
+        if ps["decode_path"] == 3:  # (the launches of kind 4 were the rows kernel's)
+            KIND_NAMES[4] = "k_decode_rows (all layers of one token for 3..16 rows: weights + KV cache)"
         if ps["gemv_launches"] > 0:
             per_launch_bytes = ps["gemv_bytes"] / ps["gemv_launches"]
             avg_ms = ps["gemv_ms_sum"] / ps["gemv_launches"]
@@ -439,7 +441,8 @@ def main():
         # which decode path the timed steps took on rank 0 and how the per-layer all-reduce travelled (the driver's SCALE run
         # reads this to confirm that N ranks were up and whether the in-kernel xGMI exchange or the RCCL fallback ran)
         "tensor_parallel": {"ranks": world if a.fake_tp <= 1 else a.fake_tp, "backend": "rccl" if world > 1 else "none",
-                            "decode_path": {0: "per-stage launches", 1: "persistent kernel", 2: "general path"}.get(
+                            "decode_path": {0: "per-stage launches", 1: "persistent kernel", 2: "general path",
+                                            3: "rows kernel (persistent layers for 3..16 rows)"}.get(
                                 st["decode_path"], str(st["decode_path"])),
                             "layer_allreduce": ("none" if tp == 1 else
                                                 "in-kernel exchange windows (peer-mapped, xGMI stores)"

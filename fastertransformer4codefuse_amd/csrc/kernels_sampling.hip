@@ -290,6 +290,142 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* red, int& tot)
     return base + inc - v;
 }
 
+// a candidate {value, id} of a slice: plain stores, or write-through ones when the reader is a workgroup of the SAME launch
+template<bool WT>
+__device__ __forceinline__ void put_cand(float* ov, int* oi, const int pos, const float v, const int id)
+{
+    if constexpr (WT) {
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        __hip_atomic_store((gu32*)(ov + pos), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gu32*)(oi + pos), (unsigned)id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else {
+        ov[pos] = v;
+        oi[pos] = id;
+    }
+}
+// The `ke` (>= 2) best of the n elements of a slice as a SET -> ov / oi [0, ke): the block's threads hold element
+// threadIdx.x + 256 j in vals[j] (j < ne); l: the slice in memory (only read when more elements equal the threshold than there
+// are places; mask_end: element end_local reads as -FLT_MAX there, as it does in vals).  See k_topk_stage1.
+template<int MAXE, bool WT>
+__device__ __forceinline__ void slice_select(const float (&vals)[MAXE], const int ne, const int n, const int ke, const float* l,
+                                             const int i0, float* ov, int* oi, int (*hist8)[257], int* hist, int* s_sel, int* redi,
+                                             const bool mask_end, const int end_local)
+{
+    // ---- radix select: key of the ke-th largest element ----
+    unsigned prefix = 0u, mask = 0u;
+    int      need = ke;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            hist8[q][threadIdx.x] = 0;
+        }
+        __syncthreads();
+        // (eight private copies of the histogram, picked by lane: the sign / exponent bytes of a row's logits fall into a
+        // handful of bins)
+#pragma unroll
+        for (int j = 0; j < MAXE; j++) {
+            const unsigned key = fkey(vals[j]);
+            if (j < ne && (key & mask) == prefix) {
+                atomicAdd(&hist8[threadIdx.x & 7][(key >> shift) & 255u], 1);
+            }
+        }
+        __syncthreads();
+        {
+            int t = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                t += hist8[q][threadIdx.x];
+            }
+            hist[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // bins 4 * lane .. 4 * lane + 3; suffix sums from the top bin down
+            const int lane = threadIdx.x;
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int       above = mine;  // inclusive suffix over lanes >= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(above, o, 64);
+                if (lane + o < 64) {
+                    above += t;
+                }
+            }
+            above -= mine;  // elements in bins of higher lanes
+            // the lane whose bins contain the need-th element (counted from the top)
+            if (above < need && above + mine >= need) {
+                int acc = above;
+                int bin = 4 * lane + 3;
+                const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    if (acc + hh[q] >= need) {
+                        bin = 4 * lane + q;
+                        break;
+                    }
+                    acc += hh[q];
+                }
+                s_sel[0] = bin;
+                s_sel[1] = need - acc;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_sel[0] << shift;
+        mask |= 255u << shift;
+        need = s_sel[1];
+        __syncthreads();
+    }
+    // prefix = key of the ke-th largest; `need` of the elements equal to it belong to the set, (ke - need) are greater
+    if (threadIdx.x == 0) {
+        s_sel[2] = 0;
+    }
+    __syncthreads();
+    int ties = 0;
+#pragma unroll
+    for (int j = 0; j < MAXE; j++) {
+        if (j < ne) {
+            const unsigned key = fkey(vals[j]);
+            if (key > prefix) {
+                const int pos = atomicAdd(&s_sel[2], 1);
+                put_cand<WT>(ov, oi, pos, vals[j], i0 + (int)threadIdx.x + 256 * j);
+            }
+            else if (key == prefix) {
+                ties++;
+            }
+        }
+    }
+    int       tot  = 0;
+    int       rank = block_excl_scan(ties, redi, tot);
+    const int tie0 = ke - need;
+    if (tot == need) {  // every element equal to the threshold belongs to the set (the usual case: exactly one)
+#pragma unroll
+        for (int j = 0; j < MAXE; j++) {
+            if (j < ne && fkey(vals[j]) == prefix) {
+                put_cand<WT>(ov, oi, tie0 + rank, vals[j], i0 + (int)threadIdx.x + 256 * j);
+                rank++;
+            }
+        }
+        return;
+    }
+    // more equal elements than places: the ones with the lowest indices (the tie rule of `better`) -- index order needs a
+    // contiguous chunk per thread
+    const int per = (n + 255) / 256;
+    const int c0 = threadIdx.x * per, c1 = min(n, c0 + per);
+    ties = 0;
+    auto elem = [&](const int i) { return (mask_end && i == end_local) ? -FLT_MAX : l[i]; };
+    for (int i = c0; i < c1; i++) {
+        ties += fkey(elem(i)) == prefix ? 1 : 0;
+    }
+    rank = block_excl_scan(ties, redi, tot);
+    for (int i = c0; i < c1 && rank < need; i++) {
+        if (fkey(elem(i)) == prefix) {
+            put_cand<WT>(ov, oi, tie0 + rank, elem(i), i0 + i);
+            rank++;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, float* cand_v, int* cand_i, int slice)
 {
     if (p.state->all_finished) {
@@ -382,120 +518,7 @@ __global__ __launch_bounds__(256) void k_topk_stage1(const SamplingParams p, flo
         }
         return;
     }
-    // ---- radix select: key of the ke-th largest element ----
-    unsigned prefix = 0u, mask = 0u;
-    int      need = ke;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            hist8[q][threadIdx.x] = 0;
-        }
-        __syncthreads();
-        // (eight private copies of the histogram, picked by lane: the sign / exponent bytes of a row's logits fall into a
-        // handful of bins)
-#pragma unroll
-        for (int j = 0; j < STAGE1_MAXE; j++) {
-            const unsigned key = fkey(vals[j]);
-            if (j < ne && (key & mask) == prefix) {
-                atomicAdd(&hist8[threadIdx.x & 7][(key >> shift) & 255u], 1);
-            }
-        }
-        __syncthreads();
-        {
-            int t = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                t += hist8[q][threadIdx.x];
-            }
-            hist[threadIdx.x] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {  // bins 4 * lane .. 4 * lane + 3; suffix sums from the top bin down
-            const int lane = threadIdx.x;
-            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-            const int mine = h0 + h1 + h2 + h3;
-            int       above = mine;  // inclusive suffix over lanes >= lane
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_down(above, o, 64);
-                if (lane + o < 64) {
-                    above += t;
-                }
-            }
-            above -= mine;  // elements in bins of higher lanes
-            // the lane whose bins contain the need-th element (counted from the top)
-            if (above < need && above + mine >= need) {
-                int acc = above;
-                int bin = 4 * lane + 3;
-                const int hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-                for (int q = 3; q >= 0; q--) {
-                    if (acc + hh[q] >= need) {
-                        bin = 4 * lane + q;
-                        break;
-                    }
-                    acc += hh[q];
-                }
-                s_sel[0] = bin;
-                s_sel[1] = need - acc;
-            }
-        }
-        __syncthreads();
-        prefix |= (unsigned)s_sel[0] << shift;
-        mask |= 255u << shift;
-        need = s_sel[1];
-        __syncthreads();
-    }
-    // prefix = key of the ke-th largest; `need` of the elements equal to it belong to the set, (ke - need) are greater
-    if (threadIdx.x == 0) {
-        s_sel[2] = 0;
-    }
-    __syncthreads();
-    int ties = 0;
-#pragma unroll
-    for (int j = 0; j < STAGE1_MAXE; j++) {
-        if (j < ne) {
-            const unsigned key = fkey(vals[j]);
-            if (key > prefix) {
-                const int pos = atomicAdd(&s_sel[2], 1);
-                ov[pos]       = vals[j];
-                oi[pos]       = i0 + (int)threadIdx.x + 256 * j;
-            }
-            else if (key == prefix) {
-                ties++;
-            }
-        }
-    }
-    int       tot  = 0;
-    int       rank = block_excl_scan(ties, redi, tot);
-    const int tie0 = ke - need;
-    if (tot == need) {  // every element equal to the threshold belongs to the set (the usual case: exactly one)
-#pragma unroll
-        for (int j = 0; j < STAGE1_MAXE; j++) {
-            if (j < ne && fkey(vals[j]) == prefix) {
-                ov[tie0 + rank] = vals[j];
-                oi[tie0 + rank] = i0 + (int)threadIdx.x + 256 * j;
-                rank++;
-            }
-        }
-        return;
-    }
-    // more equal elements than places: the ones with the lowest indices (the tie rule of `better`) -- index order needs a
-    // contiguous chunk per thread
-    const int per = (n + 255) / 256;
-    const int c0 = threadIdx.x * per, c1 = min(n, c0 + per);
-    ties = 0;
-    for (int i = c0; i < c1; i++) {
-        ties += fkey(l[i]) == prefix ? 1 : 0;
-    }
-    rank = block_excl_scan(ties, redi, tot);
-    for (int i = c0; i < c1 && rank < need; i++) {
-        if (fkey(l[i]) == prefix) {
-            ov[tie0 + rank] = l[i];
-            oi[tie0 + rank] = i0 + i;
-            rank++;
-        }
-    }
+    slice_select<STAGE1_MAXE, false>(vals, ne, n, ke, l, i0, ov, oi, hist8, hist, s_sel, redi, false, -1);
 }
 
 // ---- step 3: merge + sample (one block per row) -----------------------------------------------------------------
@@ -581,6 +604,100 @@ __device__ __forceinline__ void bitonic_sort_global(float* v, int* id, const int
     __syncthreads();
 }
 
+// The kc best of the n2 candidates sv / si (LDS) -> sv / si [0, kc) sorted best first: radix select of the kc-th best (as stage 1,
+// over the LDS copy), the winners compacted into the k2 = 2^ceil(log2 kc) slots tv / ti, THOSE sorted (k = 50: 21 network stages
+// instead of 45 over 512 pairs)
+__device__ __forceinline__ void union_topk(float* sv, int* si, const int n2, const int kc, const int k2, float* tv, int* ti, int* hist,
+                                           int* s_sel, int* redi)
+{
+    __syncthreads();
+    unsigned prefix = 0u, mask = 0u;
+    int      need = kc;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int c = threadIdx.x; c < n2; c += 256) {
+            const unsigned key = fkey(sv[c]);
+            if ((key & mask) == prefix) {
+                atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const int mine = h0 + h1 + h2 + h3;
+            int       above = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(above, o, 64);
+                if (lane + o < 64) {
+                    above += t;
+                }
+            }
+            above -= mine;
+            if (above < need && above + mine >= need) {
+                int       acc = above, bin = 4 * lane + 3;
+                const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 3; q >= 0; q--) {
+                    if (acc + hh[q] >= need) {
+                        bin = 4 * lane + q;
+                        break;
+                    }
+                    acc += hh[q];
+                }
+                s_sel[0] = bin;
+                s_sel[1] = need - acc;
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_sel[0] << shift;
+        mask |= 255u << shift;
+        need = s_sel[1];
+        __syncthreads();
+    }
+    // `need` of the entries equal to the threshold belong to the set: the ones with the smallest ids (the rule of `better`)
+    if (threadIdx.x == 0) {
+        s_sel[2] = 0;
+    }
+    for (int c = threadIdx.x; c < k2; c += 256) {
+        tv[c] = -INFINITY;
+        ti[c] = 0x7fffffff;
+    }
+    __syncthreads();
+    // (the k-th best itself always equals the threshold: the usual case is exactly `need` such entries, all taken)
+    int nties = 0;
+    for (int c = threadIdx.x; c < n2; c += 256) {
+        nties += fkey(sv[c]) == prefix ? 1 : 0;
+    }
+    int       tie_total = 0;
+    (void)block_excl_scan(nties, redi, tie_total);
+    const bool all_ties = tie_total == need;
+    for (int c = threadIdx.x; c < n2; c += 256) {
+        const unsigned key = fkey(sv[c]);
+        bool           take = key > prefix || (all_ties && key == prefix);
+        if (!all_ties && key == prefix) {
+            int rank = 0;  // entries with the same value and a smaller id: real duplicates at the threshold, rare
+            for (int d = 0; d < n2; d++) {
+                rank += (fkey(sv[d]) == prefix && (si[d] < si[c] || (si[d] == si[c] && d < c))) ? 1 : 0;
+            }
+            take = rank < need;
+        }
+        if (take) {
+            const int pos = atomicAdd(&s_sel[2], 1);
+            tv[pos]       = sv[c];
+            ti[pos]       = si[c];
+        }
+    }
+    bitonic_sort_best_first(tv, ti, k2);
+    for (int c = threadIdx.x; c < kc; c += 256) {
+        sv[c] = tv[c];
+        si[c] = ti[c];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* cand_v, int* cand_i)
 {
     if (p.state->all_finished) {
@@ -635,94 +752,7 @@ __global__ __launch_bounds__(256) void k_sample(const SamplingParams p, float* c
             // instead of 45 over 512 pairs)
             __shared__ int hist[256];
             __shared__ int s_sel[4];
-            float*         tv = reinterpret_cast<float*>(si + n2);  // [k2]
-            int*           ti = reinterpret_cast<int*>(tv + k2);    // [k2]
-            __syncthreads();
-            unsigned prefix = 0u, mask = 0u;
-            int      need = kc;
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                hist[threadIdx.x] = 0;
-                __syncthreads();
-                for (int c = threadIdx.x; c < n2; c += 256) {
-                    const unsigned key = fkey(sv[c]);
-                    if ((key & mask) == prefix) {
-                        atomicAdd(&hist[(key >> shift) & 255u], 1);
-                    }
-                }
-                __syncthreads();
-                if (threadIdx.x < 64) {
-                    const int lane = threadIdx.x;
-                    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                    const int mine = h0 + h1 + h2 + h3;
-                    int       above = mine;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int t = __shfl_down(above, o, 64);
-                        if (lane + o < 64) {
-                            above += t;
-                        }
-                    }
-                    above -= mine;
-                    if (above < need && above + mine >= need) {
-                        int       acc = above, bin = 4 * lane + 3;
-                        const int hh[4] = {h0, h1, h2, h3};
-#pragma unroll
-                        for (int q = 3; q >= 0; q--) {
-                            if (acc + hh[q] >= need) {
-                                bin = 4 * lane + q;
-                                break;
-                            }
-                            acc += hh[q];
-                        }
-                        s_sel[0] = bin;
-                        s_sel[1] = need - acc;
-                    }
-                }
-                __syncthreads();
-                prefix |= (unsigned)s_sel[0] << shift;
-                mask |= 255u << shift;
-                need = s_sel[1];
-                __syncthreads();
-            }
-            // `need` of the entries equal to the threshold belong to the set: the ones with the smallest ids (the rule of `better`)
-            if (threadIdx.x == 0) {
-                s_sel[2] = 0;
-            }
-            for (int c = threadIdx.x; c < k2; c += 256) {
-                tv[c] = -INFINITY;
-                ti[c] = 0x7fffffff;
-            }
-            __syncthreads();
-            // (the k-th best itself always equals the threshold: the usual case is exactly `need` such entries, all taken)
-            int nties = 0;
-            for (int c = threadIdx.x; c < n2; c += 256) {
-                nties += fkey(sv[c]) == prefix ? 1 : 0;
-            }
-            int       tie_total = 0;
-            (void)block_excl_scan(nties, redi, tie_total);
-            const bool all_ties = tie_total == need;
-            for (int c = threadIdx.x; c < n2; c += 256) {
-                const unsigned key = fkey(sv[c]);
-                bool           take = key > prefix || (all_ties && key == prefix);
-                if (!all_ties && key == prefix) {
-                    int rank = 0;  // entries with the same value and a smaller id: real duplicates at the threshold, rare
-                    for (int d = 0; d < n2; d++) {
-                        rank += (fkey(sv[d]) == prefix && (si[d] < si[c] || (si[d] == si[c] && d < c))) ? 1 : 0;
-                    }
-                    take = rank < need;
-                }
-                if (take) {
-                    const int pos = atomicAdd(&s_sel[2], 1);
-                    tv[pos]       = sv[c];
-                    ti[pos]       = si[c];
-                }
-            }
-            bitonic_sort_best_first(tv, ti, k2);
-            for (int c = threadIdx.x; c < kc; c += 256) {
-                sv[c] = tv[c];
-                si[c] = ti[c];
-            }
-            __syncthreads();
+            union_topk(sv, si, n2, kc, k2, reinterpret_cast<float*>(si + n2), reinterpret_cast<int*>(si + n2) + k2, hist, s_sel, redi);
         }
         else if (kc > 1) {
             bitonic_sort_best_first(sv, si, n2);
@@ -1004,6 +1034,67 @@ __global__ void k_decode_finish(const SamplingParams p)
 // TAGGED: the partials are granules {tag, value} (part: [B][nsl][4] 8-byte words, the value in the low half) written by
 // workgroups that may still be running: a batch of partials is re-read until every tag is `tag` (bounded: a give-up sets
 // p.h_flags[2] and the step is finished on what is there).
+// The tail of a step behind the picks, by the workgroup (256 threads) that made them: the NEXT token's prologue (k_step_prologue:
+// decoding_kernels.cu:145-191 embedding lookup + the step's rotary table), the step's bookkeeping (decode_finish_body) and the
+// host flags.  s_ids: the tokens of rows 0..7 in LDS (the others are re-read from output_ids).
+__device__ __forceinline__ void decode_step_tail(const SamplingParams& p, const int step, const int steps_done, const int* s_ids,
+                                                 const bool by_wave)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
+    if (p.next_x && by_wave) {
+        // (many rows: one wave per row, a row's pieces requested together -- sixteen rows copied one after the other by the whole
+        // workgroup were sixteen dependent memory round trips, 30 us of this tail)
+        constexpr int NP = 8;  // 16-byte pieces per lane and pass: 8 KiB of a row
+        for (int row = wid; row < p.B; row += 4) {
+            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
+            const f16* src = p.wte + (size_t)id * p.H;
+            f16*       dst = p.next_x + (size_t)row * p.H;
+            for (int i0 = 0; i0 < p.H; i0 += 64 * 8 * NP) {
+                u32x4 v[NP];
+#pragma unroll
+                for (int u = 0; u < NP; u++) {
+                    const int i = i0 + (u * 64 + lane) * 8;
+                    v[u]        = i < p.H ? *reinterpret_cast<const u32x4*>(src + i) : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < NP; u++) {
+                    const int i = i0 + (u * 64 + lane) * 8;
+                    if (i < p.H) {
+                        *reinterpret_cast<u32x4*>(dst + i) = v[u];
+                    }
+                }
+            }
+        }
+    }
+    else if (p.next_x) {
+        // the next token's embedding rows: requested now, under the bookkeeping below
+        for (int row = 0; row < p.B; row++) {
+            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
+            const f16* src = p.wte + (size_t)id * p.H;
+            f16*       dst = p.next_x + (size_t)row * p.H;
+            for (int i = threadIdx.x * 8; i < p.H; i += blockDim.x * 8) {
+                *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
+            }
+        }
+    }
+    const int all = decode_finish_body<true>(p, step, steps_done);  // (thread 0's value is the one that is used)
+    if (p.next_x) {
+        __syncthreads();  // (the padding counts of this step: decode_finish_body)
+        const int nstep = step + 1;
+        for (int row = 0; row < p.B; row++) {
+            if ((int)threadIdx.x < p.rot / 2) {
+                const int pos = (nstep - 1) - (p.pad_count ? p.pad_count[row] : 0);
+                float     cs, sn;
+                rotary_coef(threadIdx.x, p.rot, pos, cs, sn);
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2]     = cs;
+                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2 + 1] = sn;
+            }
+        }
+    }
+    decode_publish_host(p, step, all);
+}
+
 constexpr int GREEDY_MAXQ = 4;  // partials of a row a thread requests together
 constexpr int GREEDY_SPINS = 1 << 20;
 template<bool TAGGED = false>
@@ -1210,58 +1301,7 @@ __device__ __forceinline__ void greedy_finish(const SamplingParams& p, const flo
             }
         }
     }
-    __syncthreads();  // (thread 0's updates are this workgroup's own: a workgroup-scope barrier orders them, no agent-scope fence)
-    if (p.next_x && by_wave) {
-        // (many rows: one wave per row, a row's pieces requested together -- sixteen rows copied one after the other by the whole
-        // workgroup were sixteen dependent memory round trips, 30 us of this tail)
-        constexpr int NP = 8;  // 16-byte pieces per lane and pass: 8 KiB of a row
-        for (int row = wid; row < p.B; row += 4) {
-            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
-            const f16* src = p.wte + (size_t)id * p.H;
-            f16*       dst = p.next_x + (size_t)row * p.H;
-            for (int i0 = 0; i0 < p.H; i0 += 64 * 8 * NP) {
-                u32x4 v[NP];
-#pragma unroll
-                for (int u = 0; u < NP; u++) {
-                    const int i = i0 + (u * 64 + lane) * 8;
-                    v[u]        = i < p.H ? *reinterpret_cast<const u32x4*>(src + i) : u32x4{0u, 0u, 0u, 0u};
-                }
-#pragma unroll
-                for (int u = 0; u < NP; u++) {
-                    const int i = i0 + (u * 64 + lane) * 8;
-                    if (i < p.H) {
-                        *reinterpret_cast<u32x4*>(dst + i) = v[u];
-                    }
-                }
-            }
-        }
-    }
-    else if (p.next_x) {
-        // the next token's embedding rows: requested now, under the bookkeeping below
-        for (int row = 0; row < p.B; row++) {
-            const int  id  = row < 8 ? s_ids[row] : p.output_ids[(size_t)step * p.B + row];
-            const f16* src = p.wte + (size_t)id * p.H;
-            f16*       dst = p.next_x + (size_t)row * p.H;
-            for (int i = threadIdx.x * 8; i < p.H; i += blockDim.x * 8) {
-                *reinterpret_cast<f16x8*>(dst + i) = *reinterpret_cast<const f16x8*>(src + i);
-            }
-        }
-    }
-    const int all = decode_finish_body<true>(p, step, steps_done);  // (thread 0's value is the one that is used)
-    if (p.next_x) {
-        __syncthreads();  // (the padding counts of this step: decode_finish_body)
-        const int nstep = step + 1;
-        for (int row = 0; row < p.B; row++) {
-            if ((int)threadIdx.x < p.rot / 2) {
-                const int pos = (nstep - 1) - (p.pad_count ? p.pad_count[row] : 0);
-                float     cs, sn;
-                rotary_coef(threadIdx.x, p.rot, pos, cs, sn);
-                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2]     = cs;
-                p.rot_table[((size_t)row * (p.rot / 2) + threadIdx.x) * 2 + 1] = sn;
-            }
-        }
-    }
-    decode_publish_host(p, step, all);
+    decode_step_tail(p, step, steps_done, s_ids, by_wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1365,6 +1405,259 @@ __global__ __launch_bounds__(256) void k_greedy_decode(const SamplingParams p, f
         return;
     }
     greedy_finish(p, part, GREEDY_SLICES, step0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole dynamic-decode step of a plain TOP-K batch in ONE launch (round 5): the reference harness's default request
+// (examples/pytorch/codefuse/codefuse_example.py:799-806: top_k = 50, top_p 0, temperature 1, no penalty) took k_decode_prep +
+// k_topk_stage1 + k_sample + k_decode_finish + the next token's k_step_prologue behind the LM head -- 61 us of a 2.7 ms token
+// where the all-greedy step takes 12.  Same structure as k_greedy_decode: 32 slices per row keep their logits in registers (min_length
+// mask, soft-max statistics for return_cum_log_probs, the radix select of the slice's k best: slice_select), write-through
+// candidates + a ticket, and the workgroup that draws the last ticket merges every row's 32 candidate sets (union_topk), turns
+// the k best into probabilities and draws exactly as k_sample does (sampling_topk_kernels.cu:210-311), then runs the step's tail
+// (decode_step_tail).  Rows: top_k in [1, 64], no top-p row, temperature 1, no repetition penalty, no optional-token list,
+// at most TKD_MAXB rows (the finishing workgroup takes them one after the other).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TKD_SLICES = 32;
+constexpr int TKD_MAXE   = 16;  // logits per thread: V <= 32 * 256 * 16 = 131072
+constexpr int TKD_MAXK   = 64;
+constexpr int TKD_MAXB   = 4;
+
+__global__ __launch_bounds__(256) void k_topk_decode(const SamplingParams p, float* ws)
+{
+    if (p.state->all_finished) {
+        return;
+    }
+    const int step0 = p.state->step;
+    __shared__ float redv[4];
+    __shared__ int   redi[4];
+    __shared__ int   hist[256];
+    __shared__ int   hist8[8][257];
+    __shared__ int   s_sel[4];
+    __shared__ int   s_last;
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    const int b = blockIdx.y, blk = blockIdx.x, V = p.V;
+    // candidates [B][SLICES][MAXK] values, then ids, then {max, sum of exponentials} per slice
+    float* cand_v = ws;
+    int*   cand_i = reinterpret_cast<int*>(ws + (size_t)p.B * TKD_SLICES * TKD_MAXK);
+    float* stats  = ws + (size_t)2 * p.B * TKD_SLICES * TKD_MAXK;
+    const int slice = (V + TKD_SLICES - 1) / TKD_SLICES;
+    if (!p.finished[b]) {
+        const int    k  = p.top_k[b];
+        const int    i0 = blk * slice;
+        const int    n  = max(0, min(slice, V - i0));
+        const float* l  = p.logits + (size_t)b * V + i0;
+        float*       ov = cand_v + ((size_t)b * TKD_SLICES + blk) * TKD_MAXK;
+        int*         oi = cand_i + ((size_t)b * TKD_SLICES + blk) * TKD_MAXK;
+        // min_length (sampling_penalty_kernels.cu:485-520): end_id cannot be chosen yet
+        const bool mask_end = p.min_length && (p.seq_len[b] + 1 - p.max_input_len < p.min_length[b]);
+        float      vals[TKD_MAXE];
+        const int  ne = n > (int)threadIdx.x ? (n - (int)threadIdx.x + 255) / 256 : 0;
+#pragma unroll
+        for (int j = 0; j < TKD_MAXE; j++) {
+            vals[j] = (j < ne) ? l[threadIdx.x + 256 * j] : -INFINITY;
+        }
+        VI    best{-INFINITY, 0x7fffffff};
+        float lmax = -FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < TKD_MAXE; j++) {
+            if (j < ne) {
+                const int i = threadIdx.x + 256 * j;
+                if (mask_end && i0 + i == p.end_id) {
+                    vals[j] = -FLT_MAX;
+                }
+                const float v = vals[j];
+                lmax          = fmaxf(lmax, v);
+                if (best.i == 0x7fffffff || better(v, i, best.v, best.i)) {
+                    best.v = v;
+                    best.i = i;
+                }
+            }
+        }
+        if (p.return_cum_log_probs) {  // soft-max statistics of the slice: {max, sum of exp(v - max)}
+            lmax = wave_max(lmax);
+            if ((threadIdx.x & 63) == 0) {
+                redv[threadIdx.x >> 6] = lmax;
+            }
+            __syncthreads();
+            const float m = fmaxf(fmaxf(redv[0], redv[1]), fmaxf(redv[2], redv[3]));
+            __syncthreads();
+            float se = 0.f;
+#pragma unroll
+            for (int j = 0; j < TKD_MAXE; j++) {
+                if (j < ne) {
+                    se += __expf(vals[j] - m);
+                }
+            }
+            se = wave_sum(se);
+            if ((threadIdx.x & 63) == 0) {
+                redv[threadIdx.x >> 6] = se;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                gu32* st = (gu32*)(stats + ((size_t)b * TKD_SLICES + blk) * 2);
+                __hip_atomic_store(st + 0, __float_as_uint(n > 0 ? m : -FLT_MAX), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(st + 1, __float_as_uint(n > 0 ? ((redv[0] + redv[1]) + (redv[2] + redv[3])) : 0.f), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        const int ke = k < n ? k : n;  // candidates this slice can supply
+        for (int i = ke + threadIdx.x; i < k; i += 256) {
+            put_cand<true>(ov, oi, i, -INFINITY, -1);
+        }
+        if (ke == 1) {
+            const VI r = block_best(best, redv, redi);
+            if (threadIdx.x == 0) {
+                put_cand<true>(ov, oi, 0, r.v, i0 + r.i);
+            }
+        }
+        else if (ke > 1) {
+            slice_select<TKD_MAXE, true>(vals, ne, n, ke, l, i0, ov, oi, hist8, hist, s_sel, redi, mask_end, p.end_id - i0);
+        }
+    }
+    // ---- ticket: the last workgroup of the launch finishes the step ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's candidates have been acknowledged (write-through)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = TKD_SLICES * p.B;
+        const int t     = __hip_atomic_fetch_add(&p.state->pad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last          = (t == total - 1) ? 1 : 0;
+        if (s_last) {
+            __hip_atomic_store(&p.state->pad, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next token
+        }
+    }
+    __syncthreads();
+    if (!s_last) {
+        return;
+    }
+    // ---- the finishing workgroup: every row's pick ----
+    __shared__ float sv[TKD_SLICES * TKD_MAXK];
+    __shared__ int   si[TKD_SLICES * TKD_MAXK];
+    __shared__ float tv[TKD_MAXK];
+    __shared__ int   ti[TKD_MAXK];
+    __shared__ int   s_ids[8];
+    int steps_done = 0;
+    if (threadIdx.x == 0) {
+        steps_done = p.state->steps_done;
+    }
+    for (int row = 0; row < p.B; row++) {
+        int* out_id = p.output_ids + (size_t)step0 * p.B + row;
+        if (p.finished[row]) {
+            if (threadIdx.x == 0) {
+                *out_id = p.end_id;  // sampling_topk_kernels.cu:239-242
+                if (row < 8) {
+                    s_ids[row] = p.end_id;
+                }
+            }
+            continue;
+        }
+        const int k = p.top_k[row];
+        int       n2 = 1;
+        while (n2 < TKD_SLICES * k) {
+            n2 <<= 1;
+        }
+        int k2 = 1;
+        while (k2 < k) {
+            k2 <<= 1;
+        }
+        __syncthreads();  // (the previous row's thread 0 has read sv / si)
+        {
+            const gu32* cv = (const gu32*)(cand_v + (size_t)row * TKD_SLICES * TKD_MAXK);
+            const gu32* ci = (const gu32*)(cand_i + (size_t)row * TKD_SLICES * TKD_MAXK);
+            for (int c = threadIdx.x; c < n2; c += 256) {
+                const int q = c / k, j = c % k;
+                float     v = -INFINITY;
+                int       id = 0x7fffffff;
+                if (c < TKD_SLICES * k) {
+                    const int ii = (int)__hip_atomic_load(ci + q * TKD_MAXK + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ii >= 0) {
+                        v  = __uint_as_float(__hip_atomic_load(cv + q * TKD_MAXK + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        id = ii;
+                    }
+                }
+                sv[c] = v;
+                si[c] = id;
+            }
+        }
+        if (k > 1 && n2 >= 4 * k2) {
+            union_topk(sv, si, n2, k, k2, tv, ti, hist, s_sel, redi);
+        }
+        else if (k > 1) {
+            bitonic_sort_best_first(sv, si, n2);
+        }
+        else {  // one candidate per slice: the best of 32
+            __syncthreads();
+            VI best{-INFINITY, 0x7fffffff};
+            if (threadIdx.x < TKD_SLICES) {
+                best.v = sv[threadIdx.x];
+                best.i = si[threadIdx.x];
+            }
+            const VI r = block_best(best, redv, redi);
+            if (threadIdx.x == 0) {
+                sv[0] = r.v;
+                si[0] = r.i;
+            }
+            __syncthreads();
+        }
+        // ---- top-k layer (sampling_topk_kernels.cu:210-311): sv / si [0, k) are the row's k best ----
+        if (threadIdx.x == 0) {
+            const float smax = sv[0];
+            float       ssum = 0.f;
+            float       row_max = 0.f, row_den = 1.f;
+            if (p.return_cum_log_probs) {  // addBiasSoftMax of the row (sampling_topp_kernels.cu:1296-1345) from the slice statistics
+                const gu32* st = (const gu32*)(stats + (size_t)row * TKD_SLICES * 2);
+                float       sm[TKD_SLICES], ss[TKD_SLICES];
+                row_max = -FLT_MAX;
+                for (int q = 0; q < TKD_SLICES; q++) {
+                    sm[q]   = __uint_as_float(__hip_atomic_load(st + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    ss[q]   = __uint_as_float(__hip_atomic_load(st + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    row_max = fmaxf(row_max, sm[q]);
+                }
+                float tot = 0.f;
+                for (int q = 0; q < TKD_SLICES; q++) {
+                    tot += ss[q] * __expf(sm[q] - row_max);
+                }
+                row_den = tot + 1e-6f;
+            }
+            for (int i = 0; i < k; i++) {
+                float u = sv[i];
+                if (!p.return_cum_log_probs) {
+                    u = __expf(u - smax);  // :271-275
+                }
+                else {
+                    u = __expf(u - row_max) / row_den;  // the probability the reference's in-place softmax leaves there
+                }
+                sv[i] = u;
+                ssum += u;
+            }
+            const float u01 = ftcf_uniform(p.random_seed[row], 0, p.draw_counter[row]);
+            p.draw_counter[row] += 1;
+            float rnd  = u01 * p.top_p_topk[row] * ssum;  // :283
+            int   pick = k - 1;
+            for (int i = 0; i < k; i++) {
+                rnd -= sv[i];
+                if (rnd <= 0.0f || i == k - 1) {
+                    pick = i;
+                    break;
+                }
+            }
+            int id = si[pick];
+            if (id == 0x7fffffff || id < 0) {
+                id = 0;
+            }
+            *out_id = id;
+            if (p.return_cum_log_probs && p.cum_log_probs) {
+                p.cum_log_probs[row] += logf(sv[pick]);
+            }
+            p.seq_len[row] += 1;  // :305-308
+            p.finished[row] = (id == p.end_id);
+            if (row < 8) {
+                s_ids[row] = id;
+            }
+        }
+    }
+    decode_step_tail(p, step0, steps_done, s_ids, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1480,12 +1773,13 @@ size_t lm_head_greedy_partial_bytes(int B)
     return (size_t)B * 2048 * 4 * sizeof(unsigned long long);  // granules [B][<= 2048 workgroups][4]
 }
 
+static bool dynamic_decode_is_greedy_fused(const SamplingParams& p, bool finish);
 bool lm_head_greedy_ok(const SamplingParams& p, int K)
 {
     const int on = getenv("FTCF_LM_GREEDY") ? atoi(getenv("FTCF_LM_GREEDY")) : 1;  // (read per call: the tests switch the forms)
     // (one or two rows -- the persistent kernel's batch sizes: the kernel is held to 64 VGPRs for eight waves per SIMD, and the
     // LM head's own loop needs 68 / 76 at three / four rows)
-    return on && p.B <= 2 && K % 8 == 0 && dynamic_decode_is_fused(p, true) && p.next_x
+    return on && p.B <= 2 && K % 8 == 0 && dynamic_decode_is_greedy_fused(p, true) && p.next_x
            && lm_head_greedy_partial_bytes(p.B) <= sampling_workspace_bytes(p.B, p.V);
 }
 
@@ -1530,7 +1824,18 @@ size_t sampling_workspace_bytes(int B, int V)
            + (size_t)B * 2 * nv * sizeof(float);
 }
 
-bool dynamic_decode_is_fused(const SamplingParams& p, bool finish)
+// the one-launch step of a plain top-k batch (k_topk_decode)
+static bool dynamic_decode_is_topk_fused(const SamplingParams& p, bool finish)
+{
+    const int on = getenv("FTCF_TOPK_FUSED") ? atoi(getenv("FTCF_TOPK_FUSED")) : 1;  // (read per call: the tests switch the forms)
+    return on && finish && p.max_top_k >= 2 && p.max_top_k <= TKD_MAXK && !p.any_top_p && !p.apply_temperature
+           && !p.apply_repetition && !p.optional_last_tokens && !p.row_len && p.V <= TKD_SLICES * 256 * TKD_MAXE && p.B <= TKD_MAXB
+           && p.rot / 2 <= 256
+           && (size_t)p.B * TKD_SLICES * (TKD_MAXK * 8 + 8) <= sampling_workspace_bytes(p.B, p.V);
+}
+
+// the one-launch step of an all-greedy batch (k_greedy_decode; k_lm_head_greedy where the LM head launch takes it too)
+static bool dynamic_decode_is_greedy_fused(const SamplingParams& p, bool finish)
 {
     const int greedy_on = getenv("FTCF_GREEDY_FUSED") ? atoi(getenv("FTCF_GREEDY_FUSED")) : 1;  // (read per call: the tests switch the forms)
     return greedy_on && finish && p.max_top_k == 1 && !p.any_top_p && !p.apply_temperature && !p.apply_repetition && !p.optional_last_tokens
@@ -1538,12 +1843,22 @@ bool dynamic_decode_is_fused(const SamplingParams& p, bool finish)
            && (size_t)p.B * GREEDY_SLICES * 16 <= sampling_workspace_bytes(p.B, p.V);
 }
 
+bool dynamic_decode_is_fused(const SamplingParams& p, bool finish)
+{
+    return dynamic_decode_is_topk_fused(p, finish) || dynamic_decode_is_greedy_fused(p, finish);
+}
+
 void launch_dynamic_decode(const SamplingParams& p, hipStream_t s, bool finish)
 {
     float* cand_v = reinterpret_cast<float*>(p.ws);
     int*   cand_i = reinterpret_cast<int*>(cand_v + (size_t)p.B * TOPK_BLOCKS * TOPK_MAX);
     // every row greedy, nothing but the min-length mask touches the logits, the step's bookkeeping follows: one launch
-    if (dynamic_decode_is_fused(p, finish)) {
+    if (dynamic_decode_is_topk_fused(p, finish)) {
+        hipLaunchKernelGGL(k_topk_decode, dim3(TKD_SLICES, p.B), dim3(256), 0, s, p, cand_v);
+        FTCF_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    if (dynamic_decode_is_greedy_fused(p, finish)) {
         hipLaunchKernelGGL(k_greedy_decode, dim3(GREEDY_SLICES, p.B), dim3(256), 0, s, p, cand_v);
         FTCF_HIP_CHECK(hipGetLastError());
         return;

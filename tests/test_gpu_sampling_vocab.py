@@ -203,3 +203,39 @@ def test_beam_search_kernels_at_the_headline_vocabulary(gh, model):
     assert r["output_ids"].tolist() == o_ids.tolist()
     assert r["sequence_lengths"].tolist() == o_len.tolist()
     np.testing.assert_allclose(r["cum_log_probs"], o_cum, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_the_one_launch_top_k_step_equals_the_general_launches(gh, model, monkeypatch, B):
+    """The harness default (top_k = 50, nothing else: codefuse_example.py:799-806) takes ONE launch behind the LM head (k_topk_decode);
+    FTCF_TOPK_FUSED=0 sends the same request through k_decode_prep / k_topk_stage1 / k_sample / k_decode_finish.  Same tokens, lengths
+    and loop count from both, scores to 1e-4 (the row's soft-max denominator is summed over 32 slices instead of 8), and both what the
+    oracle picks from the GPU's logits -- with min_length holding end_id back and stop words ending rows."""
+    w, op = model
+    out = 8
+    ids = _prompts(B, 311 + B)
+    ks = [50, 8, 2][:B]
+    free = _forward(op, ids, out, top_k=ks, random_seed=[77 + b for b in range(B)])
+    g = free["output_ids"][:, S:]
+    cfg2 = dict(CFG, end_id=int(g[0, 3]))  # row 0 draws it as its fourth token
+    stop = np.full((B, 2, 2), -1, np.int32)
+    stop[:, 0, :] = 0
+    stop[B - 1, 0, :2] = g[B - 1, 4:6]
+    stop[B - 1, 1, 0] = 2
+    cases = {"plain": {}, "min_length": dict(min_length=[6] * B), "stop_words": dict(stop_words=stop)}
+    for name, extra in cases.items():
+        kw = dict(top_k=ks, random_seed=[77 + b for b in range(B)], **extra)
+        got = {}
+        for form in ("1", "0"):
+            monkeypatch.setenv("FTCF_TOPK_FUSED", form)
+            got[form] = _forward(gh.make_op(cfg2, w), ids, out, **kw)
+        a, b = got["1"], got["0"]
+        assert np.array_equal(a["output_ids"], b["output_ids"]), (name, a["output_ids"][:, S:], b["output_ids"][:, S:])
+        assert np.array_equal(a["sequence_lengths"], b["sequence_lengths"]) and a["steps"] == b["steps"], name
+        np.testing.assert_allclose(a["cum_log_probs"], b["cum_log_probs"], rtol=1e-4, atol=1e-4, err_msg=name)
+        bad, st = _replay(a, ids, out, orc.Sampling(B, **kw), cfg2["end_id"])
+        assert not bad, (name, bad)
+        assert a["steps"] == st["steps"], (name, a["steps"], st["steps"])
+        np.testing.assert_allclose(a["cum_log_probs"], st["cum"], rtol=1e-4, atol=2e-4, err_msg=name)
+        if name == "plain":
+            assert a["output_ids"][0, S + 3] == cfg2["end_id"] and a["sequence_lengths"][0] < S + out
