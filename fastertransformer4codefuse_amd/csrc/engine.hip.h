@@ -125,7 +125,7 @@ struct ftcf_gptneox {
     int*                tp_scratch = nullptr;  // device int for the barrier all-reduce of the tensor-parallel windows
     long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
     // persistent decode layers for 3..16 rows (kernels_rows.hip): on whenever the shape is eligible (FTCF_ROWS=0: general path)
-    int                 rows = 1, rows_nb = 0, rows_min = 3, rows_tp = 0;
+    int                 rows = 1, rows_nb = 0, rows_min = -1, rows_tp = 0;  // rows_min < 0: see plan()
     RowsPlan            rplan{};
     char*               rows_ws = nullptr;
     long long*          rows_ts = nullptr;
@@ -309,7 +309,13 @@ struct ftcf_gptneox {
             rplan = RowsPlan{};
             rows_ws = nullptr;
             rows_ts = nullptr;
-            if (rows && (cfg.tensor_para_size == 1 || rows_tp) && !pplan.ok && !fp32 && K == 1 && B >= rows_min && B <= 16
+            // One and two rows are the one- / two-row kernel's; where ITS plan declines a request (fp16 weights at two rows, more than
+            // 1248 / 3072 tokens of context: its LDS) the rows kernel takes it -- 2.73 ms per token at one row against 3.2 on the
+            // per-stage launches, 3.10 at two rows against 3.48 on the general path (13B int8, 1024-in / 512-out) -- but not when
+            // that kernel has been switched off (FTCF_PERSIST=0, or after it gave up once): then the per-stage launches run, the path
+            // of a tensor-parallel rank
+            const int rmin = rows_min >= 1 ? rows_min : (persist ? 1 : 3);
+            if (rows && (cfg.tensor_para_size == 1 || rows_tp) && !pplan.ok && !fp32 && K == 1 && B >= rmin && B <= 16
                 && cfg.use_gptj_residual && L <= 255) {
                 // (ranks that share ONE device -- a local group's threads, the two-process tests -- must be resident together)
                 int nb = rows_nb > 0 ? rows_nb : persist_nb;

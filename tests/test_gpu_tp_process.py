@@ -142,6 +142,23 @@ def test_two_processes_on_one_gpu_exchange_through_ipc_windows(gh, tmp_path, mod
         _check(r1["output_ids"], r1["logits"], res[0][name + ".output_ids"], res[0][name + ".logits"], lens, f"{model} {name} vs TP=1 engine", frac)
 
 
+def test_compiled_module_bootstraps_tensor_parallelism_from_the_callers_process_group(gh, tmp_path):
+    """The two ranks build `libth_gptneox.GptNeoXOp` -- the COMPILED pybind11 module -- over their gloo group: the constructor casts the
+    Python group to c10d::ProcessGroup, builds the host-exchange communicator (comm_from_group, FTCF_TP_EXCHANGE=host) and every
+    exchange of the engine (window hand-shake, agreement words, collectives of the general path) travels through
+    HostExchange::allgather on that group (csrc/th_op/th_gptneox.cc:49-97; the reference: th_op/gptneox/utils/nccl_inherit_utils.cc:25-68,
+    GptNeoXOp.cc:25-106).  Tokens equal on both ranks, logits bit-identical across ranks, and what the TP = 1 engine produces."""
+    cfg, w, _ = load_tiny()
+    res, logs = _run_ranks(tmp_path, "tiny", 0, extra_env={"FTCF_TEST_COMPILED_OP": "1"})
+    op1 = gh.make_op(cfg, w)
+    for name, (ids, lens, n_out, kw) in requests(cfg, "tiny").items():
+        assert res[0][name + ".output_ids"].tolist() == res[1][name + ".output_ids"].tolist(), name
+        np.testing.assert_array_equal(res[0][name + ".logits"], res[1][name + ".logits"])
+        r1 = gh.run_op(op1, ids, lens, n_out, cfg["vocab_size"], **kw)
+        _check(r1["output_ids"], r1["logits"], res[0][name + ".output_ids"], res[0][name + ".logits"], lens,
+               f"compiled module, {name} vs TP=1 engine", 5e-3)
+
+
 def test_two_processes_fall_back_together_when_the_windows_are_refused(gh, tmp_path):
     """FTCF_TP_WINDOWS=0 on ONE rank only: the agreement after the hand-shake leaves win_ok false on BOTH, and the request
     runs on the collective path (per-stage launches + one host-staged all-reduce per layer) with the same tokens."""

@@ -22,7 +22,8 @@ def mods():
 
 def test_the_compiled_modules_are_the_ones_on_lib_path(mods):
     g, c = mods
-    # a directory's extension modules win over its .py files: the shims next to them are the fallback of an unbuilt tree
+    # (no Python stand-ins sit next to them any more: the directory holds the compiled modules only)
+    assert not [f for f in os.listdir(os.path.dirname(g.__file__)) if f.startswith("libth_") and f.endswith(".py")]
     assert g.__file__.endswith(".so") and c.__file__.endswith(".so"), (g.__file__, c.__file__)
     assert g.compiled and c.compiled
     assert hasattr(g, "GptNeoXOp") and hasattr(g.GptNeoXOp, "forward")

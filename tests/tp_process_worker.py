@@ -36,8 +36,18 @@ def main():
     # collective path and the engine stays there (the designed fall-back).  The test is about the in-kernel path, so a
     # run in which a one- or two-row request left it is repeated with fresh engines, up to six times.
     reqs = requests(cfg, model)
+    # FTCF_TEST_COMPILED_OP=1: the COMPILED module's op (lib/libth_gptneox.so, csrc/th_op/th_gptneox.cc) instead of the ctypes one --
+    # its tensor-parallel bootstrap takes the caller's c10d::ProcessGroup (comm_from_group) and, with FTCF_TP_EXCHANGE=host, carries
+    # every exchange through HostExchange::allgather (th_op/gptneox/utils/nccl_inherit_utils.cc:25-68 is the reference's counterpart)
+    op_class = None
+    if os.environ.get("FTCF_TEST_COMPILED_OP") == "1":
+        sys.path.append(os.path.join(ROOT, "fastertransformer4codefuse_amd", "lib"))
+        import libth_gptneox
+        assert libth_gptneox.__file__.endswith(".so") and libth_gptneox.compiled
+        op_class = libth_gptneox.GptNeoXOp
     for attempt in range(6):
-        op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD)
+        op = gh.make_op(cfg, shard_weights(cfg, w, world, rank), int8_mode=int8_mode, tp=world, rank=rank, comm=dist.group.WORLD,
+                        op_class=op_class)
         res = {}
         left = 0
         for name, (ids, lens, n_out, kw) in reqs.items():

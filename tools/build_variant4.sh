@@ -7,7 +7,7 @@ name=$1; flags=$2
 cd "$(dirname "$0")/../fastertransformer4codefuse_amd/csrc"
 mkdir -p build/var
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fopenmp -Wall -Wno-unused-function -I../../include -DPS_ONLY_ONE $flags \
-  -c kernels_persist4.hip -o build/var/kp4_$name.o -Rpass-analysis=kernel-resource-usage 2> build/var/kp4_$name.log || { tail -30 build/var/kp4_$name.log; exit 1; }
+  -I. -I../../tools/experiments -c ../../tools/experiments/kernels_persist4.hip -o build/var/kp4_$name.o -Rpass-analysis=kernel-resource-usage 2> build/var/kp4_$name.log || { tail -30 build/var/kp4_$name.log; exit 1; }
 grep -E "VGPRs Spill|ScratchSize" build/var/kp4_$name.log | sed "s/.*remark: *//;s/\[-Rpass[^]]*\]//" | paste - -
 objs=$(ls build/*.o | grep -v kernels_persist4.hip.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fopenmp -o ../lib/libftcf_$name.so build/var/kp4_$name.o $objs -L/opt/rocm/lib -lrccl -lroctx64 -Wl,-rpath,/opt/rocm/lib
