@@ -629,7 +629,8 @@ struct ftcf_batcher {
     }
     // gatherTree over the group's steps (decoding_kernels.cu:452-583, as GptNeoXOp.forward returns its beams: [K][n + max_new]
     // ids padded with end_id, lengths, cum_log_probs), the result parked until it is fetched, the slots and pages freed
-    void finish_group(const int si, std::vector<Event>& ev)
+    // fire_now = false (from inside an admission): the event is only recorded, step() fires it once the admission has succeeded
+    void finish_group(const int si, std::vector<Event>& ev, const bool fire_now = true)
     {
         BeamGroup&  g = groups.at(si);
         hipStream_t st = e->stream;
@@ -649,7 +650,12 @@ struct ftcf_batcher {
         const long id    = g.id;
         beam_results[id] = std::move(r);
         release_group(si);
-        emit(ev, Event{id, -1, 1});
+        if (fire_now) {
+            emit(ev, Event{id, -1, 1});
+        }
+        else {
+            ev.push_back(Event{id, -1, 1});
+        }
     }
     // prompt -> the engine's own beam-search request of ONE step (prefill of the K tiled rows, first beam step) -> the group's
     // state; the prompt's K/V are scattered once (beam 0's rows) into pages all beams share
@@ -708,8 +714,17 @@ struct ftcf_batcher {
         e->forward(a);  // host synchronous; the engine's buffers keep the request's state: step_ids / parent_ids [n + 1][K], ...
         // the prompt's pages, shared by every beam
         std::vector<int> shared;
-        for (int i = 0; i < (n + P - 1) / P; i++) {
-            shared.push_back(take_page());
+        try {
+            for (int i = 0; i < (n + P - 1) / P; i++) {
+                shared.push_back(take_page());
+            }
+        }
+        catch (...) {  // (no group owns them yet: step()'s release_group(si) would not find them)
+            for (int pg : shared) {
+                page_ref[pg] = 1;
+                drop_page(pg);
+            }
+            throw;
         }
         g.lists.assign(K, shared);
         for (int pg : shared) {
@@ -766,7 +781,7 @@ struct ftcf_batcher {
             all_fin &= fin[k] != 0;
         }
         if (all_fin || G.generated >= G.max_new) {
-            finish_group(si, ev);
+            finish_group(si, ev, false);  // (step() fires it when the admission has succeeded)
             return;
         }
         prepare_append(G, n, fin, st);
@@ -1115,19 +1130,47 @@ struct ftcf_batcher {
                     slot_topk[si0 + k] = 1;
                     slot_temp[si0 + k] = 1.f;
                 }
-                const size_t ev0 = ev.size();
+                // slots are running and the prompt is long: its prompt phase in chunks, a decode step of the running slots after every
+                // chunk (as for a sampled request below; the events of those steps are final whatever happens to the admission)
+                bool running = false;
+                for (const Slot& s : slots) {
+                    running |= s.active;
+                }
+                const bool         chunked = running && prefill_chunk > 0 && (int)rq.prompt.size() > prefill_chunk;
+                std::vector<Event> own, between;
                 try {
-                    admit_beam(si0, rq, ev);
+                    if (chunked) {
+                        hook_ev          = &between;
+                        e->prefill_chunk = prefill_chunk;
+                        e->prefill_hook  = [this] {
+                            bool live = false;
+                            for (const Slot& s : slots) {
+                                live |= s.active && s.group < 0;
+                            }
+                            if (live || !groups.empty()) {
+                                refresh_host_flags();
+                                decode(*hook_ev);
+                            }
+                        };
+                    }
+                    admit_beam(si0, rq, own);
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
                 }
                 catch (...) {
+                    e->prefill_hook = nullptr;
+                    hook_ev         = nullptr;
                     (void)hipDeviceSynchronize();
                     (void)hipGetLastError();
                     release_group(si0);
                     beam_results.erase(rq.id);
                     waiting.push_front(std::move(rq));
-                    ev.resize(ev0);
+                    ev.insert(ev.end(), between.begin(), between.end());
                     throw;
                 }
+                ev.insert(ev.end(), between.begin(), between.end());
+                ev.insert(ev.end(), own.begin(), own.end());
+                fire(own, 0);  // (the admission's own events reach the callback only now)
             }
             refresh_host_flags();
             return;

@@ -589,7 +589,7 @@ struct ftcf_gptneox {
     // the GEMM outputs, not bit for bit.
     int                   prefill_chunk = 0;
     std::function<void()> prefill_hook;
-    bool context_decoder_chunked(int S, const int* input_lengths, int s_max)
+    bool context_decoder_chunked(int S, const int* input_lengths, int s_max, int tile = 1)
     {
         if (!prefill_hook || prefill_chunk <= 0 || S <= prefill_chunk || fp32 || cfg.tensor_para_size != 1 || !cfg.use_gptj_residual
             || !residual_dual_ln_supported(H)) {
@@ -597,7 +597,7 @@ struct ftcf_gptneox {
         }
         Range r("ftcf.GptNeoXContextDecoder.chunked");
         bind_layers();
-        const size_t cache_l = (size_t)nhl * s_max * dh;
+        const size_t cache_l = (size_t)tile * nhl * s_max * dh;  // (tile = beam_width: the sequence's K/V go to cache row 0 of tile rows)
         for (int s0 = 0; s0 < S; s0 += prefill_chunk) {
             const int s1 = std::min(S, s0 + prefill_chunk), m = s1 - s0;
             f16*      X  = px + (size_t)s0 * H;
@@ -606,7 +606,7 @@ struct ftcf_gptneox {
                 launch_residual_dual_ln(X, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, pnrm + (size_t)s0 * H,
                                         pnrm2 + (size_t)s0 * H, m, H, 1e-5f, stream);
                 context_attention_layer.forward(pnrm, pqkv, pctx, patt, w, input_lengths, k_cache + l * cache_l, v_cache + l * cache_l, 1,
-                                                S, s_max, 1, stream, s0, s1);
+                                                S, s_max, tile, stream, s0, s1);
                 ffn_layer.forward(pnrm2 + (size_t)s0 * H, pmid + (size_t)s0 * il, pffn + (size_t)s0 * H, w, m, stream);
                 launch_add_bias_attn_ffn_residual(X, pffn + (size_t)s0 * H, patt + (size_t)s0 * H, X, w.ffn2.bias, m, H, 1, 1, true, stream);
             }
@@ -708,7 +708,7 @@ struct ftcf_gptneox {
 
     void context_decoder(int B, int S, const int* input_lengths, int s_max, int tile)
     {
-        if (tile == 1 && B == 1 && context_decoder_chunked(S, input_lengths, s_max)) {
+        if (B == 1 && context_decoder_chunked(S, input_lengths, s_max, tile)) {  // (tile > 1: a beam request's prompt)
             return;
         }
         if (tile == 1 && context_decoder_overlapped(B, S, input_lengths, s_max)) {

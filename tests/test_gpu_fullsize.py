@@ -298,8 +298,8 @@ def test_13b_layer_shape_against_oracle(dtype, monkeypatch):
     t1, l1 = _run(op, ids[:1].cuda(), out, V)  # persistent kernel, one row
     assert op.stats()["decode_path"] == 1
     check(t1, l1, [0], "persistent m=1")
-    t2, l2 = _run(op, ids.cuda(), out, V)  # two rows: the persistent kernel where its LDS plan fits (int8), else the general path
-    assert op.stats()["decode_path"] == (1 if dtype == "int8" else 2)
+    t2, l2 = _run(op, ids.cuda(), out, V)  # two rows: the persistent kernel where its LDS plan fits (int8), else the rows kernel
+    assert op.stats()["decode_path"] == (1 if dtype == "int8" else 3)
     check(t2, l2, [0, 1], "two rows")
     ids16 = ids.repeat(8, 1).contiguous().cuda()
     t16, l16 = _run(op, ids16, out, V)  # the rows kernel at m = 16
