@@ -491,6 +491,50 @@ def test_beam_requests_share_the_batcher_with_greedy_ones(gh, page_tokens):
     assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
 
 
+def test_a_beam_request_with_a_long_prompt_is_admitted_in_chunks(gh, monkeypatch):
+    """Round 5: a beam request whose prompt is longer than the chunk, arriving while a greedy request runs, has its prompt phase
+    cut into chunks with a decode step of the running slot after every chunk but the last (the engine's chunked context decoder
+    takes the beam request's cache tile); its hypotheses, lengths and scores are what the engine's own beam search returns for the
+    prompt alone, the greedy request stays what it is alone, and the token callback sees the group's finished event exactly once."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    monkeypatch.setenv("FTCF_BATCHER_PREFILL_CHUNK", "8")
+    cfg, w, z = load_tiny()
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    op = gh.make_op(cfg, w)
+    rng = np.random.RandomState(23)
+    greedy, g_new = z["prompt_b"].tolist(), 14
+    g_ref = _alone(gh, op, greedy, g_new, V, end_id)[0]
+    bp, b_new, K = rng.randint(3, V, size=21).tolist(), 7, 3
+    b_ref = _beam_alone(gh, op, bp, b_new, V, K)
+    cb = ContinuousBatcher(op, max_batch=4, page_tokens=8, num_pages=40, max_seq_len=48)
+    free0 = cb.status()["free_pages"]
+    streamed = []
+    cb.set_token_callback(lambda rid, tok, fin: streamed.append((rid, tok, fin)))
+    gid = cb.submit(greedy, g_new)
+    per_step, got, bid = [], [], None
+    it = 0
+    while it == 0 or cb.busy():
+        if it == 1:
+            bid = cb.submit_beam(bp, b_new, K, 0.0, 0.0, 1.0, 1.0)
+        evs = cb.step()
+        per_step.append([(rid == gid) for rid, _, _ in evs])
+        got += [tok for rid, tok, _ in evs if rid == gid]
+        it += 1
+        assert it < 500
+    assert got == g_ref, (got, g_ref)
+    # the call that admits the 21-token prompt in chunks of 8, 8, 5: one decode step of its own + one after each of the first two chunks
+    assert per_step[1] == [True, True, True], per_step[:3]
+    out, lens, cum = cb.beam_result(bid)
+    # (the chunked prompt phase runs its GEMMs on other row counts than the one-piece one: the same arithmetic per row up to the
+    #  split-K form, so a near tie may order two hypotheses differently; the tiny model's are apart)
+    assert np.array_equal(out, b_ref[0]), (out, b_ref[0])
+    assert np.array_equal(lens, b_ref[1])
+    np.testing.assert_allclose(cum, b_ref[2], rtol=5e-3, atol=5e-3)
+    assert [e for e in streamed if e[0] == bid] == [(bid, -1, 1)]
+    cb.set_token_callback(None)
+    assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+
+
 def test_a_cancelled_beam_request_returns_its_pages(gh):
     from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
     cfg, w, z = load_tiny()
