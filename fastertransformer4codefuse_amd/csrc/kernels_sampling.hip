@@ -607,22 +607,39 @@ __device__ __forceinline__ void bitonic_sort_global(float* v, int* id, const int
 // The kc best of the n2 candidates sv / si (LDS) -> sv / si [0, kc) sorted best first: radix select of the kc-th best (as stage 1,
 // over the LDS copy), the winners compacted into the k2 = 2^ceil(log2 kc) slots tv / ti, THOSE sorted (k = 50: 21 network stages
 // instead of 45 over 512 pairs)
+// (h8: eight private copies of the histogram, picked by lane -- for unions of thousands of candidates, whose sign / exponent bytes
+//  fall into a handful of bins and would serialise on one LDS word; NULL: the single histogram)
 __device__ __forceinline__ void union_topk(float* sv, int* si, const int n2, const int kc, const int k2, float* tv, int* ti, int* hist,
-                                           int* s_sel, int* redi)
+                                           int* s_sel, int* redi, int (*h8)[257] = nullptr)
 {
     __syncthreads();
     unsigned prefix = 0u, mask = 0u;
     int      need = kc;
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[threadIdx.x] = 0;
+        if (h8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                h8[q][threadIdx.x] = 0;
+            }
+        }
         __syncthreads();
         for (int c = threadIdx.x; c < n2; c += 256) {
             const unsigned key = fkey(sv[c]);
             if ((key & mask) == prefix) {
-                atomicAdd(&hist[(key >> shift) & 255u], 1);
+                atomicAdd(h8 ? &h8[threadIdx.x & 7][(key >> shift) & 255u] : &hist[(key >> shift) & 255u], 1);
             }
         }
         __syncthreads();
+        if (h8) {
+            int t = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                t += h8[q][threadIdx.x];
+            }
+            hist[threadIdx.x] = t;
+            __syncthreads();
+        }
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
             const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
@@ -1565,23 +1582,29 @@ __global__ __launch_bounds__(256) void k_topk_decode(const SamplingParams p, flo
         {
             const gu32* cv = (const gu32*)(cand_v + (size_t)row * TKD_SLICES * TKD_MAXK);
             const gu32* ci = (const gu32*)(cand_i + (size_t)row * TKD_SLICES * TKD_MAXK);
-            for (int c = threadIdx.x; c < n2; c += 256) {
-                const int q = c / k, j = c % k;
-                float     v = -INFINITY;
-                int       id = 0x7fffffff;
-                if (c < TKD_SLICES * k) {
-                    const int ii = (int)__hip_atomic_load(ci + q * TKD_MAXK + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ii >= 0) {
-                        v  = __uint_as_float(__hip_atomic_load(cv + q * TKD_MAXK + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        id = ii;
-                    }
+            // (all of a thread's candidates requested together: one round trip, not sixteen)
+            constexpr int NC = TKD_SLICES * TKD_MAXK / 256;
+            unsigned      rv[NC], ri[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                const int c  = threadIdx.x + 256 * j;
+                const int cc = c < TKD_SLICES * k ? c : 0;
+                const int q = cc / k, e = cc - q * k;
+                ri[j] = __hip_atomic_load(ci + q * TKD_MAXK + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rv[j] = __hip_atomic_load(cv + q * TKD_MAXK + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                const int c = threadIdx.x + 256 * j;
+                if (c < n2) {
+                    const bool ok = c < TKD_SLICES * k && (int)ri[j] >= 0;
+                    sv[c]         = ok ? __uint_as_float(rv[j]) : -INFINITY;
+                    si[c]         = ok ? (int)ri[j] : 0x7fffffff;
                 }
-                sv[c] = v;
-                si[c] = id;
             }
         }
         if (k > 1 && n2 >= 4 * k2) {
-            union_topk(sv, si, n2, k, k2, tv, ti, hist, s_sel, redi);
+            union_topk(sv, si, n2, k, k2, tv, ti, hist, s_sel, redi, hist8);
         }
         else if (k > 1) {
             bitonic_sort_best_first(sv, si, n2);

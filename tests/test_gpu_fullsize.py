@@ -218,7 +218,7 @@ def test_full_depth_13b_int8_follows_the_oracle(full):
     cfg = dict(head_num=a.heads, size_per_head=a.head_dim, inter_size=I, num_layer=Lc, vocab_size=V, rotary_dim=a.rotary,
                end_id=2, int8_mode=1, fp16=1)
     m = orc.Model(cfg, layers, glob)
-    S, out = 40, 8
+    S, out = 16, 4  # (40 + 8 until round 5: the oracle walks 13.6 GB per token on the host -- 126 to 232 s of the suite, box to box)
     g = torch.Generator().manual_seed(7)
     ids = torch.randint(3, V, (1, S), generator=g, dtype=torch.int32)
     ref = m.generate(ids.numpy(), [S], out, return_logits=True)
