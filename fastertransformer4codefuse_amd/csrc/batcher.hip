@@ -1,5 +1,6 @@
 // Continuous batching over a paged K/V cache (include/ftcf.h `ftcf_batcher_*`): split out of engine.hip in round 4.
 #include "engine.hip.h"
+#include "attn_device.hip.h"  // rotary_coef (the rows kernel's rotary table of a step)
 
 #include <set>
 
@@ -42,6 +43,23 @@ __global__ void k_batcher_last_token(int* tok, const int* hist, const int* len, 
 __global__ void k_batcher_tick(DecodeState* gemm_state)
 {
     gemm_state->step = (gemm_state->step + 1) & 0x7ffff;  // part of the burst GEMMs' granule tags (19 bits)
+}
+
+// the rows kernel inside the batcher (round 5): its step counter (the hand-off tags are step * 256 + layer + 1) and the rotary table
+// of the step -- a slot's new token sits at position len[slot] (decoder_masked_multihead_attention_utils.h:1325-1345 coefficients,
+// as k_mmha_paged computes them in place)
+__global__ void k_batcher_rows_prep(int* step, float* rot_table, const int* len, int rot)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *step = *step + 1;
+    }
+    const int b = blockIdx.x;
+    for (int j = threadIdx.x; j < rot / 2; j += blockDim.x) {
+        float cs, sn;
+        rotary_coef(j, rot, len[b], cs, sn);
+        rot_table[((size_t)b * (rot / 2) + j) * 2]     = cs;
+        rot_table[((size_t)b * (rot / 2) + j) * 2 + 1] = sn;
+    }
 }
 
 // beam groups (see ftcf_batcher::BeamGroup): copy-on-write of K/V pages, every layer of both pools; pairs = {src, dst} page ids
@@ -160,6 +178,15 @@ struct ftcf_batcher {
     // chunked admission: with slots running, a prompt longer than this is prefilled alone, `prefill_chunk` tokens at a time, one
     // decode step of the running slots between two chunks (FTCF_BATCHER_PREFILL_CHUNK; 0 = whole prompts)
     int prefill_chunk = 512;
+    // the decode step's layers as ONE launch of the rows kernel (kernels_rows.hip, paged K/V form): tensor_para_size 1, at most 16
+    // slots, page_tokens a multiple of the kernel's attention block (FTCF_BATCHER_ROWS=0: the per-GEMM launches)
+    RowsPlan      rplan{};
+    bool          use_rows = false;
+    char*         rows_ws = nullptr;
+    PersistLayer* d_rlayers = nullptr;
+    float*        d_rot = nullptr;
+    int*          d_rstep = nullptr;
+    unsigned      rows_steps = 0;
     size_t       smallm_partial = 0;
     unsigned     smallm_seq = 0;
     long         gemm_steps = 0;
@@ -263,6 +290,43 @@ struct ftcf_batcher {
         d_pseq = dmalloc<int>(B);
         d_pages_tmp = dmalloc<int>(max_pages);
         samp_ws = dmalloc<char>(sampling_workspace_bytes(max_batch, V), false);
+        {
+            const int rows_env = getenv("FTCF_BATCHER_ROWS") ? atoi(getenv("FTCF_BATCHER_ROWS")) : 1;
+            if (rows_env && e->rows && e->cfg.tensor_para_size == 1 && !e->fp32 && max_batch <= 16 && e->cfg.use_gptj_residual && L <= 255
+                && (e->dh == 64 || e->dh == 128) && P % rows_paged_block(e->dh) == 0) {
+                rplan = rows_plan(max_batch, H, hl, il, e->nhl, e->dh, 1, e->int8, e->num_cu, 0);
+                if (rplan.ok && rows_resident(rplan, e->int8, e->dh, e->num_cu)) {
+                    rows_ws   = dmalloc<char>(rows_workspace_bytes(rplan, max_batch, H, hl, il, e->nhl, e->dh));
+                    d_rlayers = dmalloc<PersistLayer>(L);
+                    d_rot     = dmalloc<float>(B * std::max(1, e->cfg.rotary_embedding_dim));
+                    d_rstep   = dmalloc<int>(1);
+                    std::vector<PersistLayer> pl(L);
+                    for (int l = 0; l < L; l++) {
+                        const LayerWeights& w = e->layers[l];
+                        PersistLayer&       r = pl[l];
+                        r.ln1_g = w.ln1_g;
+                        r.ln1_b = w.ln1_b;
+                        r.ln2_g = w.ln2_g;
+                        r.ln2_b = w.ln2_b;
+                        r.w_qkv = w.qkv.kernel;
+                        r.w_ffn1 = w.ffn1.kernel;
+                        r.w_out = w.attn_out.kernel;
+                        r.w_ffn2 = w.ffn2.kernel;
+                        r.s_qkv = w.qkv.scale;
+                        r.s_ffn1 = w.ffn1.scale;
+                        r.s_out = w.attn_out.scale;
+                        r.s_ffn2 = w.ffn2.scale;
+                        r.b_qkv = w.qkv.bias;
+                        r.b_ffn1 = w.ffn1.bias;
+                        r.b_res = w.ffn2.bias;
+                        r.k_cache = kpool + (size_t)l * pool_layer_elems;
+                        r.v_cache = vpool + (size_t)l * pool_layer_elems;
+                    }
+                    FTCF_HIP_CHECK(hipMemcpy(d_rlayers, pl.data(), sizeof(PersistLayer) * L, hipMemcpyHostToDevice));
+                    use_rows = true;
+                }
+            }
+        }
         if (max_batch > 4 && max_batch <= e->SMALLM_MAX_ROWS) {
             const bool i8 = e->int8;
             const int  bc = std::min(max_batch, 16);  // 16 rows per launch
@@ -886,12 +950,51 @@ struct ftcf_batcher {
         const bool             dual = residual_dual_ln_supported(H);
         const int              tp = e->cfg.tensor_para_size;
         const bool             tp1 = tp == 1;  // (tensor parallel: the layer ends with residual + all-reduce, GptNeoXDecoder.cc:357-359)
+        e->stats.decode_path = use_rows ? 3 : 2;  // (ftcf_gptneox_get_stats of the borrowed engine: which layers the last decode step ran)
         hipLaunchKernelGGL(k_batcher_embed, dim3(B), dim3(256), 0, st, x, e->wte, d_tok, H);
         if ((gemm_steps++ & 0x3ffff) == 0 && smallm_ws) {  // the tag space of the burst GEMMs wraps: start it clean
             FTCF_HIP_CHECK(hipMemsetAsync(smallm_ws, 0, smallm_partial + gemm_smallm_ticket_bytes(), st));
         }
         hipLaunchKernelGGL(k_batcher_tick, dim3(1), dim3(1), 0, st, d_gstate);
-        for (int l = 0; l < L; l++) {
+        if (use_rows) {
+            // every layer of the step in one launch (rows_device.hip.h, paged K/V): x -> x
+            if ((rows_steps++ & 0xfffff) == 0) {  // (the tag space: start it clean now and then)
+                FTCF_HIP_CHECK(hipMemsetAsync(rows_ws, 0, rows_flag_bytes(rplan, B, e->nhl), st));
+                FTCF_HIP_CHECK(hipMemsetAsync(d_rstep, 0, sizeof(int), st));
+            }
+            hipLaunchKernelGGL(k_batcher_rows_prep, dim3(B), dim3(64), 0, st, d_rstep, d_rot, d_len, e->cfg.rotary_embedding_dim);
+            RowsParams rp{};
+            rp.layers = d_rlayers;
+            rp.L = L;
+            rp.l_begin = 0;
+            rp.l_end = L;
+            rp.x_in = x;
+            rp.x_out = x;
+            rp.M = B;
+            rp.H = H;
+            rp.Hl = hl;
+            rp.Il = il;
+            rp.nh = e->nhl;
+            rp.dh = e->dh;
+            rp.rot = e->cfg.rotary_embedding_dim;
+            rp.s_max = max_len;
+            rp.tp = 1;
+            rp.plan = rplan;
+            rows_carve(rp, rows_ws);
+            rp.d_step = d_rstep;
+            rp.d_stop = nullptr;
+            rp.seq_len = d_len;
+            rp.input_lengths = nullptr;
+            rp.max_input_len = 0;
+            rp.finished = d_fin;
+            rp.rot_table = d_rot;
+            rp.eps = 1e-5f;
+            rp.page_table = d_pt;
+            rp.page_tokens = P;
+            rp.max_pages = max_pages;
+            launch_decode_rows(rp, int8, st);
+        }
+        for (int l = 0; l < (use_rows ? 0 : L); l++) {
             const LayerWeights& w = e->layers[l];
             if (!dual) {
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
@@ -1041,6 +1144,10 @@ struct ftcf_batcher {
         }
         // tensor parallel: the window all-reduce's sticky give-up word of this step's 2 L all-reduces (a peer that never arrived:
         // x is partly reduced and the step's tokens are not to be trusted either), read with the same copies
+        int rows_err = 0;
+        if (use_rows) {
+            FTCF_HIP_CHECK(hipMemcpyAsync(&rows_err, rows_ws, sizeof(int), hipMemcpyDeviceToHost, st));
+        }
         int        ar_err  = 0;
         const bool ar_live = e->cfg.tensor_para_size > 1 && e->cfg.comm && e->cfg.comm->ar_sync && e->cfg.comm->ar_seq > 0
                              && !e->cfg.comm->ar_failed;
@@ -1056,6 +1163,12 @@ struct ftcf_batcher {
                 e->cfg.comm->ar_failed = true;  // this communicator keeps RCCL (or the emulation) from now on
                 throw Error(-2, "batcher decode: the exchange-window all-reduce gave up waiting for a peer; the step's tokens are dropped");
             }
+        }
+        if (rows_err != 0) {
+            // a hand-off of the rows kernel ran out of its bounded wait (cannot happen with every workgroup resident; bounded all the
+            // same): the step's tokens are dropped, the batcher goes on with the per-GEMM launches
+            use_rows = false;
+            throw Error(-2, "batcher decode: the rows kernel gave up waiting for a hand-off (code " + std::to_string(rows_err) + ")");
         }
         if (gemm_err != 0) {
             // the tokens of this step are not to be trusted: nothing is reported, the slots keep their state (lengths and

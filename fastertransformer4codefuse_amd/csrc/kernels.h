@@ -333,6 +333,7 @@ size_t   rows_workspace_bytes(const RowsPlan& pl, int M, int H, int Hl, int Il, 
 size_t   rows_flag_bytes(const RowsPlan& pl, int M, int nh);
 void     rows_carve(RowsParams& p, void* workspace);  // fills the buffer pointers of p (M, H, ..., plan set)
 void     launch_decode_rows(const RowsParams& p, bool int8, hipStream_t s);
+int      rows_paged_block(int dh);  // page_tokens of a paged K/V cache must be a multiple of this
 
 // ---- fp32 instantiation (FTGptNeoX<float>, GptNeoXOp.cc:56-70) : kernels_fp32.hip ----
 struct Mmha32Params {

@@ -102,6 +102,12 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
     return pl;
 }
 
+// keys of an attention block of the rows kernel (RW_KVB wave-loads of 64 / (dh / 8) keys): a paged K/V block must lie inside one page
+int rows_paged_block(int dh)
+{
+    return RW_KVB * (64 / (dh / 8));
+}
+
 static size_t al256(size_t v)
 {
     return (v + 255) & ~(size_t)255;
@@ -175,6 +181,15 @@ static const void* rw_kernel_for(bool int8, int dh, int g1, bool paged)
     RW_SEL(false, 128, 5, false)
     RW_SEL(false, 64, 4, false)
     RW_SEL(false, 64, 5, false)
+    // paged K/V (the continuous-batching front end)
+    RW_SEL(true, 128, 4, true)
+    RW_SEL(true, 128, 5, true)
+    RW_SEL(true, 64, 4, true)
+    RW_SEL(true, 64, 5, true)
+    RW_SEL(false, 128, 4, true)
+    RW_SEL(false, 128, 5, true)
+    RW_SEL(false, 64, 4, true)
+    RW_SEL(false, 64, 5, true)
 #endif
 #undef RW_SEL
     return nullptr;
@@ -186,7 +201,7 @@ bool rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu)
     if (!pl.ok) {
         return false;
     }
-    for (int paged = 0; paged < 1; paged++) {  // (the paged form is instantiated when the batcher takes this kernel)
+    for (int paged = 0; paged < 2; paged++) {
         const void* k = rw_kernel_for(int8, dh, pl.g1, paged != 0);
         if (!k) {
             return false;
@@ -212,6 +227,8 @@ void launch_decode_rows(const RowsParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.plan.ok && p.M >= 1 && p.M <= 16, "rows kernel: shape not eligible");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255 && p.l_begin >= 0 && p.l_begin < p.l_end && p.l_end <= p.L, "bad layer range");
+    FTCF_CHECK_ARG(p.page_table == nullptr || (p.page_tokens > 0 && p.page_tokens % rows_paged_block(p.dh) == 0),
+                   "rows kernel: page_tokens must be a multiple of the attention block (16 keys at size_per_head 128, 32 at 64)");
     const void* k = rw_kernel_for(int8, p.dh, p.plan.g1, p.page_table != nullptr);
     FTCF_CHECK_ARG(k != nullptr, "rows kernel: no instantiation for this shape");
     RowsParams pp     = p;

@@ -581,14 +581,24 @@ struct RwAt {
     {
         const int j = l_x + l_X * (s + RW_NS * ls);
         if constexpr (PAGED) {
+            // a block of KB keys lies inside ONE page (rows_plan_paged(): page_tokens is a multiple of KB): its page id is a scalar
+            // load -- it does not count on vmcnt, so waiting for it does not drain the ring -- and the block's rows sit at a
+            // uniform 64-bit base + a 32-bit lane offset
+            int t0 = j * KB;
+            t0     = t0 < l_tl ? t0 : l_tl - 1;
+            const int    pg   = rw_rfl(p.page_table[(size_t)l_b * p.max_pages + t0 / p.page_tokens]);
+            const size_t base = ((size_t)pg * p.nh + l_h) * p.page_tokens * DH;  // elements (uniform)
+            const f16*   kb   = lw.k_cache + base;
+            const f16*   vb   = lw.v_cache + base;
+            const int    tp0  = (j * KB) % p.page_tokens;  // the block's first key inside its page
+            const int    lim  = l_tl - j * KB;              // keys of the block that exist (>= 1 for a block that is requested)
 #pragma unroll
             for (int i = 0; i < RW_KVB; i++) {
-                int t = j * KB + i * KPI + grp;
-                t     = t < l_tl ? t : l_tl - 1;  // clamped; masked in use()
-                const int    pg = p.page_table[(size_t)l_b * p.max_pages + t / p.page_tokens];
-                const size_t ro = (((size_t)pg * p.nh + l_h) * p.page_tokens + (t % p.page_tokens)) * DH + sub * 8;
-                q.k[i]          = __builtin_nontemporal_load(RW_GP(u32x4, lw.k_cache + ro));
-                q.v[i]          = __builtin_nontemporal_load(RW_GP(u32x4, lw.v_cache + ro));
+                int d = i * KPI + grp;
+                d     = d < lim ? d : (lim > 0 ? lim - 1 : 0);  // clamped inside the block; masked in use()
+                const unsigned vo = (unsigned)((tp0 + d) * DH + sub * 8);
+                q.k[i]            = __builtin_nontemporal_load(RW_GP(u32x4, kb + vo));
+                q.v[i]            = __builtin_nontemporal_load(RW_GP(u32x4, vb + vo));
             }
         }
         else {

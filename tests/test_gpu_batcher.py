@@ -719,3 +719,57 @@ def test_beam_requests_with_stop_words_and_min_length_in_the_batcher(gh):
         assert np.array_equal(lens, refs[name][1]), (name, lens, refs[name][1])
         np.testing.assert_allclose(cum, refs[name][2], rtol=1e-2, atol=1e-2)
     assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+
+
+@pytest.mark.parametrize("model,int8_mode,page_tokens", [("tiny", 0, 32), ("mid", 1, 16), ("mid", 0, 32)])  # (tiny: size_per_head 64, blocks of 32 keys)
+def test_the_decode_step_runs_the_rows_kernel_over_paged_kv(gh, monkeypatch, model, int8_mode, page_tokens):
+    """Round 5: with tensor_para_size 1, at most 16 slots and page_tokens a multiple of the attention block (16 keys at
+    size_per_head 128), the layers of a decode step are ONE launch of the rows kernel reading K/V through the page table
+    (csrc/rows_device.hip.h, PAGED).  Requests arriving over time -- greedy, sampled, a beam group with copy-on-write pages -- are what
+    the engine produces for each of them alone, and what the batcher produces on its per-GEMM launches (FTCF_BATCHER_ROWS=0)."""
+    from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
+    if model == "tiny":
+        cfg, w, z = load_tiny()
+        prompts = [z["prompt"].tolist(), z["prompt_b"].tolist()]
+    else:
+        cfg = dict(head_num=8, size_per_head=128, inter_size=4096, num_layer=2, vocab_size=2048, rotary_dim=32, start_id=0, end_id=2)
+        w = random_model(cfg, seed=5 + int8_mode, std=0.04)
+        prompts = []
+    V, end_id = cfg["vocab_size"], cfg["end_id"]
+    rng = np.random.RandomState(31 + page_tokens)
+    prompts += [rng.randint(3, V, size=n).tolist() for n in (23, 9, 40, 17, 5)]
+    new = [12, 20, 7, 15, 9, 11, 6][:len(prompts)]
+    op = gh.make_op(cfg, w, int8_mode=int8_mode)
+    ref = [_alone(gh, op, p, n, V, end_id)[0] for p, n in zip(prompts, new)]
+    bp, b_new, K = rng.randint(3, V, size=14).tolist(), 8, 3
+    b_ref = _beam_alone(gh, op, bp, b_new, V, K)
+    results = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("FTCF_BATCHER_ROWS", form)
+        cb = ContinuousBatcher(op, max_batch=8, page_tokens=page_tokens, num_pages=48, max_seq_len=64)
+        free0 = cb.status()["free_pages"]
+        ids, got, bid = {}, {}, None
+        arrivals = {0: [0, 1], 1: [2], 2: ["beam"], 4: [3, 4], 7: list(range(5, len(prompts)))}
+        it = 0
+        while arrivals or cb.busy():
+            for k in arrivals.pop(it, []):
+                if k == "beam":
+                    bid = cb.submit_beam(bp, b_new, K, 0.0, 0.0, 1.0, 1.0)
+                else:
+                    ids[cb.submit(prompts[k], new[k])] = k
+            for rid, tok, fin in cb.step():
+                if rid != bid:
+                    got.setdefault(ids[rid], []).append(tok)
+            if it == 3:
+                assert op.stats()["decode_path"] == (3 if form == "1" else 2)  # the layers of the last decode step
+            it += 1
+            assert it < 2000
+        results[form] = (got, cb.beam_result(bid))
+        assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+    for form, (got, beam) in results.items():
+        for k in range(len(prompts)):
+            if got[k] != ref[k]:
+                # (another summation order than the engine alone: a flip must be a near tie -- not expected on these models)
+                raise AssertionError((form, k, got[k], ref[k]))
+        assert np.array_equal(beam[0], b_ref[0]) and np.array_equal(beam[1], b_ref[1]), form
+        np.testing.assert_allclose(beam[2], b_ref[2], rtol=5e-3, atol=5e-3)
