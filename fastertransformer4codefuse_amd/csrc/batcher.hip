@@ -295,7 +295,7 @@ struct ftcf_batcher {
             if (rows_env && e->rows && e->cfg.tensor_para_size == 1 && !e->fp32 && max_batch <= 16 && e->cfg.use_gptj_residual && L <= 255
                 && (e->dh == 64 || e->dh == 128) && P % rows_paged_block(e->dh) == 0) {
                 rplan = rows_plan(max_batch, H, hl, il, e->nhl, e->dh, 1, e->int8, e->num_cu, 0);
-                if (rplan.ok && rows_resident(rplan, e->int8, e->dh, e->num_cu)) {
+                if (rplan.ok && rows_resident(rplan, e->int8, e->dh, e->num_cu, true)) {
                     rows_ws   = dmalloc<char>(rows_workspace_bytes(rplan, max_batch, H, hl, il, e->nhl, e->dh));
                     d_rlayers = dmalloc<PersistLayer>(L);
                     d_rot     = dmalloc<float>(B * std::max(1, e->cfg.rotary_embedding_dim));

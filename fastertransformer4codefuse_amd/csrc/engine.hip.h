@@ -323,7 +323,7 @@ struct ftcf_gptneox {
                     nb = std::max(1, (nb > 0 ? nb : num_cu) / tpn);
                 }
                 rplan = rows_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb);
-                if (rplan.ok && !rows_resident(rplan, int8, dh, num_cu)) {
+                if (rplan.ok && !rows_resident(rplan, int8, dh, num_cu, false)) {
                     rplan = RowsPlan{};
                 }
                 if (rplan.ok) {

@@ -327,7 +327,7 @@ struct RowsParams {
     int                 page_tokens, max_pages;
 };
 RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb);
-bool     rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu);
+bool     rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu, bool paged);  // (the K/V form the caller will launch)
 // bytes of the hand-off region (flags first: rows_flag_bytes() of it must be zero when a request begins) and its carve
 size_t   rows_workspace_bytes(const RowsPlan& pl, int M, int H, int Hl, int Il, int nh, int dh);
 size_t   rows_flag_bytes(const RowsPlan& pl, int M, int nh);

@@ -94,7 +94,7 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
     pl.NB = NB;
     const int Hp = (H + 511) & ~511;
     pl.smem      = (size_t)4 * Hp * 2 + (size_t)2 * RW_NS * RW_G * 256 * 4 + (size_t)RW_UMAX * RW_NS * (dh + RW_PA) * 4
-              + (size_t)RW_NW * RW_UMAX * 2 * dh * 2 + 32 * 4 + 512 * 4 + RW_UMAX * 8 * 4 + 64;
+              + (size_t)RW_NW * RW_UMAX * 2 * dh * 2 + 32 * 4 + 512 * 4 + RW_UMAX * 8 * 4 + 256 * 4 + 64;
     if (pl.smem > 160 * 1024) {
         return pl;
     }
@@ -196,30 +196,25 @@ static const void* rw_kernel_for(bool int8, int dh, int g1, bool paged)
 }
 
 // every workgroup of the grid must be resident at once (the hand-offs spin): asked once per plan, like persist_resident()
-bool rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu)
+bool rows_resident(const RowsPlan& pl, bool int8, int dh, int num_cu, bool paged)
 {
     if (!pl.ok) {
         return false;
     }
-    for (int paged = 0; paged < 2; paged++) {
-        const void* k = rw_kernel_for(int8, dh, pl.g1, paged != 0);
-        if (!k) {
-            return false;
-        }
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, RW_NT, pl.smem) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        if (per_cu < 1 || (long)per_cu * num_cu < pl.NB) {
-            return false;
-        }
+    const void* k = rw_kernel_for(int8, dh, pl.g1, paged);
+    if (!k) {
+        return false;
     }
-    return true;
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, RW_NT, pl.smem) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return per_cu >= 1 && (long)per_cu * num_cu >= pl.NB;
 }
 
 void launch_decode_rows(const RowsParams& p, bool int8, hipStream_t s)

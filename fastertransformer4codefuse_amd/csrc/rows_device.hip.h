@@ -158,6 +158,34 @@ __device__ __forceinline__ void rw_poll(const __amdgpu_buffer_rsrc_t r, const in
         }
     }
 }
+// ... the same for the n <= 256 flags whose indices sit in the LDS list `idx`
+__device__ __forceinline__ void rw_poll_list(const __amdgpu_buffer_rsrc_t r, const int off, const int* idx, const int n, const unsigned tag,
+                                             const int lane, int* err, const int code)
+{
+    int id[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = k * 64 + lane;
+        id[k]       = idx[i < n ? i : n - 1];
+    }
+    int spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k * 64 < n) {  // (uniform)
+                ok &= (int)(rw_ld4(r, id[k] * 4, off) - tag) >= 0;
+            }
+        }
+        if (__all(ok)) {
+            break;
+        }
+        if (rw_give_up(spins, err, code)) {
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 // a wave waits until the LDS word has reached `target`
 __device__ __forceinline__ void rw_lds_wait(const int* w, const int target, int* err, const int code)
 {
@@ -252,6 +280,7 @@ struct RwSmem {
     float* stat;   // [16][2] mean, rstd of the layer input's rows
     float* scr;    // [512] scratch of the control wave
     int*   unit;   // [UMAX][8] {cached keys (-1: no such pair), row, head, input length, current token attended, -, -, -}
+    int*   lst;    // [256] flags the control wave waits for before the attention (indices of workgroups)
     int*   sync;   // [0] go, [1..2] partial sums written (per buffer), [3] attention partials written
 };
 
@@ -944,6 +973,8 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
         q += 512 * 4;
         s.unit = reinterpret_cast<int*>(q);
         q += RW_UMAX * 8 * 4;
+        s.lst = reinterpret_cast<int*>(q);
+        q += 256 * 4;
         s.sync = reinterpret_cast<int*>(q);
     }
     auto stamp = [&](const int l, const int slot) {
@@ -1139,6 +1170,50 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
                          (unsigned)rw_rfl((int)(gb_lds + (unsigned)((a0 + 1) * Hp * 2 + c * 1024))));
         }
     };
+    // What this workgroup's NEXT stream really needs, instead of every workgroup's flag (a global wait couples the stream to the chip's
+    // slowest workgroup three times per layer):
+    //   listA -- before the attention: the owners of the q | k | v column groups of this workgroup's (row, head) pairs;
+    //   FFN2 needs the mid columns of its K piece: a contiguous range of FFN1 owners (no list);
+    //   out-proj keeps the wait for every pair's context: the owners of the heads inside its K piece alone (160 flags by list)
+    //   were measured 5 us per layer SLOWER (3650 against 3445 us per launch; profiles/r05_notes.md).
+    // owner of column group g when NG groups are dealt in contiguous ranges (rw_group_begin): floor(((g + 1) NB - 1) / NG)
+    auto owner = [&](const int g, const int NG) { return (int)((((long)g + 1) * NB - 1) / NG); };
+    int nA = 0;
+    {
+        int* lA = s.lst;
+        // listA (U <= 4 pairs x three ranges of DH / 16 groups)
+        bool okA = U > 0;
+        for (int u = 0; u < U && okA; u++) {
+            const int h = s.unit[u * 8 + 2];
+            for (int part = 0; part < 3 && okA; part++) {
+                const int g0 = (part * Hl + h * DH) / 16, g1 = g0 + DH / 16 - 1;
+                const int w0 = owner(g0, NGq), w1 = owner(g1, NGq);
+                if (nA + (w1 - w0 + 1) > 256) {
+                    okA = false;
+                    break;
+                }
+                for (int w = w0 + lane; w <= w1; w += 64) {
+                    lA[nA + w - w0] = w;
+                }
+                nA += w1 - w0 + 1;
+            }
+        }
+        if (!okA) {
+            nA = 0;  // (the full poll)
+        }
+        rw_lds_fence();
+    }
+    // FFN2's K piece [k2a, k2b) k-steps = mid columns [k2a KS, k2b KS): FFN1 column groups and their owners
+    int fm_lo = (has2 && k2b > k2a) ? owner((k2a * KS) / 16, NGf) : 0;
+    int fm_hi = (has2 && k2b > k2a) ? owner((k2b * KS - 1) / 16, NGf) : -1;
+    // (A/B switches: every workgroup's flag instead)
+#ifdef RW_FULL_POLL_A
+    nA = 0;
+#endif
+#ifdef RW_FULL_POLL_F
+    fm_lo = 0;
+    fm_hi = NB - 1;
+#endif
     for (int l = p.l_begin; l < p.l_end; l++) {
         const PersistLayer& lw  = p.layers[l];
         const unsigned      tag = tag_base + (unsigned)l;
@@ -1213,7 +1288,12 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             ln_dma(p.layers[l + 1].ln1_g, p.layers[l + 1].ln1_b, 0);
         }
         // q | k | v of every producer (they travel under the FFN1 stream): the attention may start
-        rw_poll(r_ws, (int)p.o_fq, NB, tag, lane, p.err, 2);
+        if (nA > 0) {
+            rw_poll_list(r_ws, (int)p.o_fq, s.lst, nA, tag, lane, p.err, 2);
+        }
+        else if (U > 0) {
+            rw_poll(r_ws, (int)p.o_fq, NB, tag, lane, p.err, 2);
+        }
         rw_lds_set(&s.sync[0], li * RW_PHASES + 2, lane);
         stamp(l, 4);
         // ---- FFN1: mid = gelu(. + bias) ----
@@ -1244,7 +1324,9 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             ln_dma(p.layers[l + 1].ln2_g, p.layers[l + 1].ln2_b, 2);
         }
         // mid of every producer (it travels under the attention): FFN2 may start
-        rw_poll(r_ws, (int)p.o_fm, NB, tag, lane, p.err, 3);
+        if (fm_hi >= fm_lo) {
+            rw_poll(r_ws, (int)p.o_fm + fm_lo * 4, fm_hi - fm_lo + 1, tag, lane, p.err, 3);
+        }
         rw_lds_set(&s.sync[0], li * RW_PHASES + 3, lane);
         stamp(l, 6);
         // ---- the streamers' attention partials -> ctx of this workgroup's pairs, merged in wave order
