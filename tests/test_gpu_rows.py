@@ -110,3 +110,23 @@ def test_rows_kernel_with_sampling_and_finished_rows(gh):
     greedy = [0, 2, 5]
     for b in greedy:
         assert r1["output_ids"][b].tolist() == o["output_ids"][b].tolist()
+
+
+def test_rows_kernel_with_long_ragged_contexts_on_few_workgroups(gh, monkeypatch):
+    """Sixteen rows of up to 300 cached keys on 52 workgroups (FTCF_ROWS_NB): two whole (row, head) pairs + a third on 24 of them, 19
+    key blocks per pair -- the K/V ring's steady rotations across a workgroup's pairs, padded (ragged) prompts and the padding-key
+    mask, out-proj / FFN2 K pieces of an odd size -- against the oracle, and bit-identical when repeated."""
+    cfg = MID
+    B, S, out = 16, 300, 4
+    monkeypatch.setenv("FTCF_ROWS_NB", "52")
+    w = random_model(cfg, seed=123, std=0.04)
+    layers, glob = weight_list_to_layers(cfg, w)
+    layers = quantize_layers(layers)
+    ids, lens = _batch(cfg, B, S, 41)
+    op = gh.make_op(cfg, w, int8_mode=1)
+    r = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
+    assert op.stats()["decode_path"] == 3
+    r2 = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
+    assert np.array_equal(r["logits"], r2["logits"]) and np.array_equal(r["output_ids"], r2["output_ids"])
+    o = orc.Model(dict(cfg, fp16=1, int8_mode=1), layers, glob).generate(ids, lens, out, return_logits=True)
+    _follows(r, o, lens, out)
