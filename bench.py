@@ -453,6 +453,12 @@ def main():
                                                 "ran_in_the_last_request": bool(st.get("prefill_overlap", 0)),
                                                 "trial_ms_plain": st.get("prefill_ms_plain", 0.0),
                                                 "trial_ms_overlapped": st.get("prefill_ms_overlapped", 0.0)},
+                            # batched decode (4..32 rows): the layer's all-reduce on the side stream under the other micro-batch
+                            # (engine.hip.h decoder_overlapped; auto = one plain and one overlapped request timed on THIS node)
+                            "decode_overlap": {"mode": os.environ.get("FTCF_DECODE_OVERLAP", "auto" if world > 1 else "off"),
+                                               "ran_in_the_last_request": bool(st.get("decode_overlap", 0)),
+                                               "trial_step_ms_plain": st.get("decode_step_ms_plain", 0.0),
+                                               "trial_step_ms_overlapped": st.get("decode_step_ms_overlapped", 0.0)},
                             "prompt_phase_allreduces_through_windows": st.get("window_allreduces", 0),
                             "fallback": fallback_note},
     }

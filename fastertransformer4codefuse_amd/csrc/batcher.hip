@@ -2,6 +2,7 @@
 #include "engine.hip.h"
 #include "attn_device.hip.h"  // rotary_coef (the rows kernel's rotary table of a step)
 
+#include <chrono>
 #include <set>
 
 
@@ -187,7 +188,7 @@ struct ftcf_batcher {
     float*        d_rot = nullptr;
     int*          d_rstep = nullptr;
     unsigned      rows_steps = 0;
-    size_t       smallm_partial = 0;
+    size_t       smallm_partial = 0, smallm_region = 0;
     unsigned     smallm_seq = 0;
     long         gemm_steps = 0;
     std::vector<void*> owned;
@@ -327,11 +328,14 @@ struct ftcf_batcher {
                 }
             }
         }
-        if (max_batch > 4 && max_batch <= e->SMALLM_MAX_ROWS) {
+        // (tensor parallel: up to 32 slots as two micro-batches of <= 16 rows with their own split-K regions -- the decode overlap)
+        if (max_batch > 4 && (max_batch <= e->SMALLM_MAX_ROWS || (e->cfg.tensor_para_size > 1 && max_batch <= 32))) {
             const bool i8 = e->int8;
             const int  bc = std::min(max_batch, 16);  // 16 rows per launch
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, i8) + gemm_smallm_workspace_bytes(bc, il, H, i8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, i8) + gemm_smallm_workspace_bytes(bc, H, il, i8);
+            smallm_region  = smallm_partial;
+            smallm_partial *= e->cfg.tensor_para_size > 1 ? 2 : 1;
             smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
         }
         if (max_batch > 16 && max_batch <= 320) {
@@ -940,6 +944,54 @@ struct ftcf_batcher {
         }
     }
 
+    // Which form the next decode step's layers take under tensor parallelism.  Forced by FTCF_DECODE_OVERLAP = 0 / 1; "auto"
+    // (the default for ranks joined by RCCL): decode steps 4..19 of this batcher run plain, 20..35 overlapped, each timed from
+    // enqueue to the step's stream synchronisation on the host; after step 35 every rank learns the slowest rank's two sums
+    // (comm_max; the ranks' batchers run the same steps) and the batcher stays with the faster form.
+    long   ov_steps = 0;
+    double ov_us[2] = {0.0, 0.0};
+    int    ov_choice = -1;  // -1 undecided, 0 plain, 1 overlapped
+    bool   ov_auto = false, ov_last = false;
+    bool decode_overlap_now(int B, bool dual)
+    {
+        ftcf_gptneox* g  = e;
+        const char*   ev = getenv("FTCF_DECODE_OVERLAP");
+        ov_auto = (!ev || !strcmp(ev, "auto")) && g->cfg.tensor_para_size > 1 && g->cfg.comm && g->cfg.comm->comm && !g->cfg.comm->local
+                  && !g->cfg.comm->hx && g->cfg.comm->world > 1;
+        const int env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
+        ov_last = false;
+        if (g->cfg.tensor_para_size == 1 || !dual || !smallm_ws || smallm_partial < 2 * smallm_region || !g->side || B < 4 || B > 32
+            || (!env && !ov_auto)) {
+            ov_auto = false;
+            return false;
+        }
+        if (ov_auto) {
+            ov_last = ov_choice >= 0 ? ov_choice == 1 : (ov_steps >= 20 && ov_steps < 36);
+        }
+        else {
+            ov_last = true;
+        }
+        return ov_last;
+    }
+    void decode_overlap_trial(double us, hipStream_t st)
+    {
+        if (!ov_auto || ov_choice >= 0) {
+            return;
+        }
+        if (ov_steps >= 4 && ov_steps < 36) {
+            ov_us[ov_steps >= 20 ? 1 : 0] += us;
+        }
+        ov_steps++;
+        if (ov_steps == 36 && e->tp_scratch) {
+            const int a = comm_max(e->cfg.comm, (int)ov_us[0], st, e->tp_scratch), b = comm_max(e->cfg.comm, (int)ov_us[1], st, e->tp_scratch);
+            ov_choice = b < a ? 1 : 0;
+            e->stats.decode_step_ms_plain      = a * 1e-3f / 16.f;
+            e->stats.decode_step_ms_overlapped = b * 1e-3f / 16.f;
+            FT_LOG_INFO(e->cfg.device, "batcher: decode all-reduce overlap (auto): plain %.3f ms per step, overlapped %.3f -> %s", a * 1e-3 / 16,
+                        b * 1e-3 / 16, ov_choice ? "overlapped from now on" : "plain from now on");
+        }
+    }
+
     // one token for every running slot
     void decode(std::vector<Event>& ev)
     {
@@ -994,7 +1046,65 @@ struct ftcf_batcher {
             rp.max_pages = max_pages;
             launch_decode_rows(rp, int8, st);
         }
-        for (int l = 0; l < (use_rows ? 0 : L); l++) {
+        // tensor parallel, 4..32 slots: the layer's all-reduce on the side stream under the other micro-batch's launches (the
+        // engine's decoder_overlapped, engine.hip.h, on the paged cache; FTCF_DECODE_OVERLAP = 0 / 1, auto = timed on this node)
+        const bool overlap = !use_rows && decode_overlap_now(B, dual);
+        const auto t_dec0  = std::chrono::steady_clock::now();
+        if (overlap) {
+            e->decode_overlap_streams();
+            const int         r0[2] = {0, (B + 1) / 2}, r1[2] = {(B + 1) / 2, B};
+            const hipStream_t cs[2] = {st, e->side2};
+            FTCF_HIP_CHECK(hipEventRecord(e->dv_fork[0], st));
+            FTCF_HIP_CHECK(hipStreamWaitEvent(e->side2, e->dv_fork[0], 0));
+            for (int l = 0; l < L; l++) {
+                const LayerWeights& w = e->layers[l];
+                for (int c = 0; c < 2; c++) {
+                    const int         M  = r1[c] - r0[c];
+                    const size_t      o  = (size_t)r0[c], wo = (size_t)c * smallm_region;
+                    const hipStream_t s2 = cs[c];
+                    f16*              xr = x + o * H;
+                    if (l > 0) {
+                        FTCF_HIP_CHECK(hipStreamWaitEvent(s2, e->dv_red[c], 0));
+                    }
+                    launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
+                                            nrm2 + o * H, M, H, 1e-5f, s2);
+                    MmhaPagedParams mp{};
+                    mp.qkv = qkv + o * 3 * hl;
+                    mp.qkv_bias = w.qkv.bias;
+                    mp.kpool = kpool + (size_t)l * pool_layer_elems;
+                    mp.vpool = vpool + (size_t)l * pool_layer_elems;
+                    mp.page_table = d_pt + o * max_pages;
+                    mp.len = d_len + o;
+                    mp.finished = d_fin + o;
+                    mp.B = M;
+                    mp.nh = e->nhl;
+                    mp.dh = e->dh;
+                    mp.rot = e->cfg.rotary_embedding_dim;
+                    mp.P = P;
+                    mp.max_pages = max_pages;
+                    mp.ctx = ctx + o * hl;
+                    const SmallmDesc p1[2] = {{nrm + o * H, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv + o * 3 * hl, 3 * hl, H},
+                                              {nrm2 + o * H, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid + o * il, il, H}};
+                    launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, M, int8, s2, &d_gstate->step, &smallm_seq, wo);
+                    launch_mmha_paged(mp, max_len, s2);
+                    const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att + o * H, H, hl},
+                                              {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn + o * H, H, il}};
+                    launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, M, int8, s2, &d_gstate->step, &smallm_seq, wo);
+                    launch_add_bias_attn_ffn_residual(xr, ffn + o * H, att + o * H, xr, w.ffn2.bias, M, H, tp, (l > 0 && l < L - 1) ? 1 : 0,
+                                                      true, s2);
+                    FTCF_HIP_CHECK(hipEventRecord(e->dv_done[c], s2));
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->dv_done[c], 0));
+                    e->allreduce(xr, (size_t)M * H, e->side);
+                    FTCF_HIP_CHECK(hipEventRecord(e->dv_red[c], e->side));
+                }
+            }
+            FTCF_HIP_CHECK(hipEventRecord(e->dv_fork[1], e->side2));
+            FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->dv_fork[1], 0));
+            for (int c = 0; c < 2; c++) {
+                FTCF_HIP_CHECK(hipStreamWaitEvent(st, e->dv_red[c], 0));
+            }
+        }
+        for (int l = 0; l < (use_rows || overlap ? 0 : L); l++) {
             const LayerWeights& w = e->layers[l];
             if (!dual) {
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
@@ -1155,6 +1265,8 @@ struct ftcf_batcher {
             FTCF_HIP_CHECK(hipMemcpyAsync(&ar_err, e->cfg.comm->ar_sync + 2, sizeof(int), hipMemcpyDeviceToHost, st));
         }
         FTCF_HIP_CHECK(hipStreamSynchronize(st));
+        decode_overlap_trial(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_dec0).count(), st);
+        e->stats.decode_overlap = overlap ? 1 : 0;
         if (ar_live && e->tp_scratch) {
             // (collective: every rank's batcher runs the same step and has called the window all-reduce as often; all of them learn
             //  of any rank's failure and drop the step)

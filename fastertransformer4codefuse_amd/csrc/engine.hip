@@ -550,6 +550,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
     ses.e0 = e0;
     ses.e1 = e1;
     stats.decode_ms = 0.f;
+    dv_ran = dv_eligible = false;
 }
 
 // enqueues one iteration of the token loop (GptNeoX.cc:776-1048) on `stream` (and the side stream)
@@ -642,7 +643,8 @@ int ftcf_gptneox::step(int max_steps)
         const bool with_decoder = !(S > 1 && step == S);
         // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
         // has been validated on a multi-GPU node (this round's boxes have one GPU)
-        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local && !cfg.comm->hx)) && !a.debug_logits;
+        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local && !cfg.comm->hx)) && !a.debug_logits
+                                  && !(tp > 1 && decode_overlap_wanted(ses.B));
         // Several tokens per graph launch (FTCF_GRAPH_TOKENS, default 8): a graph launch costs ~14 us of GPU idle time between
         // two tokens (profiles/r03_notes.md section 6), and every kernel of a persistent-path token returns at once when the
         // device-side "every row has finished" flag is set, so the tokens of a graph behind the request's last one cost a few
@@ -788,6 +790,18 @@ void ftcf_gptneox::finish()
                         ov_ms[1] < ov_ms[0] ? "overlapped from now on" : "plain from now on");
         }
     }
+    if (dv_eligible && dv_trial < 2 && ses.steps > 0) {  // a trial of the decode overlap's auto mode (engine.hip.h decoder_overlapped)
+        const int us = comm_max(cfg.comm, (int)(stats.decode_ms * 1000.f / ses.steps), stream, tp_scratch);
+        dv_ms[dv_trial] = us * 1e-3f;
+        dv_trial++;
+        if (dv_trial == 2) {
+            FT_LOG_INFO(cfg.device, "decode all-reduce overlap (auto): plain %.3f ms per step, overlapped %.3f -> %s", dv_ms[0], dv_ms[1],
+                        dv_ms[1] < dv_ms[0] ? "overlapped from now on" : "plain from now on");
+        }
+    }
+    stats.decode_overlap            = dv_ran ? 1 : 0;
+    stats.decode_step_ms_plain      = dv_ms[0];
+    stats.decode_step_ms_overlapped = dv_ms[1];
     stats.prefill_overlap        = ov_ran ? 1 : 0;
     stats.prefill_ms_plain       = ov_ms[0];
     stats.prefill_ms_overlapped  = ov_ms[1];

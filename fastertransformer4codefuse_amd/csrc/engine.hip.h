@@ -67,7 +67,7 @@ struct ftcf_gptneox {
     hipStream_t               stream = nullptr, user_stream = nullptr;
     // second stream of the batched decode layer: [QKV -> MMHA -> out-proj] on `stream`, [FFN1 -> FFN2] here (fork / join by
     // events; under capture the branch becomes a parallel branch of the token's hipGraph)
-    hipStream_t               side = nullptr;
+    hipStream_t               side = nullptr, side2 = nullptr;  // (side2: the second micro-batch of decoder_overlapped)
     hipEvent_t                ev_fork = nullptr, ev_join = nullptr;
     // batched decode GEMMs: 1 = the attention branch and the FFN branch on two streams, 0 = one stream, the independent GEMMs
     // paired per launch.  Default: two streams at tensor_para_size 1 (the launches are bandwidth bound and fill each other's ramps:
@@ -102,7 +102,7 @@ struct ftcf_gptneox {
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
     float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..320 rows (short prompt phases)
-    size_t    smallm_partial = 0;
+    size_t    smallm_partial = 0, smallm_region = 0;  // (all of the partial sums; one set of four GEMM regions)
     unsigned  smallm_seq = 0;       // launch counter: part of the granule tag of its in-launch reduction
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
     int *  tiled_ids = nullptr, *tiled_len = nullptr, *parent_ids = nullptr, *cache_indir = nullptr;
@@ -160,6 +160,16 @@ struct ftcf_gptneox {
                     (void)hipEventDestroy(ov_done[c]);
                     (void)hipEventDestroy(ov_red[c]);
                 }
+            }
+            for (int c = 0; c < 2; c++) {
+                if (dv_done[c]) {
+                    (void)hipEventDestroy(dv_done[c]);
+                    (void)hipEventDestroy(dv_red[c]);
+                    (void)hipEventDestroy(dv_fork[c]);
+                }
+            }
+            if (side2) {
+                (void)hipStreamDestroy(side2);
             }
             if (side) {
                 (void)hipStreamDestroy(side);
@@ -339,10 +349,13 @@ struct ftcf_gptneox {
             // (a prompt phase of up to SMALLM_MAX_ROWS tokens in all is HBM bound like a decode step: it takes the same kernel)
             const int  bc         = 16;
             const long prefill_m  = S > 1 ? (long)(B / K) * S : 0;
-            const bool decode_ws  = B > STAGE_MAX_ROWS && B <= SMALLM_MAX_ROWS;
+            // (tensor parallel: up to 32 rows as two micro-batches of <= 16, each with its own regions -- decoder_overlapped)
+            const bool decode_ws  = B > STAGE_MAX_ROWS && (B <= SMALLM_MAX_ROWS || (cfg.tensor_para_size > 1 && B <= 32));
             const bool prefill_ws = prefill_m > 4 && prefill_m <= SMALLM_MAX_ROWS;
             smallm_partial = gemm_smallm_workspace_bytes(bc, 3 * hl, H, int8) + gemm_smallm_workspace_bytes(bc, il, H, int8)
                              + gemm_smallm_workspace_bytes(bc, H, hl, int8) + gemm_smallm_workspace_bytes(bc, H, il, int8);
+            smallm_region  = smallm_partial;
+            smallm_partial *= cfg.tensor_para_size > 1 ? 2 : 1;
             smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
             const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= 320);
             tiled_ws              = (!fp32 && tiled_rows) ? c.take<float>(gemm_tiled_workspace_bytes() / 4) : nullptr;
@@ -924,6 +937,9 @@ struct ftcf_gptneox {
             }
             return;
         }
+        if (!staged && decoder_overlapped(B, s_max)) {
+            return;
+        }
         for (int l = 0; l < L; l++) {
             const LayerWeights& w = layers[l];
             // layer_input/output alias for 0 < l < L-1 in the reference (:249-250) -> which residual form it runs
@@ -1039,6 +1055,120 @@ struct ftcf_gptneox {
             }
             allreduce(x, (size_t)B * H);
         }
+    }
+
+    // Batched decode under tensor parallelism with the layer's all-reduce OFF the compute stream (GptNeoXDecoder.cc:342-359 runs it
+    // in line).  A parallel-residual layer has ONE reduction, of x' = x + attn + ffn, and everything of the next layer depends on
+    // it: the only independent work is another row's.  So the batch is cut in two micro-batches of <= 16 rows that walk the
+    // layers on TWO compute streams, independent of each other from the token's embedding to its final LayerNorm; micro-batch c
+    // hands x' to the comm stream by event and waits for the reduced x' by event before its next layer, so c's reduction runs
+    // under (1 - c)'s GEMMs / attention -- and, this path being bound by the latency of dependent launches rather than by bytes
+    // (a TP 8 shard's layer at 16 rows: six launches, 43 us, 39 MB), one micro-batch's launch gaps are filled by the other's
+    // kernels.  Each micro-batch reads the layer's weight shard once: for 17..32 rows that is what the chunked GEMMs do anyway, for
+    // 4..16 rows it doubles the weight bytes.  All reductions sit on ONE stream in the order c = 0, 1, 0, 1, ...: the window
+    // all-reduce's flag words and RCCL see a serial sequence, identical on every rank.  Row-wise arithmetic is that of the loop
+    // below (the burst GEMM's K slices do not depend on the row count; the micro-batches' GEMMs have their own split-K regions), so
+    // the tokens are bit-identical to the un-overlapped path (tests/test_gpu_tp_local.py, test_gpu_tp_process.py).
+    // FTCF_DECODE_OVERLAP = 0 / 1 forces it; unset or "auto" (ranks joined by RCCL): the first eligible request's token loop runs
+    // plain, the second one overlapped, every rank keeps the slowest rank's ms per step (comm_max in finish()) and the engine
+    // stays with the faster form -- what an all-reduce over xGMI hides can only be measured on the node.
+    hipEvent_t dv_done[2] = {nullptr, nullptr}, dv_red[2] = {nullptr, nullptr}, dv_fork[2] = {nullptr, nullptr};
+    int        dv_trial = 0;
+    float      dv_ms[2] = {0.f, 0.f};  // ms per decode step of the two trials (the slowest rank's)
+    bool       dv_ran = false, dv_eligible = false;
+    bool decode_overlap_shape(int B) const
+    {
+        return cfg.tensor_para_size > 1 && !fp32 && ses.K == 1 && cfg.use_gptj_residual && residual_dual_ln_supported(H) && side
+               && smallm_ws && smallm_partial >= 2 * smallm_region && B >= 4 && B <= 2 * 16 && !pplan.ok && !rplan.ok;
+    }
+    void decode_overlap_streams()
+    {
+        if (!side2) {
+            FTCF_HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+        }
+        for (int c = 0; c < 2; c++) {
+            if (!dv_done[c]) {
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&dv_done[c], hipEventDisableTiming));
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&dv_red[c], hipEventDisableTiming));
+                FTCF_HIP_CHECK(hipEventCreateWithFlags(&dv_fork[c], hipEventDisableTiming));
+            }
+        }
+    }
+    // (no side effects: step() asks it too -- the three-stream form is enqueued eagerly, not captured into the token's hipGraph:
+    // a capture of it with FTCF_TP_GRAPH=1 aborted inside the runtime on the one-rank RCCL communicator of `bench.py --fake-tp`)
+    bool decode_overlap_wanted(int B, bool* auto_trial = nullptr) const
+    {
+        const char* ev  = getenv("FTCF_DECODE_OVERLAP");
+        const bool  aut = (!ev || !strcmp(ev, "auto")) && cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->comm && !cfg.comm->local
+                         && !cfg.comm->hx && cfg.comm->world > 1;
+        const int   env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
+        if ((!env && !aut) || !decode_overlap_shape(B)) {
+            return false;
+        }
+        if (auto_trial) {
+            *auto_trial = aut;
+        }
+        return !aut || dv_trial == 1 || (dv_trial == 2 && dv_ms[1] < dv_ms[0]);
+    }
+    bool decoder_overlapped(int B, int s_max)
+    {
+        bool aut = false;
+        const bool want = decode_overlap_wanted(B, &aut);
+        dv_eligible = aut;
+        if (!want) {
+            return false;
+        }
+        Range r("ftcf.GptNeoXDecoder.overlapped");
+        dv_ran = true;
+        decode_overlap_streams();
+        const double      wbytes = int8 ? 1.0 : 2.0;
+        const int         r0[2] = {0, (B + 1) / 2}, r1[2] = {(B + 1) / 2, B};
+        const hipStream_t cs[2] = {stream, side2};
+        // what is on the engine stream so far (embedding rows, the step's state) happens-before both micro-batches
+        FTCF_HIP_CHECK(hipEventRecord(dv_fork[0], stream));
+        FTCF_HIP_CHECK(hipStreamWaitEvent(side2, dv_fork[0], 0));
+        for (int l = 0; l < L; l++) {
+            const LayerWeights& w = layers[l];
+            const int inplace = (l > 0 && l < L - 1) ? 1 : 0;
+            for (int c = 0; c < 2; c++) {
+                const int         M  = r1[c] - r0[c];
+                const size_t      o  = (size_t)r0[c], wo = (size_t)c * smallm_region;
+                const hipStream_t st = cs[c];
+                f16*              xr = x + o * H;
+                if (l > 0) {
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(st, dv_red[c], 0));  // this micro-batch's x has been reduced
+                }
+                launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
+                                        nrm2 + o * H, M, H, 1e-5f, st);
+                MmhaParams mp = mmha_params(l, w, B, s_max, r0[c], M, l);
+                // [QKV, FFN1] -> MMHA -> [out-proj, FFN2], independent GEMMs in one launch (as the loop below)
+                const SmallmDesc p1[2] = {{nrm + o * H, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv + o * 3 * hl, 3 * hl, H},
+                                          {nrm2 + o * H, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid + o * il, il, H}};
+                timed(KIND_SMALLM, wbytes * H * (3.0 * hl + il), [&] {
+                    launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, M, int8, st, &state->step, &smallm_seq, wo);
+                }, st);
+                launch_mmha(mp, st);
+                const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att + o * H, H, hl},
+                                          {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn + o * H, H, il}};
+                timed(KIND_SMALLM, wbytes * H * ((double)hl + il), [&] {
+                    launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, M, int8, st, &state->step, &smallm_seq, wo);
+                }, st);
+                launch_add_bias_attn_ffn_residual(xr, ffn + o * H, att + o * H, xr, w.ffn2.bias, M, H, cfg.tensor_para_size, inplace,
+                                                  true, st);
+                FTCF_HIP_CHECK(hipEventRecord(dv_done[c], st));
+                FTCF_HIP_CHECK(hipStreamWaitEvent(side, dv_done[c], 0));
+                allreduce(xr, (size_t)M * H, side);
+                FTCF_HIP_CHECK(hipEventRecord(dv_red[c], side));
+            }
+        }
+        // join: both micro-batches' last reductions, and the second compute stream itself (its last wait is for dv_red[1] of layer
+        // L - 2: nothing of it is left running behind dv_red[1] of the last layer, but a capture wants every fork joined)
+        FTCF_HIP_CHECK(hipEventRecord(dv_fork[1], side2));
+        FTCF_HIP_CHECK(hipStreamWaitEvent(stream, dv_fork[1], 0));
+        for (int c = 0; c < 2; c++) {
+            FTCF_HIP_CHECK(hipStreamWaitEvent(stream, dv_red[c], 0));
+        }
+        return true;
     }
 
     // Rows up to which the per-stage GEMV launches run (when the persistent kernel is not eligible).  Measured at 13B int8,

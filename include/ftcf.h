@@ -216,6 +216,11 @@ typedef struct {
     /* all-reduces of the last request that went through the peer-mapped exchange windows instead of RCCL (the two-shot kernel
      * for prompt-phase messages; FTCF_TP_WINAR=0 switches it off, FTCF_TP_WINAR_MB sizes its buffers: 16) */
     int   window_allreduces;
+    /* tensor parallel, batched decode (4..32 rows on the general path): did the last request run the layer's all-reduce on the
+     * side stream under the other micro-batch's launches (FTCF_DECODE_OVERLAP = 1, or chosen by the auto mode), and the auto
+     * mode's two trials (ms per decode step, plain / overlapped, the slowest rank's; 0 until that trial has run) */
+    int   decode_overlap;
+    float decode_step_ms_plain, decode_step_ms_overlapped;
 } ftcf_forward_stats;
 
 int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gptneox_weights* w, ftcf_gptneox_t* out);

@@ -352,14 +352,17 @@ def test_decode_steps_inside_an_admission_use_the_running_slots_sampling_paramet
     assert len(out[g1]) <= 6 and g0 in out
 
 
-@pytest.mark.parametrize("tp,max_batch", [(2, 3), (2, 6), (4, 3)])
-def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch):
+@pytest.mark.parametrize("tp,max_batch,overlap", [(2, 3, 0), (2, 6, 0), (4, 3, 0), (2, 6, 1), (2, 19, 1), (4, 8, 1)])
+def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, monkeypatch, tp, max_batch, overlap):
     """Tensor parallelism inside the batcher (round 4; the reference's serving layer runs TP through its Triton backend,
     triton_backend/gptneox/GptNeoXTritonModelInstance.cc): one batcher per rank over its shard, fed the same requests in the
     same order -- the schedulers take identical decisions, the decode step's per-layer all-reduce and the vocabulary-split LM
     head are the engine's collectives.  The ranks are threads of a local group on this one GPU (tests/test_gpu_tp_local.py);
-    every rank must emit the same events, and every request what the TP = 1 engine generates for it alone."""
+    every rank must emit the same events, and every request what the TP = 1 engine generates for it alone.
+    overlap = 1 (round 5): the decode step's layers as two micro-batches of slots on two streams with the all-reduce on a third
+    (FTCF_DECODE_OVERLAP=1; GptNeoXDecoder.cc:342-359 has it in line) -- same events, and the stats say it ran."""
     import threading
+    monkeypatch.setenv("FTCF_DECODE_OVERLAP", str(overlap))
     from fastertransformer4codefuse_amd.batcher import ContinuousBatcher
     from fastertransformer4codefuse_amd.gptneox_op import LocalTensorParallelGroup
     from tests.helpers import shard_weights
@@ -384,7 +387,7 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
     def worker(r):
         try:
             op = gh.make_op(cfg, shard_weights(cfg, w, tp, r), tp=tp, rank=r, comm=group)
-            cb = ContinuousBatcher(op, max_batch=max_batch, page_tokens=8, num_pages=32, max_seq_len=64)
+            cb = ContinuousBatcher(op, max_batch=max_batch, page_tokens=8, num_pages=32 + 8 * max_batch, max_seq_len=64)
             free0 = cb.status()["free_pages"]
             events, ids, it, pending = [], {}, 0, dict(arrivals)
             while pending or cb.busy():
@@ -400,6 +403,7 @@ def test_tensor_parallel_batchers_follow_the_single_gpu_engine(gh, tp, max_batch
             if beam:
                 beams[r] = cb.beam_result(brid)
             assert cb.status() == {"waiting": 0, "running": 0, "free_pages": free0}
+            assert op.stats()["decode_overlap"] == (1 if overlap and max_batch >= 4 else 0)
             res[r] = events
         except BaseException as e:  # noqa: BLE001
             err.append((r, repr(e)))
