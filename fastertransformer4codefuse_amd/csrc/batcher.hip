@@ -244,9 +244,9 @@ struct ftcf_batcher {
         nrm2 = dmalloc<f16>(B * H);
         qkv = dmalloc<f16>(B * 3 * hl);
         ctx = dmalloc<f16>(B * hl);
-        att = dmalloc<f16>(B * H);
+        att = dmalloc<f16>(2 * B * H);  // [att | ffn]: one message for a tensor-parallel layer's all-reduce
+        ffn = att + B * H;
         mid = dmalloc<f16>(B * il);
-        ffn = dmalloc<f16>(B * H);
         logits = dmalloc<float>(B * V);
         // tensor parallel (every rank runs its own batcher over its shard, fed the same requests in the same order: the
         // schedulers take identical decisions, the decode step's collectives are the engine's): the LM head's [TP][B][V/TP] slices
@@ -717,6 +717,9 @@ struct ftcf_batcher {
         FTCF_HIP_CHECK(hipStreamSynchronize(st));
         const long id    = g.id;
         beam_results[id] = std::move(r);
+        while (beam_results.size() > 256) {  // (results nobody fetches do not pile up: the oldest ids go first)
+            beam_results.erase(beam_results.begin());
+        }
         release_group(si);
         if (fire_now) {
             emit(ev, Event{id, -1, 1});
@@ -1063,11 +1066,16 @@ struct ftcf_batcher {
                     const size_t      o  = (size_t)r0[c], wo = (size_t)c * smallm_region;
                     const hipStream_t s2 = cs[c];
                     f16*              xr = x + o * H;
-                    if (l > 0) {
+                    const bool pair = e->tp_pair_ar;
+                    f16* const attc = att + 2 * o * H;  // (a micro-batch's attn | ffn rows adjacent)
+                    f16* const ffnc = attc + (size_t)M * H;
+                    if (l > 0 && !pair) {
                         FTCF_HIP_CHECK(hipStreamWaitEvent(s2, e->dv_red[c], 0));
                     }
-                    launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
-                                            nrm2 + o * H, M, H, 1e-5f, s2);
+                    if (l == 0 || !pair) {
+                        launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
+                                                nrm2 + o * H, M, H, 1e-5f, s2);
+                    }
                     MmhaPagedParams mp{};
                     mp.qkv = qkv + o * 3 * hl;
                     mp.qkv_bias = w.qkv.bias;
@@ -1087,15 +1095,23 @@ struct ftcf_batcher {
                                               {nrm2 + o * H, w.ffn1.kernel, w.ffn1.scale, w.ffn1.bias, 1, mid + o * il, il, H}};
                     launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, M, int8, s2, &d_gstate->step, &smallm_seq, wo);
                     launch_mmha_paged(mp, max_len, s2);
-                    const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att + o * H, H, hl},
-                                              {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn + o * H, H, il}};
+                    const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, attc, H, hl},
+                                              {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffnc, H, il}};
                     launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, M, int8, s2, &d_gstate->step, &smallm_seq, wo);
-                    launch_add_bias_attn_ffn_residual(xr, ffn + o * H, att + o * H, xr, w.ffn2.bias, M, H, tp, (l > 0 && l < L - 1) ? 1 : 0,
-                                                      true, s2);
+                    if (!pair) {
+                        launch_add_bias_attn_ffn_residual(xr, ffnc, attc, xr, w.ffn2.bias, M, H, tp, (l > 0 && l < L - 1) ? 1 : 0, true, s2);
+                    }
                     FTCF_HIP_CHECK(hipEventRecord(e->dv_done[c], s2));
                     FTCF_HIP_CHECK(hipStreamWaitEvent(e->side, e->dv_done[c], 0));
-                    e->allreduce(xr, (size_t)M * H, e->side);
+                    e->allreduce(pair ? attc : xr, (size_t)(pair ? 2 : 1) * M * H, e->side);
                     FTCF_HIP_CHECK(hipEventRecord(e->dv_red[c], e->side));
+                    if (pair) {
+                        const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
+                        FTCF_HIP_CHECK(hipStreamWaitEvent(s2, e->dv_red[c], 0));
+                        launch_residual_dual_ln(xr, ffnc, attc, w.ffn2.bias, 1, 1, nx ? nx->ln1_g : nullptr, nx ? nx->ln1_b : nullptr,
+                                                nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm + o * H, nrm2 + o * H, M, H, 1e-5f,
+                                                s2, tp);
+                    }
                 }
             }
             FTCF_HIP_CHECK(hipEventRecord(e->dv_fork[1], e->side2));
@@ -1110,7 +1126,7 @@ struct ftcf_batcher {
                 launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, st);
                 launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, st);
             }
-            else if (l == 0 || !tp1) {
+            else if (l == 0 || (!tp1 && !e->tp_pair_ar)) {
                 launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm, nrm2, B, H,
                                         1e-5f, st);
             }
@@ -1174,7 +1190,14 @@ struct ftcf_batcher {
             }
             // (every slot's hidden state is recomputed from its token each step: the residual never aliases across steps,
             // so the fp32-sum variant of the context decoder applies to all layers)
-            if (dual && tp1) {
+            if (dual && !tp1 && e->tp_pair_ar) {
+                // attn | ffn as one all-reduce message, the residual inside the next layer's LayerNorm pass (engine.hip.h decoder)
+                e->allreduce(att, (size_t)2 * B * H, st);
+                const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
+                launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, 1, nx ? nx->ln1_g : nullptr, nx ? nx->ln1_b : nullptr,
+                                        nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H, 1e-5f, st, tp);
+            }
+            else if (dual && tp1) {
                 const LayerWeights* nx = l + 1 < L ? &e->layers[l + 1] : nullptr;
                 launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, (l > 0 && l < L - 1) ? 1 : 0, nx ? nx->ln1_g : nullptr,
                                         nx ? nx->ln1_b : nullptr, nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H,
@@ -1675,6 +1698,9 @@ extern "C" int ftcf_batcher_cancel(ftcf_batcher_t b, long request_id, int* found
                 b->release(s);
                 hit = 1;
             }
+        }
+        if (!hit && b->beam_results.erase(request_id) > 0) {  // a finished beam request whose result was never fetched
+            hit = 1;
         }
         if (found) {
             *found = hit;

@@ -1091,6 +1091,9 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
             e->decode_branches = atoi(m);
         }
         e->use_graph = cfg->use_hip_graph != 0;
+        if (const char* m = getenv("FTCF_TP_PAIR_AR")) {
+            e->tp_pair_ar = atoi(m) != 0;
+        }
         if (const char* m = getenv("FTCF_TP_GRAPH")) {
             e->tp_graph = atoi(m) != 0;
         }

@@ -77,6 +77,7 @@ struct ftcf_gptneox {
     hipEvent_t                ev_user = nullptr;
     hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
     bool                      tp_graph = false;
+    bool                      tp_pair_ar = true;  // batched decode under TP: attn | ffn all-reduced as one message, residual inside the next LN pass
     int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
     const f16 *               wte = nullptr, *final_g = nullptr, *final_b = nullptr, *lm_head = nullptr;
@@ -250,9 +251,9 @@ struct ftcf_gptneox {
             nrm2               = c.take<f16>((size_t)B * H * es);
             qkv                = c.take<f16>((size_t)B * 3 * hl * es);
             ctx                = c.take<f16>((size_t)B * hl * es);
-            att                = c.take<f16>((size_t)B * H * es);
+            att                = c.take<f16>((size_t)2 * B * H * es);  // [att | ffn]: one message for the layer's all-reduce
+            ffn                = att + (size_t)B * H * es;
             mid                = c.take<f16>((size_t)B * il * es);
-            ffn                = c.take<f16>((size_t)B * H * es);
             logits             = c.take<float>((size_t)B * V);
             gather             = c.take<float>((size_t)B * V);
             mmha_ws            = c.take<float>(mmha_workspace_bytes(B, nhl, dh, nsplit) / 4);
@@ -984,7 +985,7 @@ struct ftcf_gptneox {
                     launch_layernorm(x, w.ln1_g, w.ln1_b, nrm, B, H, 1e-5f, true, stream);
                     launch_layernorm(x, w.ln2_g, w.ln2_b, nrm2, B, H, 1e-5f, true, stream);
                 }
-                else if (l == 0 || !tp1) {
+                else if (l == 0 || (!tp1 && !tp_pair_ar)) {
                     launch_residual_dual_ln(x, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm,
                                             nrm2, B, H, 1e-5f, stream);
                 }
@@ -1041,6 +1042,19 @@ struct ftcf_gptneox {
                 else {
                     self_attention_layer.forward(nrm, qkv, ctx, att, w, mp, B, stream);
                     ffn_layer.forward(nrm2, mid, ffn, w, B, stream);
+                }
+                if (dual && !tp1 && tp_pair_ar) {
+                    // Tensor parallel: the reference closes the layer with x / TP + attn + ffn + bias and ONE all-reduce of the sum
+                    // (GptNeoXDecoder.cc:342-359, add_residual_kernels.cu:116-152), then the next layer's LayerNorms: three launches
+                    // on a path that is bound by the latency of dependent launches.  Here attn | ffn (adjacent in the arena) travel
+                    // as one message of twice the size and the residual -- x + attn + ffn + TP x (bias / TP) in fp32, rounded once
+                    // -- runs inside the next layer's LayerNorm pass, as at TP = 1: two launches (FTCF_TP_PAIR_AR=0: the former).
+                    allreduce(att, (size_t)2 * B * H);
+                    const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
+                    launch_residual_dual_ln(x, ffn, att, w.ffn2.bias, 1, 1, nx ? nx->ln1_g : nullptr, nx ? nx->ln1_b : nullptr,
+                                            nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm, nrm2, B, H, 1e-5f, stream,
+                                            cfg.tensor_para_size);
+                    continue;
                 }
                 if (dual && tp1) {
                     const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
@@ -1135,11 +1149,16 @@ struct ftcf_gptneox {
                 const size_t      o  = (size_t)r0[c], wo = (size_t)c * smallm_region;
                 const hipStream_t st = cs[c];
                 f16*              xr = x + o * H;
-                if (l > 0) {
+                if (l > 0 && !tp_pair_ar) {
                     FTCF_HIP_CHECK(hipStreamWaitEvent(st, dv_red[c], 0));  // this micro-batch's x has been reduced
                 }
-                launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
-                                        nrm2 + o * H, M, H, 1e-5f, st);
+                // (a micro-batch's attn | ffn rows are adjacent: [2 r0 H, 2 r0 H + M H) and the M H behind it)
+                f16* const attc = att + 2 * o * H;
+                f16* const ffnc = attc + (size_t)M * H;
+                if (l == 0 || !tp_pair_ar) {
+                    launch_residual_dual_ln(xr, nullptr, nullptr, nullptr, 1, 0, w.ln1_g, w.ln1_b, w.ln2_g, w.ln2_b, nrm + o * H,
+                                            nrm2 + o * H, M, H, 1e-5f, st);
+                }
                 MmhaParams mp = mmha_params(l, w, B, s_max, r0[c], M, l);
                 // [QKV, FFN1] -> MMHA -> [out-proj, FFN2], independent GEMMs in one launch (as the loop below)
                 const SmallmDesc p1[2] = {{nrm + o * H, w.qkv.kernel, w.qkv.scale, nullptr, 0, qkv + o * 3 * hl, 3 * hl, H},
@@ -1148,17 +1167,26 @@ struct ftcf_gptneox {
                     launch_gemm_smallm_group(p1, 2, smallm_ws, smallm_partial, M, int8, st, &state->step, &smallm_seq, wo);
                 }, st);
                 launch_mmha(mp, st);
-                const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, att + o * H, H, hl},
-                                          {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffn + o * H, H, il}};
+                const SmallmDesc p3[2] = {{ctx + o * hl, w.attn_out.kernel, w.attn_out.scale, nullptr, 0, attc, H, hl},
+                                          {mid + o * il, w.ffn2.kernel, w.ffn2.scale, nullptr, 0, ffnc, H, il}};
                 timed(KIND_SMALLM, wbytes * H * ((double)hl + il), [&] {
                     launch_gemm_smallm_group(p3, 2, smallm_ws, smallm_partial, M, int8, st, &state->step, &smallm_seq, wo);
                 }, st);
-                launch_add_bias_attn_ffn_residual(xr, ffn + o * H, att + o * H, xr, w.ffn2.bias, M, H, cfg.tensor_para_size, inplace,
-                                                  true, st);
+                if (!tp_pair_ar) {
+                    launch_add_bias_attn_ffn_residual(xr, ffnc, attc, xr, w.ffn2.bias, M, H, cfg.tensor_para_size, inplace, true, st);
+                }
                 FTCF_HIP_CHECK(hipEventRecord(dv_done[c], st));
                 FTCF_HIP_CHECK(hipStreamWaitEvent(side, dv_done[c], 0));
-                allreduce(xr, (size_t)M * H, side);
+                allreduce(tp_pair_ar ? attc : xr, (size_t)(tp_pair_ar ? 2 : 1) * M * H, side);
                 FTCF_HIP_CHECK(hipEventRecord(dv_red[c], side));
+                if (tp_pair_ar) {
+                    // the layer's residual inside the next layer's LayerNorm pass, behind the reduction (general loop below)
+                    const LayerWeights* nx = l + 1 < L ? &layers[l + 1] : nullptr;
+                    FTCF_HIP_CHECK(hipStreamWaitEvent(st, dv_red[c], 0));
+                    launch_residual_dual_ln(xr, ffnc, attc, w.ffn2.bias, 1, 1, nx ? nx->ln1_g : nullptr, nx ? nx->ln1_b : nullptr,
+                                            nx ? nx->ln2_g : nullptr, nx ? nx->ln2_b : nullptr, nrm + o * H, nrm2 + o * H, M, H, 1e-5f,
+                                            st, cfg.tensor_para_size);
+                }
             }
         }
         // join: both micro-batches' last reductions, and the second compute stream itself (its last wait is for dv_red[1] of layer

@@ -78,8 +78,9 @@ __global__ __launch_bounds__(256) void k_residual_dual_ln(f16* __restrict__ x, c
                                                           int tp, int inplace_variant, const f16* __restrict__ g1,
                                                           const f16* __restrict__ b1, const f16* __restrict__ g2,
                                                           const f16* __restrict__ b2, f16* __restrict__ out1,
-                                                          f16* __restrict__ out2, int n, float eps)
+                                                          f16* __restrict__ out2, int n, float eps, int bias_mul)
 {
+    // (bias_mul: tensor-parallel layers whose attn / ffn arrive already all-reduced add the rank's bias / TP that many times)
     __shared__ float red[8];
     const size_t     row = (size_t)blockIdx.x * n;
     f16x8            v[DLN_NV];
@@ -92,7 +93,13 @@ __global__ __launch_bounds__(256) void k_residual_dual_ln(f16* __restrict__ x, c
             if constexpr (RESID) {
                 const f16x8 fv = *reinterpret_cast<const f16x8*>(ffn + row + i);
                 const f16x8 av = *reinterpret_cast<const f16x8*>(attn + row + i);
-                const f16x8 bv = *reinterpret_cast<const f16x8*>(bias + i);
+                f16x8       bv = *reinterpret_cast<const f16x8*>(bias + i);
+                if (bias_mul != 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        bv[j] = (f16)((float)bv[j] * (float)bias_mul);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const f16 xin = (f16)((float)xv[j] / (float)tp);
@@ -151,7 +158,7 @@ bool residual_dual_ln_supported(int n)
 
 void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16* bias, int tp, int inplace_variant,
                              const f16* g1, const f16* b1, const f16* g2, const f16* b2, f16* out1, f16* out2, int m,
-                             int n, float eps, hipStream_t s)
+                             int n, float eps, hipStream_t s, int bias_mul)
 {
     FTCF_CHECK_ARG(residual_dual_ln_supported(n), "fused residual + LayerNorm needs n % 8 == 0 and n <= 8192");
     if (m == 0) {
@@ -159,11 +166,11 @@ void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16*
     }
     if (ffn) {
         hipLaunchKernelGGL((k_residual_dual_ln<true>), dim3(m), dim3(256), 0, s, x, ffn, attn, bias, tp, inplace_variant,
-                           g1, b1, g2, b2, out1, out2, n, eps);
+                           g1, b1, g2, b2, out1, out2, n, eps, bias_mul);
     }
     else {
         hipLaunchKernelGGL((k_residual_dual_ln<false>), dim3(m), dim3(256), 0, s, x, ffn, attn, bias, tp,
-                           inplace_variant, g1, b1, g2, b2, out1, out2, n, eps);
+                           inplace_variant, g1, b1, g2, b2, out1, out2, n, eps, bias_mul);
     }
     FTCF_HIP_CHECK(hipGetLastError());
 }

@@ -264,7 +264,8 @@ int ftcf_batcher_submit_ex(ftcf_batcher_t b, const int* prompt_ids, int prompt_l
  * then fetched ONCE with ftcf_batcher_beam_result: output_ids [beam_width][total_len] (prompt, then the beam's tokens, end_id
  * padded: total_len = prompt_len + max_new_tokens), sequence_lengths [beam_width], cum_log_probs [beam_width] -- the arrays
  * GptNeoXOp.forward returns.  output_ids == NULL: only *beam_width / *total_len are set (0 / 0: unknown id or still running).
- * 2 <= beam_width <= min(64, max_batch). */
+ * 2 <= beam_width <= min(64, max_batch).  Up to 256 finished results wait to be fetched (the oldest are dropped beyond
+ * that); ftcf_batcher_cancel of a finished request drops its result. */
 int ftcf_batcher_submit_beam(ftcf_batcher_t b, const int* prompt_ids, int prompt_len, int max_new_tokens, int beam_width,
                              float beam_search_diversity_rate, float len_penalty, float temperature, float repetition_penalty,
                              long* request_id);

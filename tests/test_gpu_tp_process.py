@@ -142,6 +142,22 @@ def test_two_processes_on_one_gpu_exchange_through_ipc_windows(gh, tmp_path, mod
         _check(r1["output_ids"], r1["logits"], res[0][name + ".output_ids"], res[0][name + ".logits"], lens, f"{model} {name} vs TP=1 engine", frac)
 
 
+def test_two_processes_overlap_the_all_reduce_of_batched_decode(gh, tmp_path):
+    """Row n1 between two PROCESSES: the four-row request's decode steps as two micro-batches on two streams with the layer's
+    all-reduce on a third (FTCF_DECODE_OVERLAP=1; engine.hip.h decoder_overlapped; GptNeoXDecoder.cc:342-359 has it in line) --
+    both ranks hold the tokens and logits of the un-overlapped pair of processes bit for bit, and the stats say which form ran."""
+    (tmp_path / "ov").mkdir()
+    (tmp_path / "plain").mkdir()
+    ov, _ = _run_ranks(tmp_path / "ov", "mid", 1, extra_env={"FTCF_DECODE_OVERLAP": "1"})
+    plain, _ = _run_ranks(tmp_path / "plain", "mid", 1, extra_env={"FTCF_DECODE_OVERLAP": "0"})
+    for r in range(2):
+        assert int(ov[r]["four_rows.decode_overlap"][0]) == 1 and int(plain[r]["four_rows.decode_overlap"][0]) == 0
+        assert int(ov[r]["one_row.decode_overlap"][0]) == 0
+        assert int(ov[r]["four_rows.decode_path"][0]) == 2
+        assert ov[r]["four_rows.output_ids"].tolist() == plain[0]["four_rows.output_ids"].tolist()
+        np.testing.assert_array_equal(ov[r]["four_rows.logits"], plain[0]["four_rows.logits"])
+
+
 def test_compiled_module_bootstraps_tensor_parallelism_from_the_callers_process_group(gh, tmp_path):
     """The two ranks build `libth_gptneox.GptNeoXOp` -- the COMPILED pybind11 module -- over their gloo group: the constructor casts the
     Python group to c10d::ProcessGroup, builds the host-exchange communicator (comm_from_group, FTCF_TP_EXCHANGE=host) and every

@@ -57,6 +57,7 @@ def main():
             res[name + ".logits"] = r["logits"]
             res[name + ".decode_path"] = np.array([st["decode_path"]])
             res[name + ".window_allreduces"] = np.array([st["window_allreduces"]])
+            res[name + ".decode_overlap"] = np.array([st["decode_overlap"]])
             if ids.shape[0] <= 2 and st["decode_path"] != 1 and os.environ.get("FTCF_TEST_EXPECT_FALLBACK") != "1":
                 left = 1
         flag = torch.tensor([left])
