@@ -175,7 +175,7 @@ struct ftcf_batcher {
     DecodeState *d_state = nullptr, *d_gstate = nullptr;
     void*        samp_ws = nullptr;
     float*       smallm_ws = nullptr;
-    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..320 rows)
+    float*       tiled_ws  = nullptr;  // split-K workspace of the tiled GEMM (decode steps of 17..768 rows)
     // chunked admission: with slots running, a prompt longer than this is prefilled alone, `prefill_chunk` tokens at a time, one
     // decode step of the running slots between two chunks (FTCF_BATCHER_PREFILL_CHUNK; 0 = whole prompts)
     int prefill_chunk = 512;
@@ -338,7 +338,7 @@ struct ftcf_batcher {
             smallm_partial *= e->cfg.tensor_para_size > 1 ? 2 : 1;
             smallm_ws = dmalloc<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4 + 1);
         }
-        if (max_batch > 16 && max_batch <= 320) {
+        if (max_batch > 16 && max_batch <= gemm_tiled_splitk_max_m()) {
             tiled_ws = dmalloc<float>(gemm_tiled_workspace_bytes() / 4);
         }
         std::vector<uint8_t> fin(max_batch, 1);

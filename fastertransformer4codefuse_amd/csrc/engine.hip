@@ -101,11 +101,11 @@ void gemm_dispatch(const f16* A, const void* W, const f16* scale, const f16* bia
 
 // the stand-alone GEMM entry points carry no workspace argument (the reference's runner takes one from its caller:
 // fpA_intB_gemm.h gemm(..., workspace_ptr, workspace_bytes)): one split-K workspace per (device, stream) that has called with
-// 17..320 rows, kept for the life of the process
+// 17..768 rows, kept for the life of the process
 static float* abi_gemm_workspace(int m, hipStream_t s)
 {
     if (m <= 16 || m > gemm_tiled_splitk_max_m()) {
-        return nullptr;  // (only the split-K form of 17..320 rows uses it)
+        return nullptr;  // (only the split-K form of 17..768 rows uses it)
     }
     static std::mutex                                    mu;
     static std::map<std::pair<int, hipStream_t>, float*> ws;

@@ -102,7 +102,7 @@ struct ftcf_gptneox {
     float *   cum = nullptr, *d_p_topk = nullptr, *d_p_topp = nullptr, *d_temp = nullptr, *d_rep = nullptr;
     uint64_t *draws = nullptr, *d_seed = nullptr;
     float*    smallm_ws = nullptr;  // split-K partials + tickets of the batched decode GEMM (5..16 rows)
-    float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..320 rows (short prompt phases)
+    float*    tiled_ws  = nullptr;  // split-K partial tiles + tickets of the tiled GEMM at 17..768 rows (short prompt phases)
     size_t    smallm_partial = 0, smallm_region = 0;  // (all of the partial sums; one set of four GEMM regions)
     unsigned  smallm_seq = 0;       // launch counter: part of the granule tag of its in-launch reduction
     // beam search (beam_width K > 1; rows = batch * K everywhere above)
@@ -358,7 +358,7 @@ struct ftcf_gptneox {
             smallm_region  = smallm_partial;
             smallm_partial *= cfg.tensor_para_size > 1 ? 2 : 1;
             smallm_ws = (!fp32 && (decode_ws || prefill_ws)) ? c.take<float>((smallm_partial + gemm_smallm_ticket_bytes()) / 4) : nullptr;
-            const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= 320);
+            const bool tiled_rows = prefill_m > 16 || (B > 16 && B <= gemm_tiled_splitk_max_m());
             tiled_ws              = (!fp32 && tiled_rows) ? c.take<float>(gemm_tiled_workspace_bytes() / 4) : nullptr;
             state              = c.take<DecodeState>(1);
             finished           = c.take<uint8_t>(B);

@@ -11,7 +11,7 @@
 // columns and keeps its dequantised B fragments in registers across all row groups of the block tile; activations
 // are staged through LDS and shared by the waves of the workgroup.  Roofline: MFMA for m >= 512, HBM below.
 //
-// Forms of k_gemm_tiled, by row count (launch_gemm_tiled): 17..320 rows with a workspace -- 32 / 48 / 64-row tiles cut along K
+// Forms of k_gemm_tiled, by row count (launch_gemm_tiled): 17..384 (int8) or 768 (fp16) rows with a workspace -- 32 / 48 / 64 / 128-row tiles cut along K
 // into ~256 workgroups, a ring of four k-steps of weight tiles and A-tile registers, the slices reduced inside the launch
 // (SPLITK, D = 4); more rows -- 64- or 128-row tiles, ring of two k-steps (D = 2) when the k-steps divide, with the A
 // fragments prefetched (PF) where one workgroup per CU runs anyway and held to 128 VGPRs (OCC2) otherwise; the plain loop
@@ -25,7 +25,13 @@ constexpr int GEMM_KSTEP = 64;
 // split-K form of the tiled GEMM (short prompt phases): partial tiles [tile][slice] of 64 x 256 fp32 + one ticket per tile
 constexpr size_t GEMM_SPLITK_WS    = (size_t)48 << 20;
 constexpr size_t GEMM_SPLITK_TILES = 4096;
-constexpr int    GEMM_SPLITK_MAX_M = 320;  // (13B int8 prompt phase, ms: 257 tokens 14.7 on the 128-row form, 12.4 here; 384: 15.5 / 16.0)
+// rows up to which the split-K form runs, and rows above which its tiles are 128 rows high instead of 64 (a weight fragment is then
+// dequantised / read from LDS for twice the MFMAs and K is cut twice as often for the same number of workgroups).  13B prompt phase,
+// ms, 64-row split-K up to 320 rows and the un-split 128-row form above (round 4) -> this (profiles/r05_prefill_sweep.txt):
+//   fp16 weights  224: 15.2 -> 12.2   256: 15.7 -> 12.5   320: 17.9 -> 13.9   384: 18.7 -> 14.7   512: 22.4 -> 19.9   640: 25.7 -> 23.4   768: 29.8 -> 28.6
+//   int8 weights  352: 14.8 -> 13.0   384: 15.0 -> 13.2   (128-row tiles at <= 320 rows: 160: 8.4 -> 10.3, 288: 12.2 -> 12.7; at 448+: no gain)
+constexpr int    GEMM_SPLITK_MAX_M_I8 = 384, GEMM_SPLITK_MAX_M_F16 = 768;
+constexpr int    GEMM_SK128_MIN_M_I8 = 320, GEMM_SK128_MIN_M_F16 = 192;
 
 // one 16-byte weight fragment against the 16 rows of x in LDS (xr: this lane's row lane&15, k group lane>>4)
 template<bool INT8>
@@ -440,8 +446,9 @@ size_t gemm_tiled_workspace_bytes()
 
 int gemm_tiled_splitk_max_m()
 {
-    static const int v = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : GEMM_SPLITK_MAX_M;
-    return v;
+    static const int v = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M"))
+                                                            : std::max(GEMM_SPLITK_MAX_M_I8, GEMM_SPLITK_MAX_M_F16);
+    return v;  // (the larger of the two weight forms' limits: who sizes a workspace by it covers both)
 }
 
 void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16* bias, int act, f16* C, int m, int n,
@@ -455,7 +462,8 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     const int NT = n / 16;
     const char*      sk_env        = getenv("FTCF_GEMM_SPLITK");  // (read per call: the tests switch it inside one process)
     const int        splitk_target = sk_env ? atoi(sk_env) : 256;
-    const int splitk_max_m = gemm_tiled_splitk_max_m();
+    static const int splitk_max_env = getenv("FTCF_GEMM_SPLITK_MAX_M") ? atoi(getenv("FTCF_GEMM_SPLITK_MAX_M")) : -1;
+    const int splitk_max_m = splitk_max_env >= 0 ? splitk_max_env : (int8 ? GEMM_SPLITK_MAX_M_I8 : GEMM_SPLITK_MAX_M_F16);
     if (workspace && m <= splitk_max_m && splitk_target > 0) {
         // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)
         static const int deep = getenv("FTCF_GEMM_DEEP") ? atoi(getenv("FTCF_GEMM_DEEP")) : 4;
@@ -465,7 +473,10 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         // dequantisation -- outweigh its MFMAs at these heights).
         static const int rgsel = getenv("FTCF_GEMM_RG32") ? atoi(getenv("FTCF_GEMM_RG32")) : 1;
         constexpr int NG = 2, DQ = 4;
-        const int     RGs = (rgsel && m <= 64) ? std::max(2, (m + 15) / 16) : 4;
+        // several row blocks: 128-row tiles above FTCF_GEMM_SK128_MIN_M rows (see GEMM_SK128_MIN_M_* for the measurements)
+        const char*   sk128_env = getenv("FTCF_GEMM_SK128_MIN_M");  // rows above which the tiles are 128 rows high
+        const int     sk128_min = sk128_env ? atoi(sk128_env) : (int8 ? GEMM_SK128_MIN_M_I8 : GEMM_SK128_MIN_M_F16);
+        const int     RGs = (rgsel && m <= 64) ? std::max(2, (m + 15) / 16) : (m > sk128_min ? 8 : 4);
         const int BM = RGs * 16;
         const int gx = (NT + 8 * NG - 1) / (8 * NG), gy = (m + BM - 1) / BM, gx8 = 8 * ((gx + 7) / 8);
         const int ksteps = k / GEMM_KSTEP;
@@ -489,6 +500,9 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     }                                                                                                                            \
     else if (RGs == 3) {                                                                                                         \
         FTCF_SK(I8, Dv, 3);                                                                                                      \
+    }                                                                                                                            \
+    else if (RGs == 8) {                                                                                                         \
+        FTCF_SK(I8, Dv, 8);                                                                                                      \
     }                                                                                                                            \
     else {                                                                                                                       \
         FTCF_SK(I8, Dv, 4);                                                                                                      \
