@@ -52,3 +52,11 @@ python tools/ps_timeline.py $O/ts.bin 20 > $O/timeline_tp1.txt; rm -f $O/ts.bin
 FTCF_PERSIST_TS=$O/ts.bin timeout 300 python bench.py --batch 16 --prompt-len 256 --output-len 64 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-pmc --profile-steps 0 >/dev/null 2>&1
 python tools/rows_timeline.py $O/ts.bin 20 > $O/timeline_rows_bs16.txt; rm -f $O/ts.bin
 ls -la $O
+# prompt phase by prompt length (int8, fp16), batched TP decode with / without the two-micro-batch overlap on one rank's shard
+timeout 600 python tools/bench_prefill.py --lens 17,33,48,64,65,96,128,160,192,256,320,384,512,640,768,1024,2048 --dtype int8 2>/dev/null | grep prompt_len > $O/prefill_sweep_int8.txt
+timeout 600 python tools/bench_prefill.py --lens 65,128,192,256,320,384,512,640,768,1024 --dtype fp16 2>/dev/null | grep prompt_len > $O/prefill_sweep_fp16.txt
+cat $O/prefill_sweep_int8.txt $O/prefill_sweep_fp16.txt | cut -c1-120
+for bs in 16 32; do for v in 0 1; do
+  FTCF_DECODE_OVERLAP=$v timeout 300 python bench.py --fake-tp 8 --batch $bs --prompt-len 256 --output-len 128 --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --no-pmc > $O/bench_faketp8_bs${bs}_overlap$v.json 2>/dev/null
+  python -c "import json; d=json.load(open('$O/bench_faketp8_bs${bs}_overlap$v.json')); print('faketp 8 bs $bs overlap $v: %.3f ms per step' % d['ms_per_step'], d['tensor_parallel']['decode_overlap'])"
+done; done
