@@ -220,6 +220,17 @@ def test_13b_tp2_shards_between_two_processes(tmp_path):
         pytest.xfail("the two processes' kernels were not co-scheduled in four attempts: in-kernel path not exercised")
     assert got == (1, 1)
     assert int(res[0]["window_allreduces"][0]) >= FULL13B["layers"]  # the 1.9 MB prompt-phase messages: two-shot window kernel
+    # row n1 at the 13B shard shape: 16 rows, the decode steps' all-reduce in line and overlapped (two micro-batches of 8 rows on two
+    # streams, the reduction on a third): bit-identical on both ranks, and -- unless the two processes' all-reduce kernels were not
+    # co-scheduled and the request was replayed on the host-staged path -- every message through the IPC-mapped windows
+    for r in range(2):
+        ov, ln = res[r]["b16_1.stats"], res[r]["b16_0.stats"]
+        assert (int(ov[0]), int(ln[0])) == (1, 0) and int(ov[1]) == 2 and int(ln[1]) == 2, (ov, ln)
+        assert res[r]["b16_1.output_ids"].tolist() == res[0]["b16_0.output_ids"].tolist()
+        np.testing.assert_array_equal(res[r]["b16_1.logits"], res[0]["b16_0.logits"])
+        if not any("exchange-window all-reduce gave up" in lg for lg in logs):
+            # prompt phase: one message per layer; two decode steps: one (in line) / two (micro-batches) per layer each
+            assert int(ln[2]) >= 3 * FULL13B["layers"] and int(ov[2]) >= 5 * FULL13B["layers"], (ov, ln)
     sys.path.insert(0, ROOT)
     import bench
     from fastertransformer4codefuse_amd.gptneox_op import GptNeoXOp

@@ -103,6 +103,24 @@ def main_13b(rank, world, out):
         del op
         if int(flag.item()) == 0:
             break
+    # Row n1 at the product shapes: a 16-row request's decode steps with the layer's all-reduce in line (FTCF_DECODE_OVERLAP=0) and on
+    # the comm stream under the other micro-batch's launches (=1; engine.hip.h decoder_overlapped) -- the 160 / 320 KB messages go
+    # through the IPC-mapped windows (k_window_allreduce), next to the burst GEMMs of two compute streams
+    op = GptNeoXOp(dist.group.WORLD, rank, a.heads, a.head_dim, a.inter, a.layers, a.vocab, a.rotary, 0, 2, world, 1, 1, 2048,
+                   True, w, q8, sc)
+    g16 = torch.Generator().manual_seed(7)
+    ids16 = torch.randint(3, a.vocab, (16, 8), generator=g16, dtype=torch.int32).cuda()
+    lens16 = torch.full((16,), 8, dtype=torch.int32, device="cuda")
+    for mode in ("0", "1"):
+        os.environ["FTCF_DECODE_OVERLAP"] = mode
+        dbg = torch.zeros((3, 16, a.vocab), dtype=torch.float32, device="cuda")
+        o = op.forward(ids16, lens16, 3, 1, torch.tensor([1], dtype=torch.int32), _debug_logits=dbg)
+        torch.cuda.synchronize()
+        st = op.stats()
+        res["b16_%s.output_ids" % mode] = o[0][:, 0].cpu().numpy()
+        res["b16_%s.logits" % mode] = dbg.cpu().numpy()
+        res["b16_%s.stats" % mode] = np.array([st["decode_overlap"], st["decode_path"], st["window_allreduces"]])
+    del op
     np.savez(out, **res)
     dist.barrier()
     dist.destroy_process_group()
