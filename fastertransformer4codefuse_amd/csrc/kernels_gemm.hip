@@ -545,7 +545,12 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         // CUs) -> 64-row tiles.
         constexpr int NG = 2;
         const int     gx = (NT + 8 * NG - 1) / (8 * NG);
-        const bool    small = (long)gx * ((m + 127) / 128) < 160;
+        static const int small_tiles = getenv("FTCF_GEMM_SMALL_TILES") ? atoi(getenv("FTCF_GEMM_SMALL_TILES")) : 160;
+        // (above 1024 rows also when the 128-row tiles would leave a partial round of the 256 CUs: n = 5120 at 1025..1536 rows is
+        // 180..240 tiles -- 13B prompt phase at 1536 tokens 51.2 -> 47.7 ms (int8), 54.0 -> 52.4 (fp16); at exactly 1024 rows, 160
+        // tiles, the 64-row form is SLOWER: 31.1 -> 32.5 / 33.1 -> 38.8)
+        const long    t128  = (long)gx * ((m + 127) / 128);
+        const bool    small = t128 < small_tiles || (m > 1024 && t128 < 256);
         const int     gy = small ? (m + 63) / 64 : (m + 127) / 128;
         dim3          grid(8 * ((gx + 7) / 8) * gy);
         // The ring form, two k-steps deep (it needs an even number of k-steps; else the plain loop).  At most one workgroup per CU
