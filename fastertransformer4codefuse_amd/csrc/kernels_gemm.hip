@@ -574,6 +574,17 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     else {                                                                                                                       \
         FTCF_BIG(I8, RGv, 0, false, false);                                                                                      \
     }
+        // fp16 weights from 2048 rows: the same 128 x 256 tile on FOUR waves of four column groups each -- an A fragment read from LDS
+        // feeds four MFMAs instead of two, two workgroups per CU (252 VGPRs, plain loop: the ring of two k-steps spills 58).  13B prompt
+        // phase, fp16 weights: 2048 tokens 64.4 -> 63.2 ms, 4096: 133.2 -> 129.6; at 1024 tokens it is slower (33.1 -> 34.7), and with
+        // int8 weights at every length (1024: 29.9 -> 33.4, 4096: 120.0 -> 121.0).  FTCF_GEMM_NG4=0: off.
+        static const int ng4 = getenv("FTCF_GEMM_NG4") ? atoi(getenv("FTCF_GEMM_NG4")) : 1;
+        if (ng4 && !int8 && !small && m >= 2048) {
+            hipLaunchKernelGGL((k_gemm_tiled<false, 8, 4, 4, false, true, false, 0, false, true>), grid, dim3(256), 0, s, A, W, scale, bias,
+                               act, C, m, n, k, gx, gy);
+            FTCF_HIP_CHECK(hipGetLastError());
+            return;
+        }
         if (small && int8) {
             FTCF_BIG_D(true, 4)
         }

@@ -72,6 +72,18 @@ def test_gemm_at_the_headline_prompt_shapes(capi, int8, n, k):
             outs.append(out.cpu())
         assert torch.equal(outs[0], outs[1]), f"m={m}: not repeatable"
         torch.testing.assert_close(outs[0].float(), torch.from_numpy(ref[:m]), rtol=1e-3, atol=2e-3, msg=lambda t: f"m={m}: {t}")
+    # 1536 and 2048 rows (the 64-row form above 1024 rows where 128-row tiles leave a partial round of the CUs; from 2048 rows
+    # fp16 weights take the four-wave / four-column-group form): the same 1024 activation rows, stacked
+    A2 = torch.cat([A, A], 0).contiguous()
+    for m in (1536, 2048):
+        out = torch.empty((m, n), dtype=torch.float16, device="cuda")
+        if int8:
+            capi.check(L.ftcf_fpA_intB_gemm(capi.vp(A2), capi.vp(qd), capi.vp(sd), capi.vp(bd), 0, capi.vp(out), m, n, k, _sp()))
+        else:
+            capi.check(L.ftcf_fp16_gemm(capi.vp(A2), capi.vp(wt), capi.vp(bd), 0, capi.vp(out), m, n, k, _sp()))
+        torch.cuda.synchronize()
+        want = torch.from_numpy(np.concatenate([ref, ref], 0)[:m])
+        torch.testing.assert_close(out.cpu().float(), want, rtol=1e-3, atol=2e-3, msg=lambda t: f"m={m}: {t}")
 
 
 def test_fixed_seed_slice_of_the_gemm_fuzzer(capi):
