@@ -461,6 +461,14 @@ struct ftcf_gptneox {
                 hx_allreduce(cfg.comm, buf, count, true, st);
                 return;
             }
+            // (timing aid, bench.py --fake-tp only: the one-rank communicator's all-reduce is the identity and costs nothing --
+            //  FTCF_FAKE_AR_US puts a one-wave kernel of that many microseconds in its place, so that what the overlapped decode form
+            //  hides can be measured on one GPU: tools/scripts/r5_fake_ar.sh, profiles/r05_decode_overlap_model.txt)
+            static const int fake_us = getenv("FTCF_FAKE_AR_US") ? atoi(getenv("FTCF_FAKE_AR_US")) : 0;
+            if (fake_us > 0 && cfg.comm->world == 1) {
+                launch_spin_us(fake_us, st);
+                return;
+            }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, st));
         }
     }
