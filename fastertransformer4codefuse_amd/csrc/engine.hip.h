@@ -1090,7 +1090,7 @@ struct ftcf_gptneox {
     // 4..16 rows it doubles the weight bytes.  All reductions sit on ONE stream in the order c = 0, 1, 0, 1, ...: the window
     // all-reduce's flag words and RCCL see a serial sequence, identical on every rank.  Row-wise arithmetic is that of the loop
     // below (the burst GEMM's K slices do not depend on the row count; the micro-batches' GEMMs have their own split-K regions), so
-    // the tokens are bit-identical to the un-overlapped path (tests/test_gpu_tp_local.py, test_gpu_tp_process.py).
+    // the tokens are bit-identical to the un-overlapped path (tests/test_gpu_tp_overlap.py, test_gpu_tp_process.py).
     // FTCF_DECODE_OVERLAP = 0 / 1 forces it; unset or "auto" (ranks joined by RCCL): the first eligible request's token loop runs
     // plain, the second one overlapped, every rank keeps the slowest rank's ms per step (comm_max in finish()) and the engine
     // stays with the faster form -- what an all-reduce over xGMI hides can only be measured on the node.
