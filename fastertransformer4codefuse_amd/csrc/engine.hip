@@ -575,8 +575,7 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
         }
         // final LayerNorm (GptNeoX.cc:854-863) is fused into the LM-head GEMV for m <= 4
         const bool fuse_ln = B <= 4 && !fp32;
-        const bool lm_done = with_decoder && pplan.ok && ps_lm_fused;  // the persistent launch computed the logits itself
-        if (!fuse_ln && !lm_done) {
+        if (!fuse_ln) {
             launch_layernorm(x, final_g, final_b, nrm, B, H, 1e-5f, !fp32, stream);
         }
         auto lm = [&](const f16* Wrows, float* out, int rows, int ld) {
@@ -592,10 +591,8 @@ void ftcf_gptneox::enqueue_step(bool with_decoder)
         };
         // one GPU, <= 2 rows, an all-greedy step: the LM head launch picks the tokens, closes the step and prepares the next
         // token's input itself (k_lm_head_greedy) -- nothing is launched behind it
-        const bool lm_greedy = !lm_done && tp == 1 && fuse_ln && ses.K == 1 && lm_head_greedy_ok(ses.sp, H);
-        if (lm_done) {
-        }
-        else if (lm_greedy) {
+        const bool lm_greedy = tp == 1 && fuse_ln && ses.K == 1 && lm_head_greedy_ok(ses.sp, H);
+        if (lm_greedy) {
             timed(KIND_LM_HEAD, 2.0 * V * H,
                   [&] { launch_lm_head_greedy(x, lm_head, logits, H, final_g, final_b, 1e-5f, ses.sp, stream); });
         }

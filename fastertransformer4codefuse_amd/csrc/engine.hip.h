@@ -118,7 +118,6 @@ struct ftcf_gptneox {
     PersistLayer*       d_players = nullptr;  // device [L]
     char*               ps_tab = nullptr;     // the plan's run / tile tables, built once per request by a launch over no layers
     bool                ps_tab_ready = false;
-    bool                ps_lm_fused = false;  // the LM head runs as the tail of the persistent launch (one GPU, H % 512 == 0)
     unsigned long long *ps_gq = nullptr, *ps_gm = nullptr, *ps_gc = nullptr, *ps_gx = nullptr, *ps_gp = nullptr,
                        *ps_ga = nullptr;
     size_t              ps_slab_n = 0;
@@ -271,23 +270,7 @@ struct ftcf_gptneox {
                 && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, tpn == 1);
-#ifdef PS_EXPERIMENTS
-                // (experiment builds only, `make EXPERIMENTS=1`; FTCF_PERSIST_A4=1 selects it)  Second form of the kernel
-                // (persist4_device.hip.h: the attention branch on the control waves under the FFN streams): built, parity green,
-                // measured 1-2.5 % SLOWER than the first form at TP = 1 (profiles/r04_notes.md) -- six streaming waves carry a
-                // lower rate than eight, and what the removed hand-off window gains is lost there
-                static const int a4_max_tp = getenv("FTCF_PERSIST_A4_MAX_TP") ? atoi(getenv("FTCF_PERSIST_A4_MAX_TP")) : 2;
-                static const int a4_cs3 = getenv("FTCF_PERSIST4_CS3") ? atoi(getenv("FTCF_PERSIST4_CS3")) : 12;
-                if (pplan.ok && B == 1 && tpn <= a4_max_tp) {
-                    const PersistPlan p4 = persist_plan4(
-                        persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, a4_cs3, false), B, H, hl, il, nhl,
-                        dh, s_max, int8);
-                    if (p4.ok && p4.a4) {
-                        pplan = p4;
-                    }
-                }
-#endif
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3);
                 const bool resident = !pplan.ok ? false
                                       : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
                                                  : persist_resident(pplan, int8, B, dh, num_cu, tpn);
@@ -295,7 +278,6 @@ struct ftcf_gptneox {
                     pplan = PersistPlan{};  // not every workgroup would be resident: the hand-offs could never complete
                 }
             }
-            ps_lm_fused = false;
             if (pplan.ok) {
                 ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
                             + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 + (size_t)B * nhl * pplan.nsplit * (dh + 2);
@@ -309,8 +291,6 @@ struct ftcf_gptneox {
                 d_players   = c.take<PersistLayer>(L);
                 ps_tab      = c.take<char>(persist_table_bytes(pplan) * pplan.NB);
                 ps_tab_ready = false;
-                static const int lm_env = persist_lm_tail_built() && getenv("FTCF_PERSIST_LM") ? atoi(getenv("FTCF_PERSIST_LM")) : 0;
-                ps_lm_fused = lm_env != 0 && tpn == 1 && H % 512 == 0;
                 ps_ts       = ps_ts_file.empty() ? nullptr : c.take<long long>((size_t)pplan.NB * L * 128);
             }
             // 3..16 rows (and what the one- / two-row kernel does not take): the rows kernel, one launch per token.  With tensor
@@ -833,14 +813,6 @@ struct ftcf_gptneox {
         pp.ts = ps_ts;
         pp.tab = ps_tab;
         pp.tab_mode = (ps_tab && ps_tab_ready) ? 2 : 0;
-        if (ps_lm_fused) {  // final LayerNorm + LM head as the launch's tail (enqueue_step then skips its own launch)
-            pp.lm_w      = lm_head;
-            pp.lm_g      = final_g;
-            pp.lm_b      = final_b;
-            pp.lm_logits = logits;
-            pp.lm_rows   = V;
-            pp.lm_ldc    = V;
-        }
         return pp;
     }
 
@@ -889,8 +861,7 @@ struct ftcf_gptneox {
         if (!ses.path_logged) {  // once per request
             ses.path_logged = true;
             FT_LOG_DEBUG(cfg.device, "decoder of this request: %s (rows %d, context %d%s)",
-                         pplan.ok ? (pplan.a4 ? "persistent layers, second form (attention branch on the control waves)"
-                                              : "persistent layers")
+                         pplan.ok ? "persistent layers"
                                   : (rplan.ok ? "persistent layers for up to 16 rows"
                                               : (staged ? "per-stage launches" : "general path (batched GEMMs)")),
                          B, s_max, pplan.ok ? (pplan.uk == 16 ? ", 512 keys per KV split" : ", 256 keys per KV split") : "");
@@ -924,7 +895,7 @@ struct ftcf_gptneox {
                 g.barrier();
                 return;
             }
-            timed(KIND_PERSIST, layer_bytes * L + (ps_lm_fused ? 2.0 * V * H : 0.0), [&] { launch_decode_persistent(pp, int8, stream); });
+            timed(KIND_PERSIST, layer_bytes * L, [&] { launch_decode_persistent(pp, int8, stream); });
             return;
         }
         if (rplan.ok) {

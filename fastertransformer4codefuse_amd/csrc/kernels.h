@@ -206,16 +206,7 @@ struct PersistPlan {
     int    xs_halves; // LDS x region
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
-    int    wt1[8], wt3[8];  // ... and the shares of all eight waves (wt[0] = wt[1] = cs; FTCF_PERSIST_WT1 / WT3, ps_wave_range_w)
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
-    int    p3l;       // the control waves' P3 share is prefetched into LDS during the attention (one row, short form, TP = 1)
-    int    a3;        // the attention runs on the control waves alone, K rows by LDS-DMA (one row, short form, TP = 1)
-    // second form of the kernel (persist4_device.hip.h, k_decode_persistent4: the attention branch on the control waves under
-    // the FFN streams; one row, short attention form):
-    int    a4;
-    int    r1max, r3max;  // runs per workgroup (P1 / P3): the partial-sum buffers' heights
-    int    mid_span;      // halves of mid a workgroup stages (the K range of its FFN2 pieces), the maximum over workgroups
-    int    ctx_off;       // LDS half offset of ctx inside the x region
     size_t smem;
 };
 struct PersistParams {
@@ -246,12 +237,6 @@ struct PersistParams {
     // the launch), 1: build and store (a launch over no layers), 2: load
     char*               tab;
     int                 tab_mode;
-    // LM head as the tail of the launch that runs the last layer (GptNeoX.cc:853-925, one GPU): final LayerNorm of x' and
-    // logits[m][v] = h[m] . lm_w[v] for all lm_rows rows of the [V][H] fp16 tensor; lm_w == NULL: not fused
-    const f16*          lm_w;
-    const f16 *         lm_g, *lm_b;
-    float*              lm_logits;  // [M][lm_ldc]
-    int                 lm_rows, lm_ldc;
 };
 constexpr int PERSIST_MAX_TP = 8;
 struct PersistGroupParams {  // local group launch: every rank's parameters, nb workgroups each
@@ -259,23 +244,17 @@ struct PersistGroupParams {  // local group launch: every rank's parameters, nb 
     int           world, nb;
 };
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int cs1, int cs3, bool allow_a3 = false);
+                         int cs1, int cs3);
 // every workgroup of the plan's grid resident at once on this device?  (also raises the kernel's dynamic-LDS limit there)
 bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp = 1);
 // bytes of the table region one workgroup stores / loads (PersistParams::tab holds NB of them)
 size_t      persist_table_bytes(const PersistPlan& pl);
-// is the LM-head tail compiled into the persistent kernel (an experiment build, -DPS_EXPERIMENTS)?
-bool        persist_lm_tail_built();
 void        launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s);
 // all ranks of a local group in one launch (grid = world * NB): residency of the whole group
 bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world);
 void        launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipStream_t s);
 // tensor-parallel instantiations (kernels_persist_tp.hip); nullptr when the shape has none
 const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
-// second form (kernels_persist4.hip): turns an eligible plan of persist_plan() into one for k_decode_persistent4 (a4 = 1, its
-// own P1 tables and LDS carve), or returns it unchanged; the kernel for a shape (nullptr: none)
-PersistPlan persist_plan4(const PersistPlan& base, int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8);
-const void* persist4_kernel(bool int8, int dh, bool tp, bool group);
 
 // ---- persistent decode layers for 3..16 rows : kernels_rows.hip ----
 // One launch runs layers [l_begin, l_end) of the batched decode step (GptNeoXDecoder.cc:245-384, any B <= 16) on one resident

@@ -17,6 +17,7 @@ const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group)
                      : reinterpret_cast<const void*>(&k_decode_persistent<I8, MM, D, PS_UK, true, false>);             \
     }
     PS_SEL(true, 1, 128)
+#ifndef PS_ONLY_ONE  // (tools/build_variant_tu.sh: kernel-variant builds instantiate the 13B int8 one-row form only)
     PS_SEL(true, 2, 128)
     PS_SEL(true, 1, 64)
     PS_SEL(true, 2, 64)
@@ -24,6 +25,7 @@ const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group)
     PS_SEL(false, 2, 128)
     PS_SEL(false, 1, 64)
     PS_SEL(false, 2, 64)
+#endif
 #undef PS_SEL
     return nullptr;
 }
