@@ -61,45 +61,64 @@ def to_word_list_format(words_list, tokenizer):
 
 
 class token_stream_2_str_stream_convertor:
-    """Turns the per-step token stream of the callback into printable text chunks (flush on newline / CJK / space)."""
+    """Incremental detokeniser behind the streaming callback: tokens in, printable text out.
+
+    Contract (pinned by tests/golden/harness_io.json "stream", captured from the reference's class of the same name):
+    the pending tokens are decoded as a whole after every arrival and the text is released up to a *safe point* --
+    everything when it ends in a newline (the pending tokens are then dropped) or in a CJK character, otherwise up to
+    and including its last space; `end_id` releases the rest (minus a trailing half-decoded character), prints the
+    end marker and closes the stream.  Only rank 0 prints."""
+
+    END_MARKER = "\n\nend\n\n"
 
     def __init__(self, end_id, tokenizer, local_rank):
         self.end_id, self.tokenizer, self.local_rank = end_id, tokenizer, local_rank
-        self.token_cache, self.print_len, self.has_stop = [], 0, False
+        self._pending = []   # tokens whose text has not been released completely
+        self._released = 0   # characters of decode(self._pending) already printed
+        self._closed = False
+
+    def _emit(self, text):
+        if self.local_rank == 0:
+            print(text, end="", flush=True)
 
     def send_str(self, str_to_send):
-        if self.local_rank == 0:
-            print(str_to_send, end="", flush=True)
+        self._emit(str_to_send)
 
     def send_finish(self):
-        if self.local_rank == 0:
-            print("\n\nend\n\n", end="", flush=True)
+        self._emit(self.END_MARKER)
+
+    @staticmethod
+    def _safe_point(text):
+        """(characters that may be shown, whether the pending tokens can be forgotten)."""
+        if text.endswith("\n"):
+            return len(text), True
+        if text and is_chinese_char(ord(text[-1])):
+            return len(text), False
+        return text.rfind(" ") + 1, False
+
+    def _release(self, text, upto):
+        chunk = text[self._released:upto] if upto > self._released else ""
+        self._released = max(self._released, upto)
+        self.send_str(chunk)
 
     def append_token(self, token):
-        if self.has_stop:
+        if self._closed:
             return
-        final = token == self.end_id
-        if not final:
-            self.token_cache.append(token)
-        text = self.tokenizer.decode(self.token_cache)
-        if final:
-            chunk = text[self.print_len:] if text else ""
-            if chunk and is_garbage(ord(chunk[-1])):
-                chunk = chunk[:-1]
-            self.token_cache, self.print_len = [], 0
-        elif text.endswith("\n"):
-            chunk = text[self.print_len:]
-            self.token_cache, self.print_len = [], 0
-        elif text and is_chinese_char(ord(text[-1])):
-            chunk = text[self.print_len:]
-            self.print_len += len(chunk)
-        else:
-            chunk = text[self.print_len:text.rfind(" ") + 1]
-            self.print_len += len(chunk)
-        self.send_str(chunk)
-        if final:
-            self.has_stop = True
+        if token == self.end_id:
+            text = self.tokenizer.decode(self._pending)
+            tail = len(text)
+            if tail > self._released and is_garbage(ord(text[-1])):
+                tail -= 1
+            self._release(text, tail)
+            self._pending, self._released, self._closed = [], 0, True
             self.send_finish()
+            return
+        self._pending.append(token)
+        text = self.tokenizer.decode(self._pending)
+        upto, forget = self._safe_point(text)
+        self._release(text, upto)
+        if forget:
+            self._pending, self._released = [], 0
 
 
 class Trie:
@@ -391,68 +410,81 @@ def init_model_and_tokenizer(lib_path, ckpt_path, tokenizer_file_path, tensor_pa
     return gpt, tokenizer, Trie(tokenizer.get_vocab())
 
 
-def _as_tensor(value, scalar_type, ctor):
+# per-request sampling arguments of GptNeoX.forward: (keyword, python scalar type, tensor constructor)
+_SAMPLING_ARGS = (("top_k", int, torch.IntTensor), ("top_p", float, torch.FloatTensor),
+                  ("beam_search_diversity_rate", float, torch.FloatTensor), ("temperature", float, torch.FloatTensor),
+                  ("len_penalty", float, torch.FloatTensor), ("repetition_penalty", float, torch.FloatTensor),
+                  ("random_seed", int, torch.LongTensor))
+
+
+def _row_tensor(value, scalar_type, ctor):
+    """None | scalar | per-row list -> None | 1-D tensor (anything else is a caller error, as in the reference)."""
     if value is None:
         return None
     if isinstance(value, scalar_type):
-        return ctor([value])
-    if isinstance(value, list):
-        return ctor(value)
-    raise RuntimeError("type don't match with %s" % str(scalar_type))
+        value = [value]
+    if not isinstance(value, list):
+        raise RuntimeError("type don't match with %s" % str(scalar_type))
+    return ctor(value)
+
+
+def _pad_rows(rows, pad):
+    """list of int lists -> (int32 tensor [B, longest] padded with `pad`, list of lengths)."""
+    lens = [len(r) for r in rows]
+    out = torch.full((len(rows), max(lens)), pad, dtype=torch.int32)
+    for b, row in enumerate(rows):
+        out[b, :lens[b]] = torch.tensor(row, dtype=torch.int32)
+    return out, lens
+
+
+def _trim_and_decode(ids, prompt_len, end_id, tokenizer):
+    """One returned hypothesis -> (text, generated length): the prompt is dropped, generation ends in front of the first
+    `end_id`, a trailing half-decoded character is not shown."""
+    gen = list(ids[prompt_len:])
+    if end_id in gen:
+        del gen[gen.index(end_id):]
+    text = tokenizer.decode(gen)
+    if text and is_garbage(ord(text[-1])):
+        text = text[:-1]
+    return text, len(gen)
 
 
 def generate(gpt, tokenizer, texts, output_len, beam_width, top_k=None, top_p=None, beam_search_diversity_rate=None,
              temperature=None, len_penalty=None, repetition_penalty=None, random_seed=None, input_ids_list=None,
              callback=None, stop_words_list=None, last_token_list=None, trie=None):
-    from torch.nn.utils.rnn import pad_sequence
+    """Prompts (texts, or token id lists) -> ([B][beam] texts, [B][beam] generated lengths, cum_log_probs, seconds).
+    Counterpart of codefuse_example.py:666-770; the request / response shapes are what CodeFuseHandler.predict serves."""
     assert texts is not None or input_ids_list is not None
-    rows = [tokenizer.encode(t) for t in texts] if texts is not None else input_ids_list
-    input_ids_list = [torch.IntTensor(r) for r in rows]
-    input_lengths_list = [ids.size(-1) for ids in input_ids_list]
-    input_ids = pad_sequence(input_ids_list, batch_first=True, padding_value=gpt.end_id)
-    input_lengths = torch.IntTensor(input_lengths_list)
-    if stop_words_list is not None:
-        stop_words_list = to_word_list_format(stop_words_list, tokenizer)
-    optional_last_tokens = None
+    prompts = [list(tokenizer.encode(t)) for t in texts] if texts is not None else [list(r) for r in input_ids_list]
+    start_ids, prompt_lens = _pad_rows(prompts, gpt.end_id)
+    sampling = {}
+    given = dict(top_k=top_k, top_p=top_p, beam_search_diversity_rate=beam_search_diversity_rate, temperature=temperature,
+                 len_penalty=len_penalty, repetition_penalty=repetition_penalty, random_seed=random_seed)
+    for name, scalar_type, ctor in _SAMPLING_ARGS:
+        sampling[name] = _row_tensor(given[name], scalar_type, ctor)
+    stop_words = None if stop_words_list is None else to_word_list_format(stop_words_list, tokenizer)
+    last_tokens = None
     if last_token_list is not None:
         assert trie is not None, "trie is None, can't select last token"
-        rows = []
-        for last_token in last_token_list:
-            found = []
-            trie.printAutoSuggestions(last_token, found)
-            ids = [tid for _, tid in found] or [gpt.end_id]
-            rows.append(torch.IntTensor(ids))
-        optional_last_tokens = pad_sequence(rows, batch_first=True, padding_value=-1)
-    start = time.time()
+        candidates = []
+        for prefix in last_token_list:  # every vocabulary entry that extends the prefix; none: the end token
+            hits = []
+            trie.printAutoSuggestions(prefix, hits)
+            candidates.append([tid for _, tid in hits] or [gpt.end_id])
+        last_tokens, _ = _pad_rows(candidates, -1)
+    t0 = time.time()
     with torch.no_grad():
-        tokens_batch, _, output_cum_log_probs = gpt(
-            start_ids=input_ids, start_lengths=input_lengths, output_len=output_len, beam_width=beam_width,
-            top_k=_as_tensor(top_k, int, torch.IntTensor), top_p=_as_tensor(top_p, float, torch.FloatTensor),
-            beam_search_diversity_rate=_as_tensor(beam_search_diversity_rate, float, torch.FloatTensor),
-            temperature=_as_tensor(temperature, float, torch.FloatTensor),
-            len_penalty=_as_tensor(len_penalty, float, torch.FloatTensor),
-            repetition_penalty=_as_tensor(repetition_penalty, float, torch.FloatTensor),
-            random_seed=_as_tensor(random_seed, int, torch.LongTensor), stop_words_list=stop_words_list,
-            optional_last_tokens=optional_last_tokens, return_output_length=True, return_cum_log_probs=1,
-            callback=callback)
-    latency = time.time() - start
-    tokens_batch = tokens_batch.detach().cpu().tolist()
-    output_cum_log_probs = output_cum_log_probs.detach().cpu().tolist()
+        out = gpt(start_ids=start_ids, start_lengths=torch.IntTensor(prompt_lens), output_len=output_len,
+                  beam_width=beam_width, stop_words_list=stop_words, optional_last_tokens=last_tokens,
+                  return_output_length=True, return_cum_log_probs=1, callback=callback, **sampling)
+    latency = time.time() - t0
+    token_rows, cum_log_probs = out[0].detach().cpu().tolist(), out[2].detach().cpu().tolist()
     outputs, output_lengths = [], []
-    for beams, in_len in zip(tokens_batch, input_lengths_list):
-        texts_out, lens_out = [], []
-        for ids in beams:
-            gen = ids[in_len:]
-            if gpt.end_id in gen:
-                gen = gen[:gen.index(gpt.end_id)]
-            text = tokenizer.decode(gen)
-            if text and is_garbage(ord(text[-1])):
-                text = text[:-1]
-            texts_out.append(text)
-            lens_out.append(len(gen))
-        outputs.append(texts_out)
-        output_lengths.append(lens_out)
-    return outputs, output_lengths, output_cum_log_probs, latency
+    for beams, n_prompt in zip(token_rows, prompt_lens):
+        decoded = [_trim_and_decode(ids, n_prompt, gpt.end_id, tokenizer) for ids in beams]
+        outputs.append([text for text, _ in decoded])
+        output_lengths.append([n for _, n in decoded])
+    return outputs, output_lengths, cum_log_probs, latency
 
 
 _BATCHED_DEFAULTS = (("top_k", 50), ("top_p", 0.), ("beam_search_diversity_rate", 0.), ("temperature", 1.),
@@ -500,40 +532,48 @@ class CodeFuseHandler:
         except BaseException as err:  # noqa: B902 -- the reference logs and carries on
             logging.exception(err)
 
+    def _shared_seed(self):
+        """One random seed per request, the same on every tensor-parallel rank (rank 0 draws, the others receive)."""
+        seed = random.randint(0, 1048576)
+        if self.world_size > 1:
+            import torch.distributed as dist
+            box = torch.IntTensor([seed]).to("cuda")
+            dist.broadcast(box, src=0)
+            seed = int(box.cpu()[0])
+        return seed
+
+    def _stream_printers(self, batch, beam):
+        """(callback for GptNeoX.forward, closer) that print every hypothesis' text as its tokens arrive."""
+        grid = [[token_stream_2_str_stream_convertor(self.model.end_id, self.tokenizer, self.local_rank)
+                 for _ in range(beam)] for _ in range(batch)]
+
+        def feed(tokens):  # tokens[b][w]
+            for row, row_tokens in zip(grid, tokens):
+                for printer, token in zip(row, row_tokens):
+                    printer.append_token(token)
+
+        def on_step(message):
+            try:
+                feed(message["last_tokens"])
+            except BaseException as err:  # noqa: B902 -- a printing problem must not end the generation
+                logging.error("callback error: %s" % str(err))
+
+        return on_step, lambda: feed([[self.model.end_id] * beam] * batch)
+
     def predict(self, request_dict, trace_id):
-        import torch.distributed as dist
         logging.info("%s request: %s" % (trace_id, json.dumps(request_dict, ensure_ascii=False)))
         try:
-            seed = random.randint(0, 1048576)
-            if self.world_size > 1:
-                t = torch.IntTensor([seed]).to("cuda")
-                dist.broadcast(t, src=0)
-                seed = t.cpu().tolist()[0]
-            pkg = get_data_package(request_dict, seed)
-            batch, beam = len(pkg["texts"]), pkg["beam_width"]
-            stream = bool(request_dict.get("stream")) and self.local_rank == 0
-            callback, convertors = None, None
-            if stream:
-                convertors = [[token_stream_2_str_stream_convertor(self.model.end_id, self.tokenizer, self.local_rank)
-                               for _ in range(beam)] for _ in range(batch)]
-
-                def callback(message):
-                    try:
-                        for b in range(batch):
-                            for w in range(beam):
-                                convertors[b][w].append_token(message["last_tokens"][b][w])
-                    except BaseException as err:  # noqa: B902
-                        logging.error("callback error: %s" % str(err))
-            result, lengths, cum_log_probs, latency = generate(self.model, self.tokenizer, trie=self.trie,
-                                                               callback=callback, **pkg)
-            if stream:
-                for row in convertors:
-                    for conv in row:
-                        conv.append_token(self.model.end_id)
-            response = {"latency": latency, "random_seed": pkg["random_seed"], "generated_code": result,
-                        "length": lengths, "cum_log_prob": cum_log_probs}
-            text = json.dumps(response, ensure_ascii=False)
-            logging.info("%s response: %s" % (trace_id, text))
-            return 0, "ok", {"res": text}
+            pkg = get_data_package(request_dict, self._shared_seed())
+            on_step = close = None
+            if request_dict.get("stream") and self.local_rank == 0:
+                on_step, close = self._stream_printers(len(pkg["texts"]), pkg["beam_width"])
+            texts, lengths, cum_log_probs, latency = generate(self.model, self.tokenizer, trie=self.trie,
+                                                              callback=on_step, **pkg)
+            if close is not None:
+                close()
+            body = json.dumps({"latency": latency, "random_seed": pkg["random_seed"], "generated_code": texts,
+                               "length": lengths, "cum_log_prob": cum_log_probs}, ensure_ascii=False)
+            logging.info("%s response: %s" % (trace_id, body))
+            return 0, "ok", {"res": body}
         except BaseException:  # noqa: B902
             return 1, traceback.format_exc(), {"res": ""}

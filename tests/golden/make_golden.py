@@ -17,7 +17,8 @@ input/output vectors that pin the oracle (oracle/) and the host-side counterpart
                           attention / FFN output biases and HF's greedy logits + tokens on `prompt`.
   tiny_gptneox_tp2.json   sha256 of every tensor the reference loader returns for tensor_para_size=2, rank 0 and 1.
   harness_io.json         I/O of to_word_list_format / Trie.printAutoSuggestions / is_garbage /
-                          token_stream_2_str_stream_convertor / get_data_package captured from the reference.
+                          token_stream_2_str_stream_convertor / get_data_package / generate / CodeFuseHandler.predict
+                          captured from the reference (the last two around a recording stand-in for the model: FakeGpt).
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
@@ -182,6 +183,56 @@ class FakeTok:
         return "".join(inv.get(int(i), "") for i in ids)
 
 
+class FakeGpt:
+    """Stands in for the GptNeoX module inside generate() / CodeFuseHandler.predict(): records the keyword arguments it is
+    called with and returns fixed hypotheses (token by token through the callback first, like the op's streaming callback)."""
+    end_id = 2
+
+    def __init__(self, hypotheses):
+        self.hypotheses = hypotheses  # [B][beam] lists of generated token ids (end_id where a hypothesis ends)
+        self.saw = None
+
+    def __call__(self, **kw):
+        self.saw = {k: ({"dtype": str(v.dtype), "value": v.tolist()} if torch.is_tensor(v) else v)
+                    for k, v in kw.items() if k != "callback"}
+        self.saw["has_callback"] = kw.get("callback") is not None
+        ids, n_out, beam = kw["start_ids"], kw["output_len"], kw["beam_width"]
+        B, S = ids.shape
+        out = torch.full((B, beam, S + n_out), self.end_id, dtype=torch.int32)
+        for b in range(B):
+            for w in range(beam):
+                out[b, w, :S] = ids[b]
+                hyp = self.hypotheses[b][w][:n_out]
+                out[b, w, S:S + len(hyp)] = torch.tensor(hyp, dtype=torch.int32)
+        if kw.get("callback") is not None:
+            for t in range(n_out):
+                kw["callback"]({"last_tokens": out[:, :, S + t].tolist()})
+        lengths = torch.full((B, beam), S + n_out, dtype=torch.int32)
+        scores = torch.tensor([[-(1.0 + b) - 0.25 * w for w in range(beam)] for b in range(B)])
+        return out, lengths, scores
+
+
+def generate_cases(tok):
+    """(keyword arguments of generate(), the stand-in model's hypotheses) -- shared with tests/test_harness_golden.py"""
+    v = tok.vocab
+    return [
+        (dict(texts=["def", "for ("], output_len=4, beam_width=1, top_k=[3, 50], temperature=[1.0, 0.5],
+              random_seed=[1, 2], stop_words_list=[["\n}"], ["x"]]),
+         [[[v[" i"], v["="], 2, v["x"]]], [[v["int"], v[" i"], v["="], v["éé"]]]]),
+        (dict(texts=None, input_ids_list=[[v["ret"], v["x"]], [v["a"]]], output_len=3, beam_width=2, top_k=5, top_p=0.9,
+              repetition_penalty=1.25, last_token_list=["re", "zzz"]),
+         [[[v["y"], v["\n"], v["}"]], [2, 2, 2]], [[v["中"], v["文"], 2], [v["b"], v["éé"], v["éé"]]]]),
+    ]
+
+
+def predict_case(tok):
+    v = tok.vocab
+    req = {"out_seq_length": 4, "stream": True,
+           "prompts": [{"prompt": "for (", "random_seed": 11, "top_k": 4, "stop_words": ["\n}"]},
+                       {"prompt": "def", "random_seed": 12, "top_k": 2, "stop_words": ["x"]}]}
+    return req, [[[v["int"], v[" i"], v["\n"], v["x"]]], [[v[" "], v["a"], v["b"], 2]]]
+
+
 def harness_io():
     import contextlib
     import io
@@ -217,10 +268,30 @@ def harness_io():
     res["get_data_package"] = {"in": req, "seed": 77, "out": ce.get_data_package(req, 77)}
     req2 = {"out_seq_length": 4, "beam_width": 1, "prompts": [{"prompt": "a"}]}
     res["get_data_package2"] = {"in": req2, "seed": 5, "out": ce.get_data_package(req2, 5)}
+    gen = []
+    for kwargs, hyps in generate_cases(tok):
+        gpt = FakeGpt(hyps)
+        texts, lengths, scores, _ = ce.generate(gpt, tok, trie=trie, **kwargs)
+        gen.append({"model_saw": gpt.saw, "texts": texts, "lengths": lengths, "cum_log_probs": scores})
+    res["generate"] = gen
+    req3, hyps3 = predict_case(tok)
+    handler = ce.CodeFuseHandler.__new__(ce.CodeFuseHandler)
+    handler.local_rank, handler.world_size, handler.tokenizer, handler.trie = 0, 1, tok, trie
+    handler.model = FakeGpt(hyps3)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        code, msg, out = handler.predict(req3, "trace-0")
+    body = json.loads(out["res"])
+    body.pop("latency")
+    res["predict"] = {"code": code, "message": msg, "response": body, "printed": buf.getvalue(), "model_saw": handler.model.saw}
     return res
 
 
 def main():
+    if "--harness-only" in sys.argv:
+        with open(os.path.join(OUT, "harness_io.json"), "w") as f:
+            json.dump(harness_io(), f, indent=1, ensure_ascii=False)
+        return
     cfg, m = build_hf()
     beam_golden(m, cfg)
     if "--beam-only" in sys.argv:

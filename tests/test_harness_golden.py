@@ -135,3 +135,41 @@ def test_quant_and_save_round_trip(hf_model, tmp_path):
     for x, y in zip(a.scale, b.scale):
         assert torch.equal(x, y)
     assert all(t.numel() == 0 for g in (2, 4, 6, 8) for t in a.w[g * 2:(g + 1) * 2])
+
+
+def _saw(model):
+    return json.loads(json.dumps(model.saw))
+
+
+def test_generate_marshals_and_post_processes_like_the_reference(io_golden, tok):
+    """generate() around a recording stand-in for the model (make_golden.FakeGpt): the tensors the model is called with --
+    padded prompts, per-row sampling tensors and their dtypes, the stop-word and optional-last-token tensors -- and the texts /
+    lengths / scores cut out of its hypotheses equal what the reference's generate() did with the same stand-in."""
+    mg = _load_make_golden()
+    trie = harness.Trie(tok.get_vocab())
+    for (kwargs, hyps), want in zip(mg.generate_cases(tok), io_golden["generate"]):
+        gpt = mg.FakeGpt(hyps)
+        texts, lengths, scores, latency = harness.generate(gpt, tok, trie=trie, **kwargs)
+        assert _saw(gpt) == want["model_saw"]
+        assert texts == want["texts"] and lengths == want["lengths"]
+        assert scores == want["cum_log_probs"] and latency >= 0.0
+
+
+def test_predict_streams_and_answers_like_the_reference(io_golden, tok):
+    mg = _load_make_golden()
+    req, hyps = mg.predict_case(tok)
+    handler = harness.CodeFuseHandler.__new__(harness.CodeFuseHandler)
+    handler.local_rank, handler.world_size, handler.tokenizer = 0, 1, tok
+    handler.trie, handler.model = harness.Trie(tok.get_vocab()), mg.FakeGpt(hyps)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        code, msg, out = handler.predict(req, "trace-0")
+    want = io_golden["predict"]
+    body = json.loads(out["res"])
+    assert body.pop("latency") >= 0.0
+    assert (code, msg, body) == (want["code"], want["message"], want["response"])
+    assert buf.getvalue() == want["printed"]
+    assert _saw(handler.model) == want["model_saw"]
+    # a failing request is answered, not raised
+    code, msg, out = handler.predict({"prompts": [{"prompt": 3}], "out_seq_length": 1}, "trace-1")
+    assert code == 1 and out == {"res": ""} and "Traceback" in msg
