@@ -1083,6 +1083,10 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_PERSIST_CS3")) {
             e->persist_cs3 = atoi(m);
         }
+        if (const char* m = getenv("FTCF_PERSIST_OWN")) {  // 0: P3 as K pieces merged by an owner (the form until round 5), 1: own-group
+                                                            // layout wherever the shape divides, 2 (default): where it measured faster
+            e->persist_own = atoi(m);
+        }
         e->decode_branches = cfg->tensor_para_size == 1 ? 1 : 0;
         if (const char* m = getenv("FTCF_DECODE_BRANCHES")) {
             e->decode_branches = atoi(m);

@@ -112,7 +112,7 @@ struct ftcf_gptneox {
     int*      h_flags = nullptr;  // pinned
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
-    int                 persist = 1, persist_tp = 1, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10;
+    int                 persist = 1, persist_tp = 1, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10, persist_own = 2;
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -270,7 +270,7 @@ struct ftcf_gptneox {
                 && (tpn == 1 || (persist_tp && cfg.comm && cfg.comm->win_ok))) {
                 // (a local group shares ONE device: every rank gets 1 / world of its compute units)
                 const int nb = tp_local ? std::max(1, (persist_nb > 0 ? persist_nb : num_cu) / tpn) : persist_nb;
-                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3);
+                pplan = persist_plan(B, H, hl, il, nhl, dh, s_max, int8, num_cu, nb, persist_cs1, persist_cs3, persist_own, L);
                 const bool resident = !pplan.ok ? false
                                       : tp_local ? persist_group_resident(pplan, int8, B, dh, num_cu, tpn)
                                                  : persist_resident(pplan, int8, B, dh, num_cu, tpn);
@@ -280,13 +280,13 @@ struct ftcf_gptneox {
             }
             if (pplan.ok) {
                 ps_slab_n   = (size_t)B * 3 * hl / 2 + (size_t)B * il / 2 + (size_t)B * hl / 2 + (size_t)B * H / 2
-                            + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 + (size_t)B * nhl * pplan.nsplit * (dh + 2);
+                            + (size_t)pplan.gp_n + (size_t)B * nhl * pplan.nsplit * (dh + 2);
                 ps_gq       = c.take<unsigned long long>(ps_slab_n + 8);
                 ps_gm       = ps_gq ? ps_gq + (size_t)B * 3 * hl / 2 : nullptr;
                 ps_gc       = ps_gq ? ps_gm + (size_t)B * il / 2 : nullptr;
                 ps_gx       = ps_gq ? ps_gc + (size_t)B * hl / 2 : nullptr;
                 ps_gp       = ps_gq ? ps_gx + (size_t)B * H / 2 : nullptr;
-                ps_ga       = ps_gq ? ps_gp + (size_t)(H / 16) * (pplan.PA + pplan.PB) * B * 16 : nullptr;
+                ps_ga       = ps_gq ? ps_gp + (size_t)pplan.gp_n : nullptr;
                 ps_err      = ps_gq ? reinterpret_cast<int*>(ps_gq + ps_slab_n) : nullptr;
                 d_players   = c.take<PersistLayer>(L);
                 ps_tab      = c.take<char>(persist_table_bytes(pplan) * pplan.NB);

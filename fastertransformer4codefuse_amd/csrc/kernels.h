@@ -207,6 +207,8 @@ struct PersistPlan {
     int    e1, e3;    // tile-table entries per wave (P1 / P3)
     int    cs1, cs3;  // stream share of a control wave in 1/16 of a streamer wave's (P1 / P3)
     int    qrot;      // rotation of the QKV column-group split over the workgroups (which ones get the lighter P1 share)
+    int    own;       // P3 in the own-group layout (whole column groups per workgroup: one hop at the layer boundary)
+    long   gp_n;      // granules of the partial-sum slab (PersistParams::gp)
     size_t smem;
 };
 struct PersistParams {
@@ -215,7 +217,7 @@ struct PersistParams {
     const f16*          x_in;        // [M][H] input of layer l_begin (plain memory)
     f16*                x_out;       // [M][H] output of layer l_end-1
     // granule slabs (pairs of halves unless noted): qkv [M][3Hl/2], mid [M][Il/2], ctx [M][Hl/2], x' [M][H/2],
-    // K pieces [NG*(PA+PB)][M*16] (fp32), attention partials [B][nh][nsplit][dh+2] (fp32); zero at request start
+    // K pieces [NG*(PA+PB)][M*16] (fp32; own-group layout: plan.gp_n granules), attention partials [B][nh][nsplit][dh+2] (fp32); zero at request start
     unsigned long long *gq, *gm, *gc, *gx, *gp, *ga;
     int*                err;              // sticky give-up flag (0 = fine)
     int                 H, Hl, Il, nh, dh, rot, s_max, B, tp;
@@ -244,7 +246,7 @@ struct PersistGroupParams {  // local group launch: every rank's parameters, nb 
     int           world, nb;
 };
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int cs1, int cs3);
+                         int cs1, int cs3, int own = 0, int L = 0);
 // every workgroup of the plan's grid resident at once on this device?  (also raises the kernel's dynamic-LDS limit there)
 bool        persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp = 1);
 // bytes of the table region one workgroup stores / loads (PersistParams::tab holds NB of them)
@@ -254,7 +256,9 @@ void        launch_decode_persistent(const PersistParams& p, bool int8, hipStrea
 bool        persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world);
 void        launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipStream_t s);
 // tensor-parallel instantiations (kernels_persist_tp.hip); nullptr when the shape has none
-const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group);
+const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group, int own = 0);
+// own-group instantiations for one GPU (kernels_persist_own.hip)
+const void* persist_own_kernel(bool int8, int M, int dh, int uk);
 
 // ---- persistent decode layers for 3..16 rows : kernels_rows.hip ----
 // One launch runs layers [l_begin, l_end) of the batched decode step (GptNeoXDecoder.cc:245-384, any B <= 16) on one resident

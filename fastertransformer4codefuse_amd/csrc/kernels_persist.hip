@@ -10,12 +10,12 @@ namespace ftcf {
 static size_t ps_smem_bytes(int M, int H, int xs_halves, int dh, int s_max, int nsplit, int e1, int e3)
 {
     return (size_t)M * H * 2 + (size_t)xs_halves * 2 + (size_t)PS_RMAX * PS_NW * M * 16 * 4 + ps_att_bytes(dh, s_max, nsplit)
-           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (e1 + e3) * 4
+           + 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + PS_OT_N * 4 + (size_t)PS_NW * (e1 + e3) * 4
            + (size_t)PS_NW * (e1 + e3) / PS_U * 4;
 }
 
 PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max, bool int8, int num_cu, int force_nb,
-                         int cs1, int cs3)
+                         int cs1, int cs3, int own, int L)
 {
     PersistPlan pl{};
     const int   M  = B;
@@ -108,6 +108,24 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
     if (best > 1e29) {
         return pl;
     }
+    // P3 in the own-group layout (persist_device.hip.h "own-group layout"): whole column groups per workgroup, one hop at the
+    // layer boundary instead of two; where the shape does not divide that way the K pieces above stay
+    // own = 2 (auto): where it measured faster -- one rank's shard of TP 2 / 4 at the 13B shape +2.7 / +2.3 %, one GPU +0.3 %; a
+    // TP 8 shard (63 tiles per workgroup: the exchange's round trip is the boundary, the wide sweeps only add) -2 %, so not below
+    // 100 tiles of [FFN2 | out-proj] per workgroup (profiles/r06_notes.md)
+    pl.own = 0;
+    if (own == 2 && (long)NG * (KT_a + KT_b) < 100L * NB) {
+        own = 0;
+    }
+    if (own != 0 && L > 0 && ps_own_ok(NB, NG, M)) {
+        RunRec tmp[PS_RMAX];
+        const int cs = cs3;
+        bool ok = cs >= 1;
+        for (int b = 0; b < NB && ok; b++) {
+            ok = ps_own_remote(b, NB, NG, KT_a, KT_b, TK, M, Il, cs, tmp, nullptr, 0) <= PS_OWN_MAXR;
+        }
+        pl.own = ok ? 1 : 0;
+    }
     // tile-table entries per wave: the exact maximum over workgroups and waves, in whole rotations (e3c: control waves, P3)
     int  e1 = 0, e3 = 0;
     {
@@ -126,16 +144,19 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
                 const int t0 = ((rA0 + j - nB) / NG) * pl.RLa;
                 return std::min(pl.RLa, KT_a - t0);
             };
-            int T3 = 0;
-            for (int j = 0; j < nB + nA; j++) {
-                T3 += nt3(j);
+            RunRec    own_r[PS_RMAX];
+            const int own_n = pl.own ? ps_own_runs(b, NB, NG, KT_a, KT_b, TK, M, Il, own_r) : 0;
+            auto      nt3o  = [&](int j) { return own_r[j].nt; };
+            int       T3    = 0;
+            for (int j = 0; j < (pl.own ? own_n : nB + nA); j++) {
+                T3 += pl.own ? nt3o(j) : nt3(j);
             }
             for (int w = 0; w < PS_NW; w++) {
                 int tb, te;
                 ps_wave_range(nr1 * KT, w, cs1, tb, te);
                 e1 = std::max(e1, ps_wave_entries(nr1, nt1, tb, te));
                 ps_wave_range(T3, w, cs3, tb, te);
-                e3 = std::max(e3, ps_wave_entries(nB + nA, nt3, tb, te));
+                e3 = std::max(e3, pl.own ? ps_wave_entries(own_n, nt3o, tb, te) : ps_wave_entries(nB + nA, nt3, tb, te));
             }
         }
     }
@@ -152,12 +173,24 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
         return pl;
     }
     pl.smem = ps_smem_bytes(M, H, pl.xs_halves, dh, s_max, nsplit, pl.e1, pl.e3);
+    if (pl.own) {  // the kernel's LDS copy of the per-layer pointer table
+        const size_t with = pl.smem + (((size_t)L * sizeof(PersistLayer) + 15) & ~(size_t)15);
+        if (with > 160 * 1024) {
+            return persist_plan(B, H, Hl, Il, nh, dh, s_max, int8, num_cu, force_nb, cs1, cs3, 0, L);
+        }
+        pl.smem = with;
+    }
     if (pl.smem > 160 * 1024) {
         return pl;
     }
     // (round 3, on the kernel with the DPP reductions: the light share on the odd XCDs -- rotation 1 or 3 -- measures 2468-2469 us per
     // launch against 2480-2486 with it on the even ones, in two builds: profiles/r03_notes.md)
     pl.qrot = 1 % NB;
+    // K-piece partials: [NG * (PA + PB)][M * 16] ; own-group layout: [NS * PC pieces][2 matrices][PS_NW waves][M * 16]
+    {
+        const int no = NG / NB, NS = NG - no * NB;
+        pl.gp_n      = pl.own ? (long)(NS > 0 ? NB : 0) * 2 * PS_NW * M * 16 + 16 : (long)NG * (pl.PA + pl.PB) * M * 16;
+    }
     pl.ok = 1;
     return pl;
 }
@@ -165,7 +198,7 @@ PersistPlan persist_plan(int B, int H, int Hl, int Il, int nh, int dh, int s_max
 size_t persist_table_bytes(const PersistPlan& pl)
 {
     // rt1 | rt3 | rsc | red | misc | lt1 | lt3 | bt1 | bt3 (persist_device.hip.h, the carve of the kernel's LDS)
-    return 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + (size_t)PS_NW * (pl.e1 + pl.e3) * 4
+    return 2 * sizeof(RunRec) * PS_RMAX + PS_RMAX * 16 * 2 + 64 * 4 + 64 * 4 + PS_OT_N * 4 + (size_t)PS_NW * (pl.e1 + pl.e3) * 4
            + (size_t)PS_NW * (pl.e1 + pl.e3) / PS_U * 4;
 }
 
@@ -174,8 +207,11 @@ static const void* ps_kernel()
 {
     return reinterpret_cast<const void*>(&k_decode_persistent<INT8, M, DH, UK, false, false>);
 }
-static const void* ps_kernel_for(bool int8, int M, int dh, int uk)
+static const void* ps_kernel_for(bool int8, int M, int dh, int uk, int own)
 {
+    if (own) {
+        return persist_own_kernel(int8, M, dh, uk);
+    }
 #define PS_SEL(I8, MM, D)                                                                                              \
     if (int8 == I8 && M == MM && dh == D) {                                                                            \
         return uk == PS_UK_LONG ? ps_kernel<I8, MM, D, PS_UK_LONG>() : ps_kernel<I8, MM, D, PS_UK>();                  \
@@ -217,14 +253,14 @@ static bool ps_kernel_resident(const void* k, const PersistPlan& pl, int num_cu,
 }
 bool persist_group_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int world)
 {
-    return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, true), pl, num_cu, (long)pl.NB * world);
+    return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, true, pl.own), pl, num_cu, (long)pl.NB * world);
 }
 bool persist_resident(const PersistPlan& pl, bool int8, int M, int dh, int num_cu, int tp)
 {
     if (tp > 1) {
-        return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false), pl, num_cu, pl.NB);
+        return ps_kernel_resident(persist_tp_kernel(int8, M, dh, pl.uk, false, pl.own), pl, num_cu, pl.NB);
     }
-    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk), pl, num_cu, pl.NB);
+    return ps_kernel_resident(ps_kernel_for(int8, M, dh, pl.uk, pl.own), pl, num_cu, pl.NB);
 }
 
 void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
@@ -233,8 +269,8 @@ void launch_decode_persistent(const PersistParams& p, bool int8, hipStream_t s)
     FTCF_CHECK_ARG(p.dh == 64 || p.dh == 128, "size_per_head must be 64 or 128");
     FTCF_CHECK_ARG(p.rot % 2 == 0 && p.rot <= p.dh && (p.rot == 0 || p.rot_table != nullptr), "bad rotary configuration");
     FTCF_CHECK_ARG(p.L <= 255, "at most 255 layers");
-    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false)
-                             : ps_kernel_for(int8, p.B, p.dh, p.plan.uk);
+    const void* k = p.tp > 1 ? persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, false, p.plan.own)
+                             : ps_kernel_for(int8, p.B, p.dh, p.plan.uk, p.plan.own);
     FTCF_CHECK_ARG(k != nullptr, "persistent decode: no kernel for this shape");
     FTCF_CHECK_ARG(p.tp >= 1 && p.tp <= PERSIST_MAX_TP && p.tp_rank >= 0 && p.tp_rank < p.tp, "bad tensor-parallel rank");
     PersistParams pp     = p;
@@ -246,7 +282,7 @@ void launch_decode_persistent_group(const PersistGroupParams& g, bool int8, hipS
 {
     FTCF_CHECK_ARG(g.world >= 2 && g.world <= PERSIST_MAX_TP && g.nb >= 1, "bad local group");
     const PersistParams& p = g.p[0];
-    const void*          k = persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true);
+    const void*          k = persist_tp_kernel(int8, p.B, p.dh, p.plan.uk, true, p.plan.own);
     FTCF_CHECK_ARG(k != nullptr && p.plan.ok && p.plan.NB == g.nb, "persistent decode: no group kernel for this shape");
     PersistGroupParams gg     = g;
     void*              args[] = {&gg};

@@ -6,8 +6,13 @@
 
 namespace ftcf {
 
-const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group)
+const void* persist_tp_own_kernel(bool int8, int M, int dh, int uk, bool group);  // kernels_persist_tp_own.hip
+
+const void* persist_tp_kernel(bool int8, int M, int dh, int uk, bool group, int own)
 {
+    if (own) {
+        return persist_tp_own_kernel(int8, M, dh, uk, group);
+    }
     if (uk != PS_UK) {
         return nullptr;
     }

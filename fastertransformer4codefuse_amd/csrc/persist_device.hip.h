@@ -53,7 +53,7 @@ constexpr bool PS_FULL_P1 = true, PS_FULL_P3 = false;
 constexpr int PS_NLN      = 2;           // LayerNorm parameter vectors (f16x8) per thread and array: H <= 8192
 
 typedef const PersistLayer PsLayerC;
-#define PS_LAYER(p, l) ((p).layers[l])
+#define PS_LAYER(p, l) (lay[l])  // (`lay`: the per-layer table -- global memory, or the workgroup's LDS copy of it)
 #define PS_RLX __ATOMIC_RELAXED
 #define PS_AGT __HIP_MEMORY_SCOPE_AGENT
 // pointers that come out of the per-layer table in memory are GLOBAL: say so (a flat access also counts on lgkmcnt)
@@ -136,6 +136,52 @@ __device__ __forceinline__ void ps_sweep(const u64* g, const int n, const int ti
     }
 }
 
+// The same for a slice of up to NMAX granules per thread in ONE round trip (own-group layout: all of mid, all of ctx): the k-th
+// load of a thread exists when k * nthr < n (uniform), so a short slice -- a tensor-parallel shard's -- issues what it needs.
+// Addresses are a uniform base per k plus the thread's index (one VGPR for all loads: twenty clamped 64-bit addresses, live
+// across the retry loop beside the control waves' prefetched batches, spilled); a pass may therefore read up to nthr - 1 granules
+// PAST n -- the slabs swept this way are followed by other slabs of the same allocation -- and ignores what it finds there.
+template<int NMAX, typename F>
+__device__ __forceinline__ void ps_sweep_wide(const u64* g, const int n, const int tid, const int nthr, const unsigned tag,
+                                              int* err, const int code, F&& sink)
+{
+    for (int base = 0; base < n; base += nthr * NMAX) {
+        u64       gv[NMAX];
+        const int kn    = (n - base + nthr - 1) / nthr;  // loads of this pass (uniform), <= NMAX of them issued
+        int       spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) {
+                if (k < kn) {
+                    const u64* gk = g + (base + k * nthr);  // uniform
+                    gv[k]         = ld_granule(&gk[tid]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) {
+                if (k < kn) {
+                    ok &= ((unsigned)(gv[k] >> 32) == tag) || (base + k * nthr + tid >= n);
+                }
+            }
+            if (__all(ok)) {
+                break;
+            }
+            if (ps_give_up(spins, err, code)) {
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) {
+            const int i = base + k * nthr + tid;
+            if (k < kn && i < n) {
+                sink(i, (unsigned)gv[k]);
+            }
+        }
+    }
+}
+
 // wave w's share of T tiles: control waves get cs/16 of a streamer wave's share and sit at the END of the flat space
 // (P3 puts the out-proj pieces there: the control waves are the ones that wait for ctx anyway).  Shares start at whole
 // batches, so that with run lengths that are multiples of PS_U every batch lies inside one run.
@@ -147,45 +193,136 @@ __host__ __device__ inline void ps_wave_range(const int T, const int w, const in
     tb              = (int)((long)T * c0 / total) / PS_U * PS_U;
     te              = (c1 == total) ? T : (int)((long)T * c1 / total) / PS_U * PS_U;
 }
-// ---- P1 shares (round 6) -------------------------------------------------------------------------------------------
-// A workgroup owns whole FFN1 column groups (their gelu needs the complete sum) and an INTERVAL [qb(b), qb(b + 1)) of the flat
-// QKV tile space (tile t = k-tile t % KT of column group t / KT), sized so that every workgroup streams the same number of P1
-// tiles: a column group cut by an interval bound is summed by its consumer, the attention workgroup, from fp32 partials in
-// slot order (q/k/v carry no bias and no activation, so a partial is as good as the sum).  Until round 5 the QKV share was
-// whole column groups too: 3.75 per workgroup at 13B -- 720 tiles on three of four workgroups, 640 on the fourth, and the
-// layer ran at the pace of the heavy ones; a tensor-parallel shard with fewer groups than workgroups was 160 against 80.
-// Bounds are multiples of `unit` tiles (whole batches, and at most KT / unit pieces per group).
-__host__ __device__ inline int ps_q_unit(const int KT)
+// ---- P3 in the own-group layout (round 6; plan.own) ------------------------------------------------------------------
+// Until round 5 every 16-column group of [FFN2 | out-proj] was cut along K into PB + PA pieces dealt over the workgroups
+// (each workgroup: the same K range of ten groups -- a short sweep of mid), the pieces met as fp32 partials, the owner of a
+// group's last piece merged them and published x', and every workgroup gathered x': TWO chip-wide hops at the layer boundary,
+// 3.4 of a layer's 62.7 us on one GPU and 3 of 25 on a TP 8 shard.  Here a workgroup owns `no` = NG / NB column groups over
+// their WHOLE K extent -- it finishes them alone and publishes x' (or this rank's share into the exchange windows) the moment
+// its stream ends: one hop.  The NS = NG - no * NB groups left over (64 of 320 at 256 workgroups) are cut into PC = NB / NS
+// pieces of their flat [FFN2 | out-proj] tile space, one per workgroup; the pieces without ctx-dependent tiles come FIRST in
+// their workgroup's stream and every wave publishes its partial of such a run when it flushes it (PS_BT_PUB), so the owner of the
+// last piece (the merger: it has the out-proj tiles, which are late anyway) finds them waiting when its own stream ends.
+// Price: a workgroup reads all of mid and all of ctx (wide sweeps), not one K range of them.
+constexpr unsigned PS_BT_PUB    = 1u << 7;  // batch descriptor: the run's partial of this wave is published when flushed
+constexpr int      PS_OWN_MAXG  = 12;       // groups a workgroup finishes (own + one merged)
+constexpr int      PS_OWN_ITEMS = 3;        // (group, row, column) items per control-wave thread
+constexpr int      PS_OWN_MAXR  = 16;       // remote partial slots a merger adds
+// own table (LDS ints): [0] groups finished here, [1] remote slots, [2] index of the merged group (-1: none),
+// [4..15] group ids, [16..27] local runs of a group (FFN2 run | out-proj run << 8, 0xff: none), [28..43] remote slots
+// ((slot * PS_NW + wave) << 1 | out-proj)
+constexpr int PS_OT_G = 4, PS_OT_RUNS = 16, PS_OT_REM = 28, PS_OT_N = 64;
+// RunRec::pad in this layout: 1 piece of a shared group merged elsewhere (published at flush), 2 own group, 4 the merger's piece
+__host__ __device__ inline int ps_own_bound(const int KTT, const int PC, const int q)
 {
-    return KT % 16 == 0 ? 16 : (KT % 8 == 0 ? 8 : KT);
-}
-// QKV tiles in front of workgroup b, before the bounds are made monotone (a prefix maximum: a workgroup whose FFN1 groups
-// alone exceed the balanced share gets an empty interval)
-__host__ __device__ inline int ps_q_bound_raw(const int b, const int NT0, const int NF, const int KT, const int NB, const int unit)
-{
-    const long TQ = (long)NT0 * KT;
-    if (b <= 0) {
+    if (q <= 0) {
         return 0;
     }
-    if (b >= NB) {
-        return (int)TQ;
+    if (q >= PC) {
+        return KTT;
     }
-    long want = (long)(NT0 + NF) * KT * b / NB - (long)KT * ((long)NF * b / NB);
-    want      = want < 0 ? 0 : (want > TQ ? TQ : want);
-    const long r = (want + unit / 2) / unit * unit;
-    return (int)(r > TQ ? TQ : r);
+    long v = (long)KTT * q / PC;
+    if (KTT / PC >= 4 * PS_U) {
+        v = (v + PS_U / 2) / PS_U * PS_U;  // whole batches where a piece is long enough for it to matter
+    }
+    return (int)v;
 }
-// distinct bounds v with lo < v <= hi (bnd[0..NB] monotone): the pieces of a column group in front of a position
-__host__ __device__ inline int ps_q_cuts(const int* bnd, const int NB, const int lo, const int hi)
+__host__ __device__ inline bool ps_own_ok(const int NB, const int NG, const int M)
 {
-    int n = 0;
-    for (int b = 1; b < NB; b++) {
-        const int v = bnd[b];
-        n += (v > lo && v <= hi && v != bnd[b - 1]) ? 1 : 0;
+    if (NB < 1 || NG < NB) {
+        return false;
+    }
+    const int no = NG / NB, NS = NG - no * NB;
+    if (NS > 0 && NB % NS != 0) {
+        return false;
+    }
+    return 2 * no + 2 <= PS_RMAX && no + 1 <= PS_OWN_MAXG && (no + 1) * M * 16 <= PS_OWN_ITEMS * PS_NC * 64;
+}
+// the P3 runs of workgroup b in stream order (r may be null: count only)
+__host__ __device__ inline int ps_own_runs(const int b, const int NB, const int NG, const int KT_a, const int KT_b, const int TK,
+                                           const int M, const int Il, RunRec* r)
+{
+    const int no = NG / NB, NS = NG - no * NB, PC = NS > 0 ? NB / NS : 0, KTT = KT_a + KT_b;
+    int       n  = 0;
+    auto      put = [&](const int g, const int sel, const int t0, const int nt, const int rid, const int flags) {
+        if (r) {
+            RunRec x;
+            x.tile0 = g * (sel ? KT_a : KT_b) + t0;
+            x.sel   = sel;
+            x.nt    = nt;
+            x.xoff  = sel ? M * (Il + XPAD) + t0 * TK : t0 * TK;
+            x.xsel  = sel;
+            x.rid   = rid;
+            x.grp   = g;
+            x.pad   = flags;
+            r[n]    = x;
+        }
+        n++;
+    };
+    int sg = 0, lo = 0, hi = 0, q = 0;
+    if (NS > 0) {
+        sg = no * NB + b / PC;
+        q  = b % PC;
+        lo = ps_own_bound(KTT, PC, q);
+        hi = ps_own_bound(KTT, PC, q + 1);
+    }
+    const bool merger = NS > 0 && q == PC - 1;
+    const int  fl = lo < KT_b ? lo : KT_b, fh = hi < KT_b ? hi : KT_b;                 // FFN2 tiles [fl, fh) of the piece
+    const int  ol = (lo > KT_b ? lo : KT_b) - KT_b, oh = (hi > KT_b ? hi : KT_b) - KT_b;  // out-proj tiles [ol, oh)
+    const int  slot = NS > 0 ? ((sg - no * NB) * PC + q) * 2 : 0;
+    if (NS > 0 && !merger && fh > fl) {
+        put(sg, 0, fl, fh - fl, slot, 1);
+    }
+    for (int k = 0; k < no; k++) {
+        put(b * no + k, 0, 0, KT_b, -1, 2);
+    }
+    if (merger && fh > fl) {
+        put(sg, 0, fl, fh - fl, slot, 4);
+    }
+    if (NS > 0 && oh > ol) {
+        put(sg, 1, ol, oh - ol, slot + 1, merger ? 4 : 1);
+    }
+    for (int k = 0; k < no; k++) {
+        put(b * no + k, 1, 0, KT_a, -1, 2);
     }
     return n;
 }
-constexpr int PS_QSLOTS = 6;  // partial sums of one q/k/v column at most (the plan falls back to whole groups beyond)
+// merger b: the (slot, wave) partials the other pieces of its shared group publish, in the order they are added
+// (tmp: room for PS_RMAX runs; ent may be null: count only)
+__host__ __device__ inline int ps_own_remote(const int b, const int NB, const int NG, const int KT_a, const int KT_b, const int TK,
+                                             const int M, const int Il, const int cs3, RunRec* tmp, int* ent, const int maxent)
+{
+    const int no = NG / NB, NS = NG - no * NB, PC = NS > 0 ? NB / NS : 0;
+    if (NS == 0 || b % PC != PC - 1) {
+        return 0;
+    }
+    int n = 0;
+    for (int q = 0; q < PC - 1; q++) {
+        const int nr = ps_own_runs((b / PC) * PC + q, NB, NG, KT_a, KT_b, TK, M, Il, tmp);
+        int       T  = 0;
+        for (int j = 0; j < nr; j++) {
+            T += tmp[j].nt;
+        }
+        int pre = 0;
+        for (int j = 0; j < nr; j++) {
+            if (tmp[j].pad & 1) {
+                for (int w = 0; w < PS_NW; w++) {
+                    int tb, te;
+                    ps_wave_range(T, w, cs3, tb, te);
+                    const int a = tb > pre ? tb : pre, e = te < pre + tmp[j].nt ? te : pre + tmp[j].nt;
+                    if (e > a) {
+                        if (ent && n < maxent) {
+                            ent[n] = ((tmp[j].rid * PS_NW + w) << 1) | tmp[j].sel;
+                        }
+                        n++;
+                    }
+                }
+            }
+            pre += tmp[j].nt;
+        }
+    }
+    return n;
+}
 
 // table entries a wave needs for [tb, te) over runs of the given lengths: every run piece is padded to whole batches
 template<typename NT>
@@ -218,7 +355,7 @@ struct PsStage {
     int             xs0, xs1;
 };
 
-template<bool INT8, int M>
+template<bool INT8, int M, bool OWN = false>
 struct PsStream {
     static constexpr int TK = TileK<INT8>::value;
     u32x4      R0[PS_U], R1[PS_U], R2[PS_U], R3[PS_U];
@@ -230,6 +367,10 @@ struct PsStream {
     const int* flag;    // LDS arrival counter of the second x vector
     int        target;  // value it reaches when that vector is staged
     int        lane, wid;
+    // own-group layout: runs of the stage (LDS), the slab of published partials and the layer's tag (PS_BT_PUB)
+    const RunRec* rt;
+    u64*          gpub;
+    unsigned      ptag;
 
     __device__ __forceinline__ void bind(const PsStage& g_, const f16* rsc_, const f16* xs_, float* part_, const int tx,
                                          const int* flag_ = nullptr, const int target_ = 0)
@@ -254,12 +395,25 @@ struct PsStream {
                 (const __attribute__((address_space(1))) u32x4*)(base + ((size_t)(e & 0x7fffffffu) * 64 + lane) * 16));
         }
     }
-    __device__ __forceinline__ void flush(const int j)
+    __device__ __forceinline__ void flush(const int j, const unsigned bd)
     {
         if (lane < 16) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 part[((size_t)j * PS_NW + wid) * (M * 16) + m * 16 + lane] = acc_row(acc, m);
+            }
+        }
+        if constexpr (OWN) {
+            // a piece of a shared group whose merger is another workgroup: this wave's partial leaves NOW (the merger adds the
+            // waves' partials in a fixed order), long before the merger's own stream ends
+            if (bd & PS_BT_PUB) {
+                const int slot = ps_rfl(rt[j].rid);
+                if (lane < 16) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        st_granule(&gpub[((size_t)slot * PS_NW + wid) * (M * 16) + m * 16 + lane], ptag, acc_row(acc, m));
+                    }
+                }
             }
         }
         acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -298,7 +452,7 @@ struct PsStream {
             }
         }
         if (bd & PS_BT_FLUSH) {
-            flush(j);
+            flush(j, bd);
         }
     }
     // the first rotation: issued before the hand-off this stage waits for.  The streamer waves issue only half of it
@@ -391,7 +545,7 @@ __device__ __forceinline__ void ps_build_tables(const RunRec* rt, const int nrun
                 sel   = r.sel;
                 bd    = PS_BT_FAST | ((t + cnt == b) ? PS_BT_FLUSH : 0u) | ((unsigned)(j + jbase) << 2)
                      | ((unsigned)(r.xoff + off * TK) << 8) | (r.xsel ? (PS_BT_XSEL | PS_BT_WAIT) : 0u)
-                     | ((unsigned)cnt << 27);
+                     | ((unsigned)cnt << 27) | ((r.pad & 1) ? PS_BT_PUB : 0u);
             }
             eb += nb;
             pre += r.nt;
@@ -413,6 +567,8 @@ struct PsSmem {
     f16*      rsc;   // [RMAX][16] scales of the current stage
     float*    red;   // 64
     int*      misc;  // 64: [0] nmerge, [1..8] merge groups
+    int*      otab;  // PS_OT_N: the own-group layout's table (see PS_OT_*)
+    u64*      layt;  // own-group layout: the launch's per-layer pointer table, copied in at kernel entry
     unsigned *lt1, *lt3;  // [NW][e1], [NW][e3]
     unsigned *bt1, *bt3;  // [NW][e1 / PS_U], [NW][e3 / PS_U]
 };
@@ -429,13 +585,13 @@ __host__ __device__ inline size_t ps_att_bytes(int dh, int s_max, int nsplit)
 // attention of one (row b, head h, split sp) on the whole 8-wave workgroup
 // (decoder_masked_multihead_attention_template.hpp:1099-1919; same arithmetic as attn_device.hip.h::mmha_partial)
 // ---------------------------------------------------------------------------------------------------------------
-template<int DH, int UK, int NSW = 3 * DH / 2>
+template<int DH, int UK, int NSW = 3 * DH / 2, bool AL = (UK > PS_U)>
 struct PsAttn {
     static constexpr int LPK = DH / 8;
     static constexpr int NQ  = 3 * DH / 2;             // q | k | v granules (pairs of halves) of one head
     static constexpr int NB2 = (NQ + NSW - 1) / NSW;   // granules per sweeping thread (NSW threads sweep)
     static constexpr int KPI = 64 / LPK;
-    static constexpr bool ALIAS = UK > PS_U;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
+    static constexpr bool ALIAS = AL;  // rows live in the stream's register batches: K in R0 | R1, V in R2 | R3
     static_assert(UK <= 2 * PS_U, "K rows live in R0|R1, V rows in R2|R3");
     u32x4 kreg[ALIAS ? 1 : UK], vreg[ALIAS ? 1 : UK];
     template<typename ST>
@@ -1084,7 +1240,7 @@ __device__ __forceinline__ void ps_tp_exchange(const PersistParams& p, const uns
 // Rejected forms of this kernel (the attention on the control waves alone, P3 tiles prefetched into LDS, the LM head as the launch's
 // tail, q/k/v published from inside the stream, a second kernel with the attention branch under the FFN streams) are described
 // with their measurements in profiles/r03_notes.md and profiles/r04_notes.md; their code is no longer in the tree.
-template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false>
+template<bool INT8, int M, int DH, int UK, bool TP, bool GROUP = false, bool OWN = false>
 __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     const typename std::conditional<GROUP, PersistGroupParams, PersistParams>::type pa)
 {
@@ -1112,7 +1268,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     // loads are harmless re-reads); so do the two-row and tensor-parallel forms, which spilled 35-41 VGPRs without it.
     // The short one-row form -- the headline's -- keeps the code it was tuned with: the same change
     // there measured -0.7 % (profiles/r02_notes.md: hipcc's allocation of this kernel moves +-2 % with anything).
-    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP;
+    constexpr bool NOCARRY = UK > PS_U || M > 1 || TP || OWN;
     const int     H = p.H, Hl = p.Hl, Il = p.Il;
     const int     NB = p.plan.NB;
     const int     wid = threadIdx.x >> 6;
@@ -1142,6 +1298,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         q += 64 * 4;
         s.misc = reinterpret_cast<int*>(q);
         q += 64 * 4;
+        s.otab = reinterpret_cast<int*>(q);
+        q += PS_OT_N * 4;
         s.lt1 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * E1 * 4;
         s.lt3 = reinterpret_cast<unsigned*>(q);
@@ -1150,6 +1308,18 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         q += (size_t)PS_NW * (E1 / PS_U) * 4;
         s.bt3 = reinterpret_cast<unsigned*>(q);
         q += (size_t)PS_NW * (E3 / PS_U) * 4;
+        s.layt = reinterpret_cast<u64*>(q);
+    }
+    // The per-layer table (17 pointers per layer) lives in global memory and every use of it is a DEPENDENT vector load: on a
+    // compute unit whose other waves stream, ~3-4 us each -- once per layer at the boundary, in front of the gather of x', and
+    // again in front of the streamer waves' first requests.  The own-group kernels copy it into LDS when they start.
+    const PersistLayer* lay = p.layers;
+    if constexpr (OWN) {
+        const auto* src = PS_G(u64, p.layers);
+        for (int i = threadIdx.x; i < p.L * (int)(sizeof(PersistLayer) / 8); i += PS_NT) {
+            s.layt[i] = src[i];
+        }
+        lay = reinterpret_cast<const PersistLayer*>(s.layt);
     }
     if (p.d_stop && *p.d_stop) {
         return;  // every row has finished (a token of a multi-token graph behind the request's last one): uniform over the grid
@@ -1177,7 +1347,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     const int rB0 = (int)((long)NG * PB * bid / NB), rB1 = (int)((long)NG * PB * (bid + 1) / NB);
     const int rA0 = (int)((long)NG * PA * bid / NB), rA1 = (int)((long)NG * PA * (bid + 1) / NB);
     const int nB = rB1 - rB0, nA = rA1 - rA0;
-    const int nruns1 = nq + (f1 - f0), nruns3 = nB + nA;
+    const int nruns1 = nq + (f1 - f0);
+    const int nruns3 = OWN ? ps_own_runs(bid, NB, NG, KT_a, KT_b, TK, M, Il, nullptr) : nB + nA;
     const int n_items = p.B * p.nh * p.plan.nsplit;
     // The run tables and the per-wave tile / batch tables depend on the plan and the workgroup only -- not on the layer, the
     // token or the request.  Building them took 17.5 us of every launch (0.7 % of a token): the engine now builds them ONCE
@@ -1217,7 +1388,38 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             r.pad    = 0;
             s.rt1[j] = r;
         }
-        if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
+        if constexpr (OWN) {  // P3, own-group layout: the runs in stream order, the groups finished here, the merger's remote slots
+            if (threadIdx.x == 0) {
+                ps_own_runs(bid, NB, NG, KT_a, KT_b, TK, M, Il, s.rt3);
+                int ng = 0, mg = -1;
+                for (int j = 0; j < nruns3; j++) {  // groups in the order of their first run; a group has at most one run per matrix here
+                    const RunRec r = s.rt3[j];
+                    if (r.pad & 1) {
+                        continue;  // merged elsewhere
+                    }
+                    int k = 0;
+                    while (k < ng && s.otab[PS_OT_G + k] != r.grp) {
+                        k++;
+                    }
+                    if (k == ng) {
+                        s.otab[PS_OT_G + k]    = r.grp;
+                        s.otab[PS_OT_RUNS + k] = 0xffff;
+                        ng++;
+                    }
+                    if (r.pad & 4) {
+                        mg = k;
+                    }
+                    const int old = s.otab[PS_OT_RUNS + k];
+                    s.otab[PS_OT_RUNS + k] = r.sel ? ((old & 0xff) | (j << 8)) : ((old & 0xff00) | j);
+                }
+                s.otab[0] = ng;
+                s.otab[2] = mg;
+                // (the temporary run list of the other pieces' workgroups lives in the partial buffer, free until the first layer)
+                s.otab[1] = ps_own_remote(bid, NB, NG, KT_a, KT_b, TK, M, Il, p.plan.cs3, reinterpret_cast<RunRec*>(s.part),
+                                          &s.otab[PS_OT_REM], PS_OWN_MAXR);
+            }
+        }
+        else if ((int)threadIdx.x < nruns3) {  // P3: FFN2 K pieces first, then out-proj K pieces (piece-major ids)
             const int  j     = threadIdx.x;
             const bool isA   = j >= nB;
             const int  idx   = isA ? rA0 + (j - nB) : rB0 + j;
@@ -1348,7 +1550,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     auto body = [&](auto role) {
         constexpr bool    CTRL = decltype(role)::value;
         int               tid  = threadIdx.x;
-        PsStream<INT8, M> st;
+        PsStream<INT8, M, OWN> st;
         auto stamp = [&](const int l, const int k) {
             const int lane = tid & 63, wid = tid >> 6;
             if (p.ts && lane == 0) {
@@ -1357,7 +1559,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         };
         // ---- per-layer constants, fetched one stage ahead into registers (before that stage's prefetch) ----
         f16   r_sc1 = (f16)1.f, r_sc3 = (f16)1.f;  // scale of (run tid/16, column tid%16) of P1 / P3
-        f16   r_b1[2], r_bres[2];                  // ffn1 bias of the P1 epilogue items / residual bias of the merge items
+        constexpr int NBR = OWN ? PS_OWN_ITEMS : 2;
+        f16   r_b1[2], r_bres[NBR];                // ffn1 bias of the P1 epilogue items / residual bias of the merge items
         f16x8 r_ln[4][PS_NLN];                     // ln1_g, ln1_b, ln2_g, ln2_b vectors tid, tid + 512
         auto  load_sc1 = [&](const int l) {
             if constexpr (INT8) {
@@ -1408,13 +1611,14 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
         auto load_p3_consts = [&](const int l) {  // residual bias of layer l, P1 scales of layer l + 1
             if constexpr (CTRL) {
                 PsLayerC& lw = PS_LAYER(p, l);
-                const int           nm = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
+                const int           nm = OWN ? s.otab[0] : (s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE);
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < NBR; k++) {
                     const int t = tid + k * PS_NC * 64;
                     r_bres[k]   = (f16)0.f;
                     if (t < nm * M * 16) {
-                        r_bres[k] = PS_G(f16, lw.b_res)[s.misc[1 + t / (M * 16)] * 16 + (t & 15)];
+                        const int g = OWN ? s.otab[PS_OT_G + t / (M * 16)] : s.misc[1 + t / (M * 16)];
+                        r_bres[k]   = PS_G(f16, lw.b_res)[g * 16 + (t & 15)];
                     }
                 }
             }
@@ -1460,6 +1664,11 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             sg3.w0 = reinterpret_cast<const char*>(lw.w_ffn2);
             sg3.w1 = reinterpret_cast<const char*>(lw.w_out);
             st.bind(sg3, s.rsc, s.xs, s.part, tid, &s.misc[32], (l - p.l_begin + 1) * PS_NC);
+            if constexpr (OWN) {
+                st.rt   = s.rt3;
+                st.gpub = p.gp;
+                st.ptag = tag_base + (unsigned)l;
+            }
         };
 
         load_sc1(p.l_begin);
@@ -1602,7 +1811,8 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             // prefetch and the share still needs a second loaded latency: slower, profiles/r04_notes.md); ATT_WP -- the attention
             // with wave-private soft-max statistics (three workgroup barriers instead of five: +1 % on a shard, -1 % on one GPU).
             constexpr bool CTRL_EARLY = TP, ATT_WP = TP;
-            using Attn          = PsAttn<DH, UK>;
+            // (own-group layout: the short form keeps its rows in the idle stream batches too -- 64 VGPRs that the wide sweeps need)
+            using Attn          = PsAttn<DH, UK, 3 * DH / 2, (UK > PS_U) || OWN>;
             Attn       at;
             const bool has_item = bid < n_items;
             int        a_sp = 0, a_h = 0, a_b = 0;
@@ -1639,12 +1849,20 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             }
             // the K range of mid this workgroup's FFN2 pieces read -> LDS, by all eight waves (published at the end of P1: long
             // there), after the attention (ahead of it, it made the attention wait for the slowest FFN1)
+            if constexpr (OWN) {  // all of mid (the own groups run over the whole K), every row, one round trip
+                ps_sweep_wide<(TP ? 10 : 20)>(p.gm, (M * Il) >> 1, tid, PS_NT, tag, p.err, 6, [&](const int i, const unsigned v) {
+                    const int m = (M > 1 && i >= (Il >> 1)) ? 1 : 0, c = i - m * (Il >> 1);
+                    reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD))[c] = v;
+                });
+            }
+            else {
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                ps_sweep<3>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NT, tag, p.err, 6,
-                            [&](const int i, const unsigned v) {
-                                reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
-                            });
+                for (int m = 0; m < M; m++) {
+                    ps_sweep<3>(p.gm + (((size_t)m * Il + mid_lo) >> 1), (mid_hi - mid_lo) >> 1, tid, PS_NT, tag, p.err, 6,
+                                [&](const int i, const unsigned v) {
+                                    reinterpret_cast<unsigned*>(s.xs + (size_t)m * (Il + XPAD) + mid_lo)[i] = v;
+                                });
+                }
             }
             stamp(l, 7);
             __syncthreads();  // mid staged, attention scratch free
@@ -1701,12 +1919,22 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
                 if constexpr (CTRL_EARLY) {
                     st.prime();
                 }
+                if constexpr (OWN) {
+                    // All of ctx, 20 granules per thread and pass on one GPU.  (Waiting on ONE granule per head first and sweeping when
+                    // those carry the tag -- a quarter of the polling traffic -- costs a second loaded round trip: +3 us, measured.)
+                    ps_sweep_wide<(TP ? 10 : 20)>(p.gc, (M * Hl) >> 1, tid, PS_NC * 64, tag, p.err, 7, [&](const int i, const unsigned v) {
+                        const int m = (M > 1 && i >= (Hl >> 1)) ? 1 : 0, c = i - m * (Hl >> 1);
+                        reinterpret_cast<unsigned*>(s.xs + (size_t)M * (Il + XPAD) + (size_t)m * (Hl + XPAD))[c] = v;
+                    });
+                }
+                else {
 #pragma unroll
-                for (int m = 0; m < M; m++) {
-                    ps_sweep<5>(p.gc + (((size_t)m * Hl + ctx_lo) >> 1), (ctx_hi - ctx_lo) >> 1, tid, PS_NC * 64, tag,
-                                p.err, 7, [&](const int i, const unsigned v) {
-                                    reinterpret_cast<unsigned*>(s.xs + (size_t)M * (Il + XPAD) + (size_t)m * (Hl + XPAD) + ctx_lo)[i] = v;
-                                });
+                    for (int m = 0; m < M; m++) {
+                        ps_sweep<5>(p.gc + (((size_t)m * Hl + ctx_lo) >> 1), (ctx_hi - ctx_lo) >> 1, tid, PS_NC * 64, tag,
+                                    p.err, 7, [&](const int i, const unsigned v) {
+                                        reinterpret_cast<unsigned*>(s.xs + (size_t)M * (Il + XPAD) + (size_t)m * (Hl + XPAD) + ctx_lo)[i] = v;
+                                    });
+                    }
                 }
                 stamp(l, 14);
                 if (lane == 0) {
@@ -1722,21 +1950,53 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             stamp(l, 10);
             __syncthreads();
             asm volatile("" : "+v"(tid));
-            // K pieces -> granules
+            // own-group layout: the sums of the groups this workgroup finishes, out of the waves' partials (control waves; the
+            // partial buffer is the streamer waves' again behind the next barrier)
+            float own_sa[NBR], own_sb[NBR];
+            if constexpr (OWN) {
+                if constexpr (CTRL) {
+                    const int ng = s.otab[0];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int idx = tid + k * PS_NT;
-                if (idx < nruns3 * M * 16) {
-                    const int j = idx / (M * 16), r = idx % (M * 16);
-                    float     v = 0.f;
+                    for (int k2 = 0; k2 < NBR; k2++) {
+                        const int t = tid + k2 * PS_NC * 64;
+                        own_sa[k2]  = 0.f;
+                        own_sb[k2]  = 0.f;
+                        if (t < ng * M * 16) {
+                            const int k = t / (M * 16), r = t % (M * 16);
+                            const int runs = s.otab[PS_OT_RUNS + k], jf = runs & 0xff, jo = (runs >> 8) & 0xff;
+                            if (jf != 0xff) {
 #pragma unroll
-                    for (int w = 0; w < PS_NW; w++) {
-                        v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                                for (int w = 0; w < PS_NW; w++) {  // wave order: deterministic
+                                    own_sb[k2] += s.part[((size_t)jf * PS_NW + w) * (M * 16) + r];
+                                }
+                            }
+                            if (jo != 0xff) {
+#pragma unroll
+                                for (int w = 0; w < PS_NW; w++) {
+                                    own_sa[k2] += s.part[((size_t)jo * PS_NW + w) * (M * 16) + r];
+                                }
+                            }
+                        }
                     }
-                    st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
                 }
             }
-            const int  nmerge = s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE;
+            else {
+                // K pieces -> granules
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int idx = tid + k * PS_NT;
+                    if (idx < nruns3 * M * 16) {
+                        const int j = idx / (M * 16), r = idx % (M * 16);
+                        float     v = 0.f;
+#pragma unroll
+                        for (int w = 0; w < PS_NW; w++) {
+                            v += s.part[((size_t)j * PS_NW + w) * (M * 16) + r];
+                        }
+                        st_granule(&p.gp[(size_t)s.rt3[j].rid * (M * 16) + r], tag, v);
+                    }
+                }
+            }
+            const int  nmerge = OWN ? s.otab[0] : (s.misc[0] < PS_MAXMERGE ? s.misc[0] : PS_MAXMERGE);
             const bool last   = (l == p.l_end - 1);
             // layer_input/output alias for 0 < l < L-1 in the reference (GptNeoXDecoder.cc:249-250) -> residual form
             const int inplace = (l > 0 && l < p.L - 1) ? 1 : 0;
@@ -1755,41 +2015,85 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
             // merge the groups this workgroup owns (control waves) -> x'
             if constexpr (CTRL) {
 #pragma unroll
-                for (int k2 = 0; k2 < 2; k2++) {
+                for (int k2 = 0; k2 < NBR; k2++) {
                     const int t = tid + k2 * PS_NC * 64;
                     if (t < nmerge * M * 16) {
                         const int k = t / (M * 16), r = t % (M * 16), m = r >> 4, c = r & 15;
-                        const int g = s.misc[1 + k];
-                        u64       gv[PS_MAXP];
-                        int       spins = 0;
-                        for (;;) {
-                            bool ok = true;
+                        const int g = OWN ? s.otab[PS_OT_G + k] : s.misc[1 + k];
+                        float     sa = 0.f, sb = 0.f;
+                        if constexpr (OWN) {
+                            // the group of which this workgroup holds the last piece: the other pieces' partials, one per (run,
+                            // wave) that streamed a part of it, were published when those waves flushed them -- long ago
+                            const int nrem = s.otab[1];
+                            if (nrem > 0 && k == s.otab[2]) {
+                                u64 gv[PS_OWN_MAXR];
+                                int spins = 0;
+                                for (;;) {
+                                    bool ok = true;
 #pragma unroll
-                            for (int q = 0; q < PS_MAXP; q++) {
-                                if (q < PA + PB) {
-                                    const int rid = (q < PA) ? NG * PB + q * NG + g : (q - PA) * NG + g;
-                                    gv[q]         = ld_granule(&p.gp[(size_t)rid * (M * 16) + r]);
+                                    for (int q = 0; q < PS_OWN_MAXR; q++) {
+                                        if (q < nrem) {
+                                            gv[q] = ld_granule(&p.gp[(size_t)(s.otab[PS_OT_REM + q] >> 1) * (M * 16) + r]);
+                                        }
+                                    }
+#pragma unroll
+                                    for (int q = 0; q < PS_OWN_MAXR; q++) {
+                                        if (q < nrem) {
+                                            ok &= ((unsigned)(gv[q] >> 32) == tag);
+                                        }
+                                    }
+                                    if (ok || ps_give_up(spins, p.err, 4)) {
+                                        break;
+                                    }
+                                    __builtin_amdgcn_s_sleep(1);
+                                }
+#pragma unroll
+                                for (int q = 0; q < PS_OWN_MAXR; q++) {  // slot order: deterministic
+                                    if (q < nrem) {
+                                        const float v = __uint_as_float((unsigned)gv[q]);
+                                        if (s.otab[PS_OT_REM + q] & 1) {
+                                            sa += v;
+                                        }
+                                        else {
+                                            sb += v;
+                                        }
+                                    }
                                 }
                             }
-#pragma unroll
-                            for (int q = 0; q < PS_MAXP; q++) {
-                                if (q < PA + PB) {
-                                    ok &= ((unsigned)(gv[q] >> 32) == tag);
-                                }
-                            }
-                            if (ok || ps_give_up(spins, p.err, 4)) {
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
+                            sa += own_sa[k2];
+                            sb += own_sb[k2];
                         }
-                        float sa = 0.f, sb = 0.f;
+                        else {
+                            u64 gv[PS_MAXP];
+                            int spins = 0;
+                            for (;;) {
+                                bool ok = true;
 #pragma unroll
-                        for (int q = 0; q < PS_MAXP; q++) {  // piece order: deterministic
-                            if (q < PA) {
-                                sa += __uint_as_float((unsigned)gv[q]);
+                                for (int q = 0; q < PS_MAXP; q++) {
+                                    if (q < PA + PB) {
+                                        const int rid = (q < PA) ? NG * PB + q * NG + g : (q - PA) * NG + g;
+                                        gv[q]         = ld_granule(&p.gp[(size_t)rid * (M * 16) + r]);
+                                    }
+                                }
+#pragma unroll
+                                for (int q = 0; q < PS_MAXP; q++) {
+                                    if (q < PA + PB) {
+                                        ok &= ((unsigned)(gv[q] >> 32) == tag);
+                                    }
+                                }
+                                if (ok || ps_give_up(spins, p.err, 4)) {
+                                    break;
+                                }
+                                __builtin_amdgcn_s_sleep(1);
                             }
-                            else if (q < PA + PB) {
-                                sb += __uint_as_float((unsigned)gv[q]);
+#pragma unroll
+                            for (int q = 0; q < PS_MAXP; q++) {  // piece order: deterministic
+                                if (q < PA) {
+                                    sa += __uint_as_float((unsigned)gv[q]);
+                                }
+                                else if (q < PA + PB) {
+                                    sb += __uint_as_float((unsigned)gv[q]);
+                                }
                             }
                         }
                         const int    n    = g * 16 + c;
