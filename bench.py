@@ -449,13 +449,13 @@ def main():
                                                 if st["decode_path"] == 1 else "ncclAllReduce per layer"),
                             # prompt phase: FTCF_PREFILL_OVERLAP unset = decided from data on THIS node (engine.hip
                             # context_decoder_overlapped: one plain and one overlapped prompt phase are timed, the faster form stays)
-                            "prefill_overlap": {"mode": os.environ.get("FTCF_PREFILL_OVERLAP", "auto" if world > 1 else "off"),
+                            "prefill_overlap": {"mode": os.environ.get("FTCF_PREFILL_OVERLAP", "off"),
                                                 "ran_in_the_last_request": bool(st.get("prefill_overlap", 0)),
                                                 "trial_ms_plain": st.get("prefill_ms_plain", 0.0),
                                                 "trial_ms_overlapped": st.get("prefill_ms_overlapped", 0.0)},
                             # batched decode (4..32 rows): the layer's all-reduce on the side stream under the other micro-batch
                             # (engine.hip.h decoder_overlapped; auto = one plain and one overlapped request timed on THIS node)
-                            "decode_overlap": {"mode": os.environ.get("FTCF_DECODE_OVERLAP", "auto" if world > 1 else "off"),
+                            "decode_overlap": {"mode": os.environ.get("FTCF_DECODE_OVERLAP", "off"),
                                                "ran_in_the_last_request": bool(st.get("decode_overlap", 0)),
                                                "trial_step_ms_plain": st.get("decode_step_ms_plain", 0.0),
                                                "trial_step_ms_overlapped": st.get("decode_step_ms_overlapped", 0.0)},

@@ -718,6 +718,8 @@ struct ftcf_batcher {
         const long id    = g.id;
         beam_results[id] = std::move(r);
         while (beam_results.size() > 256) {  // (results nobody fetches do not pile up: the oldest ids go first)
+            FT_LOG_WARNING(e->cfg.device, "batcher: the result of beam request %ld was never fetched and is dropped (256 wait at most)",
+                           beam_results.begin()->first);
             beam_results.erase(beam_results.begin());
         }
         release_group(si);
@@ -947,8 +949,8 @@ struct ftcf_batcher {
         }
     }
 
-    // Which form the next decode step's layers take under tensor parallelism.  Forced by FTCF_DECODE_OVERLAP = 0 / 1; "auto"
-    // (the default for ranks joined by RCCL): decode steps 4..19 of this batcher run plain, 20..35 overlapped, each timed from
+    // Which form the next decode step's layers take under tensor parallelism.  FTCF_DECODE_OVERLAP (read when a request begins: an admission)
+    // = 1 switches the overlapped form on, the default is off; "auto" (ranks joined by RCCL): decode steps 4..19 of this batcher run plain, 20..35 overlapped, each timed from
     // enqueue to the step's stream synchronisation on the host; after step 35 every rank learns the slowest rank's two sums
     // (comm_max; the ranks' batchers run the same steps) and the batcher stays with the faster form.
     long   ov_steps = 0;
@@ -958,10 +960,9 @@ struct ftcf_batcher {
     bool decode_overlap_now(int B, bool dual)
     {
         ftcf_gptneox* g  = e;
-        const char*   ev = getenv("FTCF_DECODE_OVERLAP");
-        ov_auto = (!ev || !strcmp(ev, "auto")) && g->cfg.tensor_para_size > 1 && g->cfg.comm && g->cfg.comm->comm && !g->cfg.comm->local
+        ov_auto = g->decode_overlap_mode == 2 && g->cfg.tensor_para_size > 1 && g->cfg.comm && g->cfg.comm->comm && !g->cfg.comm->local
                   && !g->cfg.comm->hx && g->cfg.comm->world > 1;
-        const int env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
+        const int env = g->decode_overlap_mode == 1 ? 1 : 0;
         ov_last = false;
         if (g->cfg.tensor_para_size == 1 || !dual || !smallm_ws || smallm_partial < 2 * smallm_region || !g->side || B < 4 || B > 32
             || (!env && !ov_auto)) {

@@ -259,9 +259,8 @@ bool window_allreduce(ftcf_comm* c, f16* buf, size_t count, hipStream_t s)
     }
     // workgroups per rank: every rank's grid must be resident together with its peers' (ranks sharing one device -- the local
     // group, two test processes -- split the compute units) and next to a GEMM on another stream
-    static const int nb_env = getenv("FTCF_TP_WINAR_NB") ? atoi(getenv("FTCF_TP_WINAR_NB")) : 0;
     const int        shared = (c->local || c->hx) ? c->world : 1;
-    const int        nb     = nb_env > 0 ? nb_env : std::max(8, 128 / shared);
+    const int        nb     = std::max(8, 128 / shared);
     WinArParams      p{};
     for (int r = 0; r < c->world; r++) {
         p.win[r] = static_cast<unsigned long long*>(c->win[r]);

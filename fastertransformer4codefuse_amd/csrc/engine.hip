@@ -258,6 +258,10 @@ static std::vector<T> broadcast_arg(const T* p, int n, int B, T dflt, const char
 
 void ftcf_gptneox::begin(const ftcf_forward_args& a)
 {
+    {  // (once per request, not per token)
+        const char* m       = getenv("FTCF_DECODE_OVERLAP");
+        decode_overlap_mode = !m ? 0 : (!strcmp(m, "auto") ? 2 : (atoi(m) ? 1 : 0));
+    }
     Range r("ftcf.begin");
     FT_LOG_TRACE(cfg.device, "begin: batch %d x beam %d, max_input_len %d, output_len %d", a.batch_size, a.beam_width, a.max_input_len,
                  a.output_len);
@@ -402,8 +406,7 @@ void ftcf_gptneox::begin(const ftcf_forward_args& a)
             FTCF_HIP_CHECK(hipMemsetAsync(ps_gq, 0, (ps_slab_n + 8) * 8, stream));
         }
         ps_tab_ready = false;
-        static const int tab_env = getenv("FTCF_PERSIST_TABLES") ? atoi(getenv("FTCF_PERSIST_TABLES")) : 1;
-        if (pplan.ok && tab_env && ps_tab && !(cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->local)) {
+        if (pplan.ok && ps_tab && !(cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->local)) {
             // the run / tile tables of this plan: one launch over no layers builds and stores them, every token's launch
             // loads them (17 us of table building per launch otherwise)
             PersistParams pp = persist_params(B, s_max);
@@ -638,10 +641,9 @@ int ftcf_gptneox::step(int max_steps)
     while (done < max_steps && ses.next_step < total && !ses.all_finished) {
         const int  step         = ses.next_step;
         const bool with_decoder = !(S > 1 && step == S);
-        // with tensor parallelism the step contains RCCL collectives: capturing them is opt-in (FTCF_TP_GRAPH=1) until it
-        // has been validated on a multi-GPU node (this round's boxes have one GPU)
-        const bool graph_ok     = use_graph && with_decoder && !profiling && (tp == 1 || (tp_graph && !cfg.comm->local && !cfg.comm->hx)) && !a.debug_logits
-                                  && !(tp > 1 && decode_overlap_wanted(ses.B));
+        // (with tensor parallelism the step contains RCCL collectives or the exchange windows' spins: not captured -- a capture
+        // of the RCCL form aborted inside this image's HIP runtime, profiles/r05_notes.md)
+        const bool graph_ok     = use_graph && with_decoder && !profiling && tp == 1 && !a.debug_logits;
         // Several tokens per graph launch (FTCF_GRAPH_TOKENS, default 8): a graph launch costs ~14 us of GPU idle time between
         // two tokens (profiles/r03_notes.md section 6), and every kernel of a persistent-path token returns at once when the
         // device-side "every row has finished" flag is set, so the tokens of a graph behind the request's last one cost a few
@@ -1039,12 +1041,6 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_SMALLM_MAX_ROWS")) {
             e->SMALLM_MAX_ROWS = std::max(16, std::min(256, atoi(m)));
         }
-        if (const char* m = getenv("FTCF_K3_Q")) {
-            e->k3_q = atoi(m);
-        }
-        if (const char* m = getenv("FTCF_K1_WPG")) {
-            e->k1_wpg = atoi(m);
-        }
         {
             hipDeviceProp_t prop;
             FTCF_HIP_CHECK(hipGetDeviceProperties(&prop, cfg->device));
@@ -1056,14 +1052,8 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         if (const char* m = getenv("FTCF_ROWS")) {
             e->rows = atoi(m);
         }
-        if (const char* m = getenv("FTCF_ROWS_TP")) {
-            e->rows_tp = atoi(m);
-        }
         if (const char* m = getenv("FTCF_ROWS_NB")) {
             e->rows_nb = atoi(m);
-        }
-        if (const char* m = getenv("FTCF_ROWS_MIN_ROWS")) {
-            e->rows_min = std::max(1, atoi(m));
         }
         if (const char* m = getenv("FTCF_PERSIST_FAIL_ONCE")) {
             e->persist_fail_once = atoi(m);
@@ -1094,9 +1084,6 @@ extern "C" int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gp
         e->use_graph = cfg->use_hip_graph != 0;
         if (const char* m = getenv("FTCF_TP_PAIR_AR")) {
             e->tp_pair_ar = atoi(m) != 0;
-        }
-        if (const char* m = getenv("FTCF_TP_GRAPH")) {
-            e->tp_graph = atoi(m) != 0;
         }
         if (const char* m = getenv("FTCF_USE_GRAPH")) {
             e->use_graph = atoi(m) != 0;

@@ -76,7 +76,6 @@ struct ftcf_gptneox {
     int                       decode_branches = 1;
     hipEvent_t                ev_user = nullptr;
     hipEvent_t                tok_ev[2] = {nullptr, nullptr};  // per-token events of the pipelined token loop
-    bool                      tp_graph = false;
     bool                      tp_pair_ar = true;  // batched decode under TP: attn | ffn all-reduced as one message, residual inside the next LN pass
     int                       k1_wpg = 2;  // waves per column group of the QKV launch (0: legacy 4-groups-per-block form)
     std::vector<LayerWeights> layers;
@@ -113,6 +112,7 @@ struct ftcf_gptneox {
     int       nsplit = 1;
     // persistent decode layers (kernels_persist.hip): on whenever the shape is eligible (FTCF_PERSIST=0: per-stage launches)
     int                 persist = 1, persist_tp = 1, persist_nb = 0, persist_cs1 = 12, persist_cs3 = 10, persist_own = 2;
+    int                 decode_overlap_mode = 0;  // FTCF_DECODE_OVERLAP as read when the last request began: 0 off (default), 1 on, 2 "auto" (timed trial, RCCL ranks)
     int                 num_cu = 0;
     PersistPlan         pplan{};
     PersistLayer*       d_players = nullptr;  // device [L]
@@ -125,7 +125,7 @@ struct ftcf_gptneox {
     int*                tp_scratch = nullptr;  // device int for the barrier all-reduce of the tensor-parallel windows
     long long*          ps_ts = nullptr;  // FTCF_PERSIST_TS=<file>: in-kernel stamps of the last token
     // persistent decode layers for 3..16 rows (kernels_rows.hip): on whenever the shape is eligible (FTCF_ROWS=0: general path)
-    int                 rows = 1, rows_nb = 0, rows_min = -1, rows_tp = 0;  // rows_min < 0: see plan()
+    int                 rows = 1, rows_nb = 0, rows_min = -1;  // rows_min < 0: see plan()
     RowsPlan            rplan{};
     char*               rows_ws = nullptr;
     long long*          rows_ts = nullptr;
@@ -296,7 +296,7 @@ struct ftcf_gptneox {
             // 3..16 rows (and what the one- / two-row kernel does not take): the rows kernel, one launch per token.  With tensor
             // parallelism it would be one launch per layer and the all-reduce of x' between them: a rank's shard of a layer is a few
             // microseconds of HBM time behind five in-kernel hand-offs, and the paired launches of the general path are faster
-            // (one rank's shard of TP 8 at bs 16: 2.67 against 1.69 ms per step) -- so only with FTCF_ROWS_TP=1
+            // (one rank's shard of TP 8 at bs 16: 2.67 against 1.69 ms per step): tensor_para_size 1 only
             rplan = RowsPlan{};
             rows_ws = nullptr;
             rows_ts = nullptr;
@@ -306,7 +306,7 @@ struct ftcf_gptneox {
             // that kernel has been switched off (FTCF_PERSIST=0, or after it gave up once): then the per-stage launches run, the path
             // of a tensor-parallel rank
             const int rmin = rows_min >= 1 ? rows_min : (persist ? 1 : 3);
-            if (rows && (cfg.tensor_para_size == 1 || rows_tp) && !pplan.ok && !fp32 && K == 1 && B >= rmin && B <= 16
+            if (rows && cfg.tensor_para_size == 1 && !pplan.ok && !fp32 && K == 1 && B >= rmin && B <= 16
                 && cfg.use_gptj_residual && L <= 255) {
                 // (ranks that share ONE device -- a local group's threads, the two-process tests -- must be resident together)
                 int nb = rows_nb > 0 ? rows_nb : persist_nb;
@@ -439,14 +439,6 @@ struct ftcf_gptneox {
             }
             if (cfg.comm->hx) {
                 hx_allreduce(cfg.comm, buf, count, true, st);
-                return;
-            }
-            // (timing aid, bench.py --fake-tp only: the one-rank communicator's all-reduce is the identity and costs nothing --
-            //  FTCF_FAKE_AR_US puts a one-wave kernel of that many microseconds in its place, so that what the overlapped decode form
-            //  hides can be measured on one GPU: tools/scripts/r5_fake_ar.sh, profiles/r05_decode_overlap_model.txt)
-            static const int fake_us = getenv("FTCF_FAKE_AR_US") ? atoi(getenv("FTCF_FAKE_AR_US")) : 0;
-            if (fake_us > 0 && cfg.comm->world == 1) {
-                launch_spin_us(fake_us, st);
                 return;
             }
             FTCF_NCCL_CHECK(ncclAllReduce(buf, buf, count, ncclFloat16, ncclSum, cfg.comm->comm, st));
@@ -637,10 +629,9 @@ struct ftcf_gptneox {
         const bool  aut = (!ev || !strcmp(ev, "auto")) && cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->comm && !cfg.comm->local
                          && !cfg.comm->hx && cfg.comm->world > 1;
         const int   env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
-        static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;
         ov_ran      = false;
         ov_eligible = false;
-        if ((!env && !aut) || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side || valu_form) {
+        if ((!env && !aut) || cfg.tensor_para_size == 1 || !cfg.use_gptj_residual || !residual_dual_ln_supported(H) || !side) {
             return false;
         }
         if (aut) {
@@ -1062,9 +1053,11 @@ struct ftcf_gptneox {
     // all-reduce's flag words and RCCL see a serial sequence, identical on every rank.  Row-wise arithmetic is that of the loop
     // below (the burst GEMM's K slices do not depend on the row count; the micro-batches' GEMMs have their own split-K regions), so
     // the tokens are bit-identical to the un-overlapped path (tests/test_gpu_tp_overlap.py, test_gpu_tp_process.py).
-    // FTCF_DECODE_OVERLAP = 0 / 1 forces it; unset or "auto" (ranks joined by RCCL): the first eligible request's token loop runs
-    // plain, the second one overlapped, every rank keeps the slowest rank's ms per step (comm_max in finish()) and the engine
-    // stays with the faster form -- what an all-reduce over xGMI hides can only be measured on the node.
+    // FTCF_DECODE_OVERLAP = 1 switches it on; "auto" (ranks joined by RCCL): the first eligible request's token loop runs plain,
+    // the second one overlapped, every rank keeps the slowest rank's ms per step (comm_max in finish()) and the engine stays with
+    // the faster form -- what an all-reduce over xGMI hides can only be measured on the node.  The default is OFF since round 6:
+    // the eager three-stream form hides 5-15 % of a modelled reduction and loses at 16 rows (profiles/r05_decode_overlap_model.txt),
+    // the auto trial compares two different requests, and none of it has run on a multi-GPU node.
     hipEvent_t dv_done[2] = {nullptr, nullptr}, dv_red[2] = {nullptr, nullptr}, dv_fork[2] = {nullptr, nullptr};
     int        dv_trial = 0;
     float      dv_ms[2] = {0.f, 0.f};  // ms per decode step of the two trials (the slowest rank's)
@@ -1088,13 +1081,13 @@ struct ftcf_gptneox {
         }
     }
     // (no side effects: step() asks it too -- the three-stream form is enqueued eagerly, not captured into the token's hipGraph:
-    // a capture of it with FTCF_TP_GRAPH=1 aborted inside the runtime on the one-rank RCCL communicator of `bench.py --fake-tp`)
+    // a capture of it aborted inside the runtime on the one-rank RCCL communicator of `bench.py --fake-tp`, round 5)
     bool decode_overlap_wanted(int B, bool* auto_trial = nullptr) const
     {
-        const char* ev  = getenv("FTCF_DECODE_OVERLAP");
-        const bool  aut = (!ev || !strcmp(ev, "auto")) && cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->comm && !cfg.comm->local
+        // (decode_overlap_mode: FTCF_DECODE_OVERLAP read when a request begins -- 0, the default, 1, or 2 = "auto")
+        const bool  aut = decode_overlap_mode == 2 && cfg.tensor_para_size > 1 && cfg.comm && cfg.comm->comm && !cfg.comm->local
                          && !cfg.comm->hx && cfg.comm->world > 1;
-        const int   env = (ev && strcmp(ev, "auto")) ? atoi(ev) : 0;
+        const int   env = decode_overlap_mode == 1 ? 1 : 0;
         if ((!env && !aut) || !decode_overlap_shape(B)) {
             return false;
         }

@@ -109,7 +109,6 @@ bool residual_dual_ln_supported(int n);
 void launch_residual_dual_ln(f16* x, const f16* ffn, const f16* attn, const f16* bias, int tp, int inplace_variant,
                              const f16* g1, const f16* b1, const f16* g2, const f16* b2, f16* out1, f16* out2, int m,
                              int n, float eps, hipStream_t s, int bias_mul = 1);
-void launch_spin_us(int us, hipStream_t s);  // timing aid: a one-wave kernel that lasts `us` microseconds (FTCF_FAKE_AR_US)
 // out = (bias + a) + b in fp32, rounded once (sequential-residual layers)
 void launch_add_bias_residual(f16* out, const f16* a, const f16* b, const f16* bias, int m, int n, hipStream_t s);
 void launch_add_bias_attn_ffn_residual(void* out, const void* ffn, const void* attn, const void* in, const void* bias,

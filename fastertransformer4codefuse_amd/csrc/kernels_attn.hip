@@ -10,8 +10,7 @@
 //  * k_qkv_bias_rotary_cache + k_context_attention : prefill, the counterpart of add_fusedQKV_bias_transpose_kernel
 //      (kernels/unfused_attention_kernels.cu:1326-1484), transpose_4d_batch_major_{k,v}_cache (:1673-1749), the
 //      batched QK^T / P.V GEMMs and softmax_kernel (:255-332) of GptContextAttentionLayer.cc:142-345, fused into a
-//      causal online-softmax kernel (no S x S score buffers); k_context_attention_mfma is the form in use (QK^T and PV
-//      on MFMA tiles), k_context_attention the first VALU form (FTCF_CTX_ATTN_VALU=1, A/B runs).
+//      causal online-softmax kernel (no S x S score buffers): k_context_attention_mfma (QK^T and PV on MFMA tiles).
 //
 // Cache layout (engine private): K and V both [B, nh, s_max, dh] fp16, dh contiguous: one wave-load = 1 KiB of
 // consecutive keys.  Roofline: HBM (decode: 4*t*dh*nh bytes per layer per row).
@@ -248,125 +247,6 @@ __global__ __launch_bounds__(256) void k_qkv_bias_rotary_cache(f16* qkv, const f
         base[i]       = q;
         k_cache[cidx] = k;
         v_cache[cidx] = v;
-    }
-}
-
-template<int DH>
-__global__ __launch_bounds__(256) void k_context_attention(const f16* __restrict__ qkv, const int* __restrict__ input_lengths,
-                                                           const f16* __restrict__ k_cache, const f16* __restrict__ v_cache,
-                                                           int S, int nh, int s_max, f16* __restrict__ ctx, float qk_scale,
-                                                           int crm)
-{
-    constexpr int KT  = 64;       // keys per tile
-    constexpr int LDK = DH + 8;   // padded LDS row (halves)
-    constexpr int DPL = DH / 64;  // output dims per lane
-    __shared__ __attribute__((aligned(16))) f16   sK[KT * LDK];
-    __shared__ __attribute__((aligned(16))) f16   sV[KT * DH];
-    __shared__ __attribute__((aligned(16))) f16   sQ[16 * DH];
-    __shared__ __attribute__((aligned(16))) float sP[4][KT][4];  // [wave][key][row]
-
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 16;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int hl = nh * DH;
-    const int len = input_lengths[b];
-    if (q0 >= len) {
-        return;  // padded query rows are discarded by the reference
-    }
-    // stage the 16 query rows (already bias+rotary'd in place in the qkv buffer)
-    for (int i = threadIdx.x; i < 16 * DH / 8; i += 256) {
-        const int r = i / (DH / 8), ch = i % (DH / 8);
-        int       qi = q0 + r;
-        qi           = qi < S ? qi : S - 1;
-        *reinterpret_cast<f16x8*>(&sQ[r * DH + ch * 8]) =
-            *reinterpret_cast<const f16x8*>(qkv + ((size_t)b * S + qi) * 3 * hl + h * DH + ch * 8);
-    }
-    const f16* kc = k_cache + ((size_t)b * crm * nh + h) * s_max * DH;
-    const f16* vc = v_cache + ((size_t)b * crm * nh + h) * s_max * DH;
-
-    float m_run[4], l_run[4], o[4][DPL];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        m_run[r] = -INFINITY;
-        l_run[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < DPL; j++) {
-            o[r][j] = 0.f;
-        }
-    }
-    const int q_last = min(q0 + 15, len - 1);
-    for (int k0 = 0; k0 <= q_last; k0 += KT) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < KT * DH / 8; i += 256) {
-            const int r = i / (DH / 8), ch = i % (DH / 8);
-            int       kk = k0 + r;
-            kk           = kk < S ? kk : S - 1;
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(kc + (size_t)kk * DH + ch * 8);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(vc + (size_t)kk * DH + ch * 8);
-            *reinterpret_cast<u32x4*>(&sK[r * LDK + ch * 8]) = kv;
-            *reinterpret_cast<u32x4*>(&sV[r * DH + ch * 8])  = vv;
-        }
-        __syncthreads();
-        // ---- scores: lane = key ----
-        float sc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int ch = 0; ch < DH / 8; ch++) {
-            const f16x8 kv = *reinterpret_cast<const f16x8*>(&sK[lane * LDK + ch * 8]);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const f16x8 qv = *reinterpret_cast<const f16x8*>(&sQ[(wid * 4 + r) * DH + ch * 8]);
-                float       a  = sc[r];
-                a              = dot2(f16x2{qv[0], qv[1]}, f16x2{kv[0], kv[1]}, a);
-                a              = dot2(f16x2{qv[2], qv[3]}, f16x2{kv[2], kv[3]}, a);
-                a              = dot2(f16x2{qv[4], qv[5]}, f16x2{kv[4], kv[5]}, a);
-                a              = dot2(f16x2{qv[6], qv[7]}, f16x2{kv[6], kv[7]}, a);
-                sc[r]          = a;
-            }
-        }
-        const int key = k0 + lane;
-        float     pr[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int  qi    = q0 + wid * 4 + r;
-            const bool valid = (key <= qi) && (qi < len);  // mask of gpt_kernels.cu:359-402
-            const float s    = valid ? qk_scale * sc[r] : -INFINITY;
-            const float mt   = wave_max(s);
-            const float mn   = fmaxf(m_run[r], mt);
-            const float al   = (m_run[r] == -INFINITY) ? 0.f : __expf(m_run[r] - mn);
-            const float e    = (s == -INFINITY || mn == -INFINITY) ? 0.f : __expf(s - mn);
-            l_run[r]         = l_run[r] * al + wave_sum(e);
-            m_run[r]         = mn;
-            pr[r]            = e;
-#pragma unroll
-            for (int j = 0; j < DPL; j++) {
-                o[r][j] *= al;
-            }
-        }
-        *reinterpret_cast<f32x4*>(&sP[wid][lane][0]) = f32x4{pr[0], pr[1], pr[2], pr[3]};
-        // sP[wid] is written and read by the same wave only: LDS ops of a wave are ordered, no barrier needed
-        // ---- P.V: lane = output dims ----
-        const int kmax = min(KT, q_last - k0 + 1);
-        for (int kk = 0; kk < kmax; kk++) {
-            const f32x4 pk = *reinterpret_cast<const f32x4*>(&sP[wid][kk][0]);
-#pragma unroll
-            for (int j = 0; j < DPL; j++) {
-                const float vv = (float)sV[kk * DH + lane * DPL + j];
-                o[0][j]        = fmaf(pk[0], vv, o[0][j]);
-                o[1][j]        = fmaf(pk[1], vv, o[1][j]);
-                o[2][j]        = fmaf(pk[2], vv, o[2][j]);
-                o[3][j]        = fmaf(pk[3], vv, o[3][j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int qi = q0 + wid * 4 + r;
-        if (qi < len && qi < S) {
-            const float inv = 1.f / (l_run[r] + 1e-6f);  // unfused_attention_kernels.cu:322
-#pragma unroll
-            for (int j = 0; j < DPL; j++) {
-                ctx[((size_t)b * S + qi) * hl + h * DH + lane * DPL + j] = (f16)(o[r][j] * inv);
-            }
-        }
     }
 }
 
@@ -684,20 +564,7 @@ void launch_context_attention(const f16* qkv, const f16* qkv_bias, const int* in
     }
     // qk_scale is computed in T by the reference (GptContextAttentionLayer.cc: `const T qk_scale = (T)(1/sqrtf(dh))`)
     const float qk_scale = (float)(f16)(1.0f / sqrtf((float)dh));
-    static const bool valu_form = getenv("FTCF_CTX_ATTN_VALU") != nullptr;  // the first (dot2 / fma) form, kept for A/B runs
-    if (valu_form) {
-        FTCF_CHECK_ARG(s_lo == 0 && s_hi == S && (dh == 64 || dh == 128), "the VALU form of the prompt attention takes whole prompts and head sizes 64 / 128");
-        dim3 grid((S + 15) / 16, nh, B);
-        if (dh == 128) {
-            hipLaunchKernelGGL(k_context_attention<128>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                               s_max, ctx, qk_scale, cache_row_mult);
-        }
-        else {
-            hipLaunchKernelGGL(k_context_attention<64>, grid, dim3(256), 0, s, qkv, input_lengths, k_cache, v_cache, S, nh,
-                               s_max, ctx, qk_scale, cache_row_mult);
-        }
-    }
-    else {
+    {
         // key split of the heaviest query blocks (see the kernel): those whose chain is longer than half the longest one, when the
         // launch is long enough to care (>= 8 key tiles), the partials fit the workspace and nobody is capturing a graph (the
         // workspace is allocated on first use).  FTCF_CTX_SPLIT=0 switches it off.

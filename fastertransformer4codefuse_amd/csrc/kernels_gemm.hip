@@ -466,12 +466,12 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
     const int splitk_max_m = splitk_max_env >= 0 ? splitk_max_env : (int8 ? GEMM_SPLITK_MAX_M_I8 : GEMM_SPLITK_MAX_M_F16);
     if (workspace && m <= splitk_max_m && splitk_target > 0) {
         // 64-row tiles cut along K until ~1 workgroup per CU is in flight (FTCF_GEMM_SPLITK: the target number of workgroups)
-        static const int deep = getenv("FTCF_GEMM_DEEP") ? atoi(getenv("FTCF_GEMM_DEEP")) : 4;
+        constexpr int deep = 4;  // ring depth of the split-K form (0 / 2: measured slower, profiles/r03_notes.md)
         // 64-row tiles; one row block (m <= 64): the lowest tile that covers it, 32 / 48 / 64 rows -- a 64-row tile on 17..32 rows
         // spends half its MFMAs and LDS reads on clamped duplicate rows (13B int8 prompt phase: 17 tokens 5.2 -> 4.4 ms, 33: 5.3 ->
         // 5.0).  With several row blocks lower tiles measured no better (a k-step's fixed costs -- barrier, A staging,
         // dequantisation -- outweigh its MFMAs at these heights).
-        static const int rgsel = getenv("FTCF_GEMM_RG32") ? atoi(getenv("FTCF_GEMM_RG32")) : 1;
+        constexpr int rgsel = 1;
         constexpr int NG = 2, DQ = 4;
         // several row blocks: 128-row tiles above FTCF_GEMM_SK128_MIN_M rows (see GEMM_SK128_MIN_M_* for the measurements)
         const char*   sk128_env = getenv("FTCF_GEMM_SK128_MIN_M");  // rows above which the tiles are 128 rows high
@@ -545,7 +545,7 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         // CUs) -> 64-row tiles.
         constexpr int NG = 2;
         const int     gx = (NT + 8 * NG - 1) / (8 * NG);
-        static const int small_tiles = getenv("FTCF_GEMM_SMALL_TILES") ? atoi(getenv("FTCF_GEMM_SMALL_TILES")) : 160;
+        constexpr int small_tiles = 160;
         // (above 1024 rows also when the 128-row tiles would leave a partial round of the 256 CUs: n = 5120 at 1025..1536 rows is
         // 180..240 tiles -- 13B prompt phase at 1536 tokens 51.2 -> 47.7 ms (int8), 54.0 -> 52.4 (fp16); at exactly 1024 rows, 160
         // tiles, the 64-row form is SLOWER: 31.1 -> 32.5 / 33.1 -> 38.8)
@@ -558,7 +558,7 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         // prefetch and held to 128 VGPRs, so that two workgroups share a CU as in the plain form (124 VGPRs).  13B int8 layer,
         // us, plain loop / ring at one workgroup per CU / ring at two: m = 1024: QKV 163 / 180 / 163, out-proj 91 / 80 / 93,
         // FFN1 218 / 235 / 216, FFN2 293 / 270 / 295; m = 2048: 348 / 375 / 340, 138 / 147 / 135, 392 / 418 / 380, 506 / 532 / 487.
-        static const int big_deep = getenv("FTCF_GEMM_BIG_DEEP") ? atoi(getenv("FTCF_GEMM_BIG_DEEP")) : 2;
+        constexpr int big_deep = 2;
         const int        bd       = (k / GEMM_KSTEP) % 2 == 0 ? big_deep : 0;
         const bool       lone     = (long)gx * gy <= 256;
 #define FTCF_BIG(I8, RGv, Dv, PFv, O2v)                                                                                          \
@@ -577,9 +577,8 @@ void launch_gemm_tiled(const f16* A, const void* W, const f16* scale, const f16*
         // fp16 weights from 2048 rows: the same 128 x 256 tile on FOUR waves of four column groups each -- an A fragment read from LDS
         // feeds four MFMAs instead of two, two workgroups per CU (252 VGPRs, plain loop: the ring of two k-steps spills 58).  13B prompt
         // phase, fp16 weights: 2048 tokens 64.4 -> 63.2 ms, 4096: 133.2 -> 129.6; at 1024 tokens it is slower (33.1 -> 34.7), and with
-        // int8 weights at every length (1024: 29.9 -> 33.4, 4096: 120.0 -> 121.0).  FTCF_GEMM_NG4=0: off.
-        static const int ng4 = getenv("FTCF_GEMM_NG4") ? atoi(getenv("FTCF_GEMM_NG4")) : 1;
-        if (ng4 && !int8 && !small && m >= 2048) {
+        // int8 weights at every length (1024: 29.9 -> 33.4, 4096: 120.0 -> 121.0).
+        if (!int8 && !small && m >= 2048) {
             hipLaunchKernelGGL((k_gemm_tiled<false, 8, 4, 4, false, true, false, 0, false, true>), grid, dim3(256), 0, s, A, W, scale, bias,
                                act, C, m, n, k, gx, gy);
             FTCF_HIP_CHECK(hipGetLastError());
@@ -1243,16 +1242,12 @@ void launch_gemm_nk_f32out(const f16* A, const f16* W_nk, float* C, int m, int n
 {
     FTCF_CHECK_ARG(k % 32 == 0, "k must be a multiple of 32");
     {
-        const char* e = getenv("FTCF_LMHEAD_TR");  // (0: the fragment-order form below)
-        if ((!e || atoi(e) != 0) && k % NKT_KC == 0 && n >= 16) {
+        if (k % NKT_KC == 0 && n >= 16) {  // (else the fragment-order form below)
             constexpr int WAVES = 4;
             const int     NRG = (n + 15) / 16;
             // 100864 x 5120 at 16 rows, us per launch by trips per wave: 1 (1576 workgroups): 171.0, 2: 190.9, 3 (526 workgroups = 2.05 per
             // CU): 213.2, 4: 172.2, 6: 221.7 -- the fragment-order form: 283.7
-            int           trips = 1;
-            if (const char* t = getenv("FTCF_LMHEAD_TRIPS")) {
-                trips = std::max(1, atoi(t));
-            }
+            constexpr int trips = 1;
             const int     gx    = (NRG + WAVES * trips - 1) / (WAVES * trips);
             dim3          grid(gx, (m + 15) / 16);
             hipLaunchKernelGGL((k_gemm_nk_f32out_tr<WAVES>), grid, dim3(64 * WAVES), 0, s, A, W_nk, C, m, n, k, ldc, trips);

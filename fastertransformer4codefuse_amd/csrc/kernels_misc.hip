@@ -396,19 +396,4 @@ void launch_fp16_rowmajor_to_tiled(const f16* w, size_t K, size_t N, f16* out, h
     FTCF_HIP_CHECK(hipGetLastError());
 }
 
-// timing aid (bench.py --fake-tp with FTCF_FAKE_AR_US): one wave that does nothing for `us` microseconds -- stands in for the latency
-// of an all-reduce whose peers are not there, so that what the overlapped decode form hides can be measured on one GPU
-__global__ void k_spin_us(long long ticks)
-{
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) {
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-void launch_spin_us(int us, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, s, (long long)us * 100);  // wall_clock64: 100 MHz
-    FTCF_HIP_CHECK(hipGetLastError());
-}
-
 }  // namespace ftcf

@@ -40,13 +40,9 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
         // a leftover pair is shared by FX workgroups only when EVERY pair is a leftover pair (fewer pairs than workgroups: small
         // batches, tensor-parallel shards): then all pairs have the same reduction tree.  With whole pairs next to shared ones
         // (bs 16 at 40 heads: 2.5 pairs per workgroup) the shared pairs' tree would differ from the whole pairs' and identical
-        // rows of a batch would stop being bit-identical; sharing them anyway (FTCF_ROWS_FX=2) balances the attention stream
-        // and was measured neutral on the step
+        // rows of a batch would stop being bit-identical; sharing them anyway balances the attention stream and was measured
+        // neutral on the step (profiles/r05_notes.md)
         pl.FX = (rem > 0 && full == 0) ? std::max(1, std::min(NB / rem, 8)) : 1;
-        static const int fx_env = getenv("FTCF_ROWS_FX") ? atoi(getenv("FTCF_ROWS_FX")) : 0;
-        if (fx_env >= 1 && rem > 0 && rem * fx_env <= NB) {
-            pl.FX = fx_env;
-        }
         pl.U = full + (rem > 0 ? 1 : 0);
     }
     if (pl.U > RW_UMAX) {
@@ -68,24 +64,9 @@ RowsPlan rows_plan(int M, int H, int Hl, int Il, int nh, int dh, int s_max, bool
         }
         pl.cw = H / pl.CR;
     }
-    // K shares of the streamer waves (FTCF_ROWS_WS=a,b,c,d,e,f,g: relative weights)
+    // K shares of the streamer waves: equal (unequal weights measured no better: profiles/r05_notes.md)
     {
-        int         w[RW_NS] = {16, 16, 16, 16, 16, 16, 16};
-        const char* e        = getenv("FTCF_ROWS_WS");
-        if (e) {
-            int v[RW_NS];
-            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == RW_NS) {
-                bool good = true;
-                for (int i = 0; i < RW_NS; i++) {
-                    good = good && v[i] >= 1 && v[i] <= 1024;
-                }
-                if (good) {
-                    for (int i = 0; i < RW_NS; i++) {
-                        w[i] = v[i];
-                    }
-                }
-            }
-        }
+        const int w[RW_NS] = {16, 16, 16, 16, 16, 16, 16};
         pl.wcum[0] = 0;
         for (int i = 0; i < RW_NS; i++) {
             pl.wcum[i + 1] = pl.wcum[i] + w[i];

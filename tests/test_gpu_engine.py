@@ -226,16 +226,19 @@ def test_engine_is_deterministic_across_calls(gh, tiny):
     assert np.array_equal(a["logits"], b["logits"]) and np.array_equal(a["output_ids"], b["output_ids"])
 
 
-@pytest.mark.parametrize("variant", ["per_layer", "grid24", "grid40", "grid32", "grid48", "grid64", "own0"])
+_VARIANT_REF = {}
+
+
+@pytest.mark.parametrize("variant", ["per_layer", "grid24", "grid40", "grid32", "grid48", "own0"])
 @pytest.mark.parametrize("int8_mode", [0, 1])
 def test_persistent_kernel_variants_agree(gh, monkeypatch, decode_path, variant, int8_mode):
     """The persistent decode-layer kernel under other launch shapes: one launch per layer (what tensor parallelism uses,
     the layer input / output then travel through plain memory instead of granules) must be bit-identical to the
     one-launch-per-token form; a grid of 24 or 40 workgroups (several runs and attention splits per workgroup, other K
     piece counts) changes the fp32 summation order only, so it stays within the GEMV tolerance of the default grid.
-    Grids of 32 / 64 / 48 workgroups put the out-proj / FFN2 stage into the own-group layout (round 6: whole column groups per
-    workgroup -- two or one of this model's 64, and at 48 workgroups one each plus a third of one of the 16 left over, whose
-    merger adds partials published from inside the other pieces' streams); own0 switches that layout off."""
+    Grids of 32 / 48 workgroups put the out-proj / FFN2 stage into the own-group layout (round 6: whole column groups per
+    workgroup -- two of this model's 64, and at 48 workgroups one each plus a third of one of the 16 left over, whose merger
+    adds partials published from inside the other pieces' streams); own0 switches that layout off."""
     if decode_path != "persistent":
         pytest.skip("variants of the persistent path only")
     cfg = MID
@@ -246,9 +249,12 @@ def test_persistent_kernel_variants_agree(gh, monkeypatch, decode_path, variant,
     ids = np.full((B, S), cfg["end_id"], dtype=np.int32)
     for b in range(B):
         ids[b, :lens[b]] = rng.randint(3, cfg["vocab_size"], size=lens[b])
-    op = gh.make_op(cfg, w, int8_mode=int8_mode)
-    ref = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
-    assert op.stats()["decode_path"] == 1
+    if int8_mode not in _VARIANT_REF:  # (the default launch shape once per weight form: every variant compares against it)
+        op = gh.make_op(cfg, w, int8_mode=int8_mode)
+        _VARIANT_REF[int8_mode] = gh.run_op(op, ids, lens, out, cfg["vocab_size"], top_k=1)
+        assert op.stats()["decode_path"] == 1
+        del op
+    ref = _VARIANT_REF[int8_mode]
     if variant == "per_layer":
         monkeypatch.setenv("FTCF_PERSIST_PER_LAYER", "1")
     elif variant == "own0":
