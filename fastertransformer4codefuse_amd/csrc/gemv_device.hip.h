@@ -5,10 +5,7 @@
 
 namespace ftcf {
 
-#ifndef FTCF_GEMV_U
-#define FTCF_GEMV_U 8
-#endif
-constexpr int GEMV_U = FTCF_GEMV_U;  // tiles per batch (x2 batches in flight)
+constexpr int GEMV_U = 8;  // tiles per batch (x2 batches in flight)
 // The rows of x staged in LDS are XPAD halves (16 B) further apart than their length: K is a multiple of 64 halves, so
 // unpadded rows start in the same bank and the A-fragment reads of m rows conflict m ways (measured: the m = 4 GEMV
 // step took 1.7x the m = 1 step although the MFMA work is identical)

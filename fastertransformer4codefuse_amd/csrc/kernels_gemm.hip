@@ -213,10 +213,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC2 ? WAVES / 2 : 1) void k_gemm_tiled
         if constexpr (PF) {
             // all A fragments of the step requested up front (their LDS latency passes under the dequantisation), then the MFMAs
             // back to back with the two k halves of an accumulator RG * NG instructions apart (a dependent MFMA stalls its wave)
-#ifndef GEMM_PF_ROWS
-#define GEMM_PF_ROWS 2
-#endif
-            constexpr int PR = RG % GEMM_PF_ROWS == 0 ? GEMM_PF_ROWS : 1;  // row groups whose fragments are in flight together
+            constexpr int PR = RG % 2 == 0 ? 2 : 1;  // row groups whose fragments are in flight together
             f16x8         af[PR][2];
 #pragma unroll
             for (int r = 0; r < PR; r++) {
@@ -359,10 +356,7 @@ __global__ __launch_bounds__(64 * WAVES, OCC2 ? WAVES / 2 : 1) void k_gemm_tiled
                     acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-#ifndef GEMM_ZB
-#define GEMM_ZB 1
-#endif
-            constexpr int ZB = RG <= 4 ? GEMM_ZB : 2;  // slices requested together (32 / 64 VGPRs each)
+            constexpr int ZB = RG <= 4 ? 1 : 2;  // slices requested together (32 / 64 VGPRs each)
             for (int z0 = 0; z0 < KS; z0 += ZB) {
                 u64 v[ZB][RG][NG][2];
 #pragma unroll
@@ -775,10 +769,7 @@ __global__ __launch_bounds__(256) void k_gemm_smallm(const f16* __restrict__ A, 
 // is that a slot streams nothing while its workgroup computes, leaves and is replaced: ~60 % of the in-flight capacity.)
 // tag = f(decode step, launch) is unique per launch within a request; the engine zeroes the granules when a request begins.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef SMB_T_TILES
-#define SMB_T_TILES 20
-#endif
-constexpr int SMB_T     = SMB_T_TILES;  // tiles per wave and slice
+constexpr int SMB_T     = 20;  // tiles per wave and slice
 constexpr int SMB_WAVES = 4;        // waves (16-column groups) per workgroup: they share the x slice
 constexpr int SMB_SPINS = 1 << 22;  // bounded: a protocol bug must not hang the GPU
 typedef unsigned long long                          smb_u64;

@@ -36,31 +36,17 @@ constexpr int RW_NW     = 8;
 constexpr int RW_NT     = RW_NW * 64;
 constexpr int RW_NS     = RW_NW - 1;  // streamer waves
 constexpr int RW_G      = 5;          // 16-column groups per k-step (compile-time maximum; the QKV pass may use 4)
-#ifndef RW_R_
-#define RW_R_ 4
-#endif
-#ifndef RW_KVR_
-#define RW_KVR_ 4
-#endif
-constexpr int RW_R      = RW_R_;      // ring slots of a weight pass (three k-steps in flight while one is consumed)
+constexpr int RW_R      = 4;          // ring slots of a weight pass (three k-steps in flight while one is consumed)
 // ring slots of the QKV pass: its weights are requested at the layer boundary, while the pieces of x' travel and the HBM has nothing
 // else to do -- deep enough to take most of the wave's share (G1 = 4: 8 x 24 registers; G1 = 5: 6 x 28)
-#ifndef RW_RQ4_
-#define RW_RQ4_ 4
-#endif
-#ifndef RW_RQ5_
-#define RW_RQ5_ 4
-#endif
-#ifndef RW_RQA_
-#define RW_RQA_ 1
-#endif
+// (deeper rings -- 8 / 6 slots -- and A fragments requested fewer steps ahead were measured no better: profiles/r05_notes.md)
 template<int G1>
 struct RwQ {
-    static constexpr int R  = G1 <= 4 ? RW_RQ4_ : RW_RQ5_;
-    static constexpr int RA = R / RW_RQA_;
+    static constexpr int R  = 4;
+    static constexpr int RA = R;
 };
 constexpr int RW_KVB    = 4;          // K (and V) wave-loads per ring slot of the attention stream
-constexpr int RW_KVR    = RW_KVR_;    // its ring slots
+constexpr int RW_KVR    = 4;          // its ring slots
 constexpr int RW_UMAX   = 4;          // (row, head) pairs of a workgroup at most
 constexpr int RW_SPIN   = 1 << 18;
 constexpr int RW_PHASES = 4;  // go values of a layer: QKV (+ FFN1), AT, FFN2, OUT
@@ -396,9 +382,6 @@ struct RwPass {
 #pragma unroll
         for (int g = 0; g < G; g++) {
             rw_tile<INT8>(q.w[r][g], a0, a1, sc2[g], acc[g]);
-#ifdef RW_TILE_FENCE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     }
     // the weight tiles of the first ring.  A load is never a duplicate: the ring's conditions are uniform, and only the first ring
@@ -1114,12 +1097,10 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
             // ---- attention ----
             rw_lds_wait(&s.sync[0], li * RW_PHASES + 2, p.err, 11);
             stamp(l, 4);
-#ifndef RW_PROBE_NO_AT
             if (U > 0) {
                 at.stage(p, lw, r_ws, s.unit, aw, vw);
                 at.run(p, lw, s.unit, aw, vw, s.apart);
             }
-#endif
             RwPass<INT8, RW_G, false> p2;
             p2.bind_w(lw.w_ffn2, KT2, NGo, cb2 * RW_G, ng2, lw.s_ffn2, ln, kb2, ke2);
             p2.prime_w(ring);
@@ -1154,9 +1135,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
         }
         return;
     }
-#ifdef RW_PROBE_NO_CTRL
-    return;
-#endif
     // =============================================== control wave ===============================================
     const unsigned gb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s.gb;
     // the LayerNorm parameters of layer `nx` by LDS-DMA: arrays a0, a0 + 1 of gb (1 KiB per request; the last chunk re-reads the
@@ -1206,14 +1184,6 @@ __global__ __launch_bounds__(RW_NT) void k_decode_rows(const RowsParams p)
     // FFN2's K piece [k2a, k2b) k-steps = mid columns [k2a KS, k2b KS): FFN1 column groups and their owners
     int fm_lo = (has2 && k2b > k2a) ? owner((k2a * KS) / 16, NGf) : 0;
     int fm_hi = (has2 && k2b > k2a) ? owner((k2b * KS - 1) / 16, NGf) : -1;
-    // (A/B switches: every workgroup's flag instead)
-#ifdef RW_FULL_POLL_A
-    nA = 0;
-#endif
-#ifdef RW_FULL_POLL_F
-    fm_lo = 0;
-    fm_hi = NB - 1;
-#endif
     for (int l = p.l_begin; l < p.l_end; l++) {
         const PersistLayer& lw  = p.layers[l];
         const unsigned      tag = tag_base + (unsigned)l;

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "one_decode_path: the test's path does not depend on the decode-path switch; it runs once")
 
 
 @pytest.fixture(scope="session")

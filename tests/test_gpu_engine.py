@@ -21,6 +21,8 @@ def decode_path(request, monkeypatch):
     """Every engine test runs twice: with the product defaults (persistent decode-layer kernel for B <= 2, general path with
     the burst GEMMs above) and with the per-stage launches for up to 4 rows (FTCF_PERSIST=0 FTCF_STAGE_MAX_ROWS=4: what one
     row runs under tensor parallelism; the 2..4-row forms stay covered).  The engine reads the variables when it is created."""
+    if request.param == "launches" and request.node.get_closest_marker("one_decode_path"):
+        pytest.skip("the path this test takes does not depend on the switch: it runs once")
     monkeypatch.setenv("FTCF_PERSIST", "1" if request.param == "persistent" else "0")
     if request.param == "launches":
         monkeypatch.setenv("FTCF_STAGE_MAX_ROWS", "4")
@@ -101,6 +103,7 @@ def test_mid_model_fused_and_general_decode_paths(gh, B, int8_mode):
     _mid_model_follows_the_oracle(gh, B, int8_mode)
 
 
+@pytest.mark.one_decode_path
 @pytest.mark.parametrize("int8_mode", [0, 1])
 @pytest.mark.parametrize("max_rows", [16, 64])
 def test_mid_model_decode_steps_above_16_rows(gh, monkeypatch, max_rows, int8_mode):
@@ -185,6 +188,7 @@ def test_stop_words_optional_last_tokens_and_callback(gh, tiny):
     assert r2["output_ids"].tolist() == o2["output_ids"].tolist()
 
 
+@pytest.mark.one_decode_path
 @pytest.mark.parametrize("dh", [48, 80, 96, 160, 256])
 def test_other_head_sizes_run_the_general_path_against_the_oracle(gh, dh):
     """size_per_head outside {64, 128} (the reference dispatches 32 ... 256, decoder_masked_multihead_attention.cu:29-59): the
@@ -379,6 +383,7 @@ def test_persistent_kernel_long_key_ranges(gh, tiny, monkeypatch, decode_path):
             break
 
 
+@pytest.mark.one_decode_path
 @pytest.mark.parametrize("seed", range(4))
 def test_sampling_kernels_reproduce_the_oracle_given_the_same_logits(gh, tiny, seed):
     """The GPU's own per-step logits pushed through the oracle's dynamic decode (same counter-based uniforms, same (value

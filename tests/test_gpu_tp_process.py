@@ -61,7 +61,17 @@ def _free_port():
     return p
 
 
+_RANK_RUNS = {}  # results of a pair of rank processes by (model, weights, environment): tests that need the same run share it
+
+
 def _run_ranks(tmp_path, model, int8_mode, world=2, extra_env=None, timeout=600):
+    key = (model, int8_mode, world, tuple(sorted((extra_env or {}).items())))
+    if key not in _RANK_RUNS:
+        _RANK_RUNS[key] = _launch_ranks(tmp_path, model, int8_mode, world, extra_env, timeout)
+    return _RANK_RUNS[key]
+
+
+def _launch_ranks(tmp_path, model, int8_mode, world, extra_env, timeout):
     port = str(_free_port())
     env = dict(os.environ, FTCF_PERSIST_NB="128", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
@@ -149,7 +159,7 @@ def test_two_processes_overlap_the_all_reduce_of_batched_decode(gh, tmp_path):
     (tmp_path / "ov").mkdir()
     (tmp_path / "plain").mkdir()
     ov, _ = _run_ranks(tmp_path / "ov", "mid", 1, extra_env={"FTCF_DECODE_OVERLAP": "1"})
-    plain, _ = _run_ranks(tmp_path / "plain", "mid", 1, extra_env={"FTCF_DECODE_OVERLAP": "0"})
+    plain, _ = _run_ranks(tmp_path / "plain", "mid", 1)  # (the default is the in-line form; the run is shared with the test above)
     for r in range(2):
         assert int(ov[r]["four_rows.decode_overlap"][0]) == 1 and int(plain[r]["four_rows.decode_overlap"][0]) == 0
         assert int(ov[r]["one_row.decode_overlap"][0]) == 0
