@@ -444,6 +444,9 @@ def main():
                             "decode_path": {0: "per-stage launches", 1: "persistent kernel", 2: "general path",
                                             3: "rows kernel (persistent layers for 3..16 rows)"}.get(
                                 st["decode_path"], str(st["decode_path"])),
+                            # (one- / two-row kernel: its out-proj / FFN2 stage -- DESIGN.md section 4b)
+                            "persistent_p3_layout": ("own groups (one hop at the layer boundary)" if st.get("persist_layout") else
+                                                     "K pieces merged by an owner") if st["decode_path"] == 1 else None,
                             "layer_allreduce": ("none" if tp == 1 else
                                                 "in-kernel exchange windows (peer-mapped, xGMI stores)"
                                                 if st["decode_path"] == 1 else "ncclAllReduce per layer"),

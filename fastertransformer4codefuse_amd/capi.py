@@ -60,7 +60,8 @@ class ForwardStats(C.Structure):
                 ("gemv_ms_sum", C.c_float), ("gemv_launches", C.c_long), ("gemv_bytes", C.c_double),
                 ("gemv_kind", C.c_int), ("decode_path", C.c_int), ("prefill_overlap", C.c_int),
                 ("prefill_ms_plain", C.c_float), ("prefill_ms_overlapped", C.c_float), ("window_allreduces", C.c_int),
-                ("decode_overlap", C.c_int), ("decode_step_ms_plain", C.c_float), ("decode_step_ms_overlapped", C.c_float)]
+                ("decode_overlap", C.c_int), ("decode_step_ms_plain", C.c_float), ("decode_step_ms_overlapped", C.c_float),
+                ("persist_layout", C.c_int)]
 
 
 # every symbol include/ftcf.h declares (tests/test_capi_host.py checks the list against the header and the library)

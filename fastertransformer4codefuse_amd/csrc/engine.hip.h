@@ -849,6 +849,7 @@ struct ftcf_gptneox {
         // (beam search reads K/V through the cache indirection, sequential-residual layers have their own order: general path)
         const bool staged = B <= STAGE_MAX_ROWS && ses.K == 1 && cfg.use_gptj_residual && (dh == 64 || dh == 128);
         stats.decode_path = pplan.ok ? 1 : (staged ? 0 : 2);
+        stats.persist_layout = pplan.ok ? pplan.own : 0;
         if (!ses.path_logged) {  // once per request
             ses.path_logged = true;
             FT_LOG_DEBUG(cfg.device, "decoder of this request: %s (rows %d, context %d%s)",

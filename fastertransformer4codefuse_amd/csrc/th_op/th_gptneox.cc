@@ -282,6 +282,7 @@ public:
         d["prefill_ms_plain"]      = s.prefill_ms_plain;
         d["prefill_ms_overlapped"] = s.prefill_ms_overlapped;
         d["window_allreduces"]     = s.window_allreduces;
+        d["persist_layout"]        = s.persist_layout;
         d["decode_overlap"]        = s.decode_overlap;
         d["decode_step_ms_plain"]  = s.decode_step_ms_plain;
         d["decode_step_ms_overlapped"] = s.decode_step_ms_overlapped;

@@ -221,6 +221,9 @@ typedef struct {
      * mode's two trials (ms per decode step, plain / overlapped, the slowest rank's; 0 until that trial has run) */
     int   decode_overlap;
     float decode_step_ms_plain, decode_step_ms_overlapped;
+    /* decode_path 1: how the one- / two-row kernel ran its out-proj / FFN2 stage: 0 K pieces merged by an owner (two hops at the
+     * layer boundary), 1 own-group layout (one hop; FTCF_PERSIST_OWN) */
+    int   persist_layout;
 } ftcf_forward_stats;
 
 int ftcf_gptneox_create(const ftcf_gptneox_config* cfg, const ftcf_gptneox_weights* w, ftcf_gptneox_t* out);

@@ -267,6 +267,7 @@ def test_persistent_kernel_variants_agree(gh, monkeypatch, decode_path, variant,
     op2 = gh.make_op(cfg, w, int8_mode=int8_mode)
     got = gh.run_op(op2, ids, lens, out, cfg["vocab_size"], top_k=1)
     assert op2.stats()["decode_path"] == 1
+    assert op2.stats()["persist_layout"] == (1 if variant in ("grid32", "grid48") else 0)  # (the layout under test really ran)
     for t in range(out):
         for b in range(B):
             _logit_close(got["logits"][t, b], ref["logits"][t, b])
@@ -294,6 +295,7 @@ def test_long_sequences_leave_the_single_pass_attention_forms(gh, tiny):
     assert r["sequence_lengths"].tolist() == o["sequence_lengths"].tolist()
 
 
+@pytest.mark.one_decode_path
 @pytest.mark.parametrize("int8_mode", [0, 1])
 def test_sequential_residual_layers_follow_hf_and_oracle(gh, tiny, int8_mode):
     """use_gptj_residual = 0: h = attn + bias + x ; x' = ffn(LN2(h)) + bias + h (GptNeoXDecoder.cc:313-331,362-367); the
@@ -466,6 +468,7 @@ def test_begin_step_finish_equals_forward(gh, tiny):
     assert seq[:, 0].cpu().numpy().tolist() == ref["sequence_lengths"].tolist()
 
 
+@pytest.mark.one_decode_path
 def test_invalid_requests_raise_and_leave_the_engine_usable(gh, tiny):
     """Argument errors come back as exceptions with a message (the reference TORCH_CHECKs / exits); the engine keeps working."""
     import torch
@@ -486,6 +489,7 @@ def test_invalid_requests_raise_and_leave_the_engine_usable(gh, tiny):
     assert r["output_ids"][0, 16:].tolist() == z["hf_tokens"].tolist()
 
 
+@pytest.mark.one_decode_path
 @pytest.mark.parametrize("int8_mode", [0, 1])
 def test_mid_model_long_ragged_prefill(gh, int8_mode):
     """Prefill kernels on shapes that cross their tile sizes: 257 / 130-token prompts (64-query and 64-key tiles of the MFMA
