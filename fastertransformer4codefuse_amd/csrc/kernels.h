@@ -274,7 +274,7 @@ struct RowsPlan {
     int    FX;            // ... of a leftover pair: each of the M nh % NB leftover pairs is shared by FX workgroups
     int    CR, cw;        // the layer boundary: column ranges per row (merger = row * CR + range), columns per range
     int    wcum[8];       // K shares of the seven streamer waves: wave s streams [n wcum[s] / wcum[7], n wcum[s + 1] / wcum[7]) of a
-                          // workgroup's n k-steps (the younger wave of a SIMD's pair issues behind the older one: FTCF_ROWS_WS)
+                          // workgroup's n k-steps (equal shares; unequal ones measured no better: profiles/r05_notes.md)
     size_t smem;
 };
 struct RowsParams {

@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(PS_NT) void k_decode_persistent(
     // table: they are streamed first, so qkv is complete -- and published -- well before the stage ends)
     const int NF  = Il / 16;
     // (NT0 / NB is not whole at 13B: 3.75 -> three of four workgroups stream 4 QKV groups, one streams 3, i.e. 720 vs 640
-    // tiles.  plan.qrot (FTCF_PERSIST_QROT, default 0) rotates WHICH workgroups get the light share: workgroup b runs on XCD
+    // tiles.  plan.qrot (1: kernels_persist.hip) rotates WHICH workgroups get the light share: workgroup b runs on XCD
     // b % 8 and the stamps show XCDs 2 / 6 ending P1 1.3 us after the others on equal shares; moving the light share onto
     // them measured +-0.3 %: whoever is last, the next hand-off waits for it)
     const int qb  = (bid + p.plan.qrot) % NB;
