@@ -2,6 +2,8 @@
 the path selection (persistent kernel, per-stage launches, general path with split-K / burst / tiled GEMMs), odd sizes
 (one head, inter sizes that are not powers of two, rotary 0 / partial / full, one-token prompts, ragged batches) and rows
 that finish on end_id."""
+import os
+
 import numpy as np
 import pytest
 import torch  # noqa: F401
@@ -10,6 +12,7 @@ from oracle import oracle as orc
 from tests.helpers import quantize_layers, random_model, weight_list_to_layers
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -71,3 +74,22 @@ def test_random_configuration_follows_the_oracle(gh, seed):
                 top2 = np.sort(ref)[-2:]
                 assert top2[1] - top2[0] <= 1e-2 * scale, ("token flip without a near tie", what, b, t)
                 break
+
+
+def test_own_group_layout_on_random_shapes_and_grids(gh):
+    """A fixed-seed slice of tools/fuzz_own_layout.py: the one- / two-row persistent kernel with the own-group layout of its out-proj /
+    FFN2 stage forced wherever the shape divides (FTCF_PERSIST_OWN=1) on random hidden sizes (64..1024), grids of 4..64 workgroups, one
+    and two rows, fp16 / int8 -- every case against the oracle (2 % of the logit range, arg max equal outside a near tie), and the
+    layout must really have run in a good part of them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_own_layout", os.path.join(ROOT, "tools", "fuzz_own_layout.py"))
+    mod = importlib.util.module_from_spec(spec)
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        spec.loader.exec_module(mod)
+        bad, own = mod.run(1, 16, verbose=False)
+    finally:
+        os.chdir(cwd)
+    assert bad == 0
+    assert own >= 4
